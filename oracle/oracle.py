@@ -1,0 +1,147 @@
+"""ctypes/numpy front-end of the CPU ORACLE (oracle/sparse_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``languagegroundedsemseg_amd/`` or
+``MinkowskiEngine/`` imports this module; it is used by ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg as the checker.
+
+Parity status: *unpinned against MinkowskiEngine 0.5.4* (un-vendored, absent; see the
+header of sparse_oracle.c) -- pinned against dense ``torch.nn.functional.conv3d`` /
+``conv_transpose3d`` known answers (tests/test_oracle_dense.py).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile sparse_oracle.c with gcc (needs no GPU)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "sparse_oracle.c"))):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        i64, i32, vp = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p
+        L.orc_unique_coords.restype = i64
+        L.orc_unique_coords.argtypes = [vp, i64, vp, vp]
+        L.orc_stride_coords.restype = i64
+        L.orc_stride_coords.argtypes = [vp, i64, i32, vp, vp]
+        L.orc_kernel_map.restype = i64
+        L.orc_kernel_map.argtypes = [vp, i64, vp, i64, ctypes.c_int, i32, vp, vp, vp]
+        L.orc_conv_forward.restype = None
+        L.orc_conv_forward.argtypes = [vp, i64, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, i64, vp, i64]
+        L.orc_conv_dgrad.restype = None
+        L.orc_conv_dgrad.argtypes = [vp, i64, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, i64, vp, i64]
+        L.orc_conv_wgrad.restype = None
+        L.orc_conv_wgrad.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, i64, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _coords(c):
+    c = np.ascontiguousarray(c, dtype=np.int32)
+    assert c.ndim == 2 and c.shape[1] == 4, "coords must be [N,4] (batch,x,y,z)"
+    return c
+
+
+def unique_coords(coords):
+    """-> (unique_index[nu] ascending, inverse[N]); first occurrence wins."""
+    c = _coords(coords)
+    n = c.shape[0]
+    ui = np.empty(max(n, 1), np.int64)
+    inv = np.empty(max(n, 1), np.int64)
+    nu = lib().orc_unique_coords(_p(c), n, _p(ui), _p(inv))
+    return ui[:nu].copy(), inv[:n].copy()
+
+
+def stride_coords(coords, ts_out):
+    """-> (out_coords[no,4], parent[N]): unique floor(c/ts_out)*ts_out, first-occurrence order."""
+    c = _coords(coords)
+    n = c.shape[0]
+    oc = np.empty((max(n, 1), 4), np.int32)
+    par = np.empty(max(n, 1), np.int64)
+    no = lib().orc_stride_coords(_p(c), n, int(ts_out), _p(oc), _p(par))
+    return oc[:no].copy(), par[:n].copy()
+
+
+def kernel_map(in_coords, out_coords, ks, ts_in):
+    """-> (k[M] int32, in_row[M] int64, out_row[M] int64) with c_in = c_out + off_k*ts_in."""
+    ci, co = _coords(in_coords), _coords(out_coords)
+    cap = max(co.shape[0] * ks ** 3, 1)
+    kk = np.empty(cap, np.int32)
+    ki = np.empty(cap, np.int64)
+    ko = np.empty(cap, np.int64)
+    m = lib().orc_kernel_map(_p(ci), ci.shape[0], _p(co), co.shape[0], int(ks), int(ts_in), _p(kk), _p(ki), _p(ko))
+    return kk[:m].copy(), ki[:m].copy(), ko[:m].copy()
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _km(km):
+    k, i, o = km
+    return (np.ascontiguousarray(k, np.int32), np.ascontiguousarray(i, np.int64), np.ascontiguousarray(o, np.int64))
+
+
+def conv_forward(x, w, km, n_out, bias=None):
+    """x[n_in,Cin], w[K,Cin,Cout] -> out[n_out,Cout]."""
+    x, w = _f32(x), _f32(w)
+    if w.ndim == 2:
+        w = w[None]
+    k, i, o = _km(km)
+    cin, cout = w.shape[1], w.shape[2]
+    assert x.shape[1] == cin
+    out = np.zeros((n_out, cout), np.float32)
+    b = _f32(bias).reshape(-1) if bias is not None else None
+    lib().orc_conv_forward(_p(x), x.shape[0], cin, _p(w), cout, _p(b) if b is not None else None,
+                           _p(k), _p(i), _p(o), k.shape[0], _p(out), n_out)
+    return out
+
+
+def conv_dgrad(gout, w, km, n_in):
+    gout, w = _f32(gout), _f32(w)
+    if w.ndim == 2:
+        w = w[None]
+    k, i, o = _km(km)
+    cin, cout = w.shape[1], w.shape[2]
+    assert gout.shape[1] == cout
+    gin = np.zeros((n_in, cin), np.float32)
+    lib().orc_conv_dgrad(_p(gout), gout.shape[0], cout, _p(w), cin, _p(k), _p(i), _p(o), k.shape[0], _p(gin), n_in)
+    return gin
+
+
+def conv_wgrad(x, gout, km, K):
+    x, gout = _f32(x), _f32(gout)
+    k, i, o = _km(km)
+    cin, cout = x.shape[1], gout.shape[1]
+    gw = np.zeros((K, cin, cout), np.float32)
+    lib().orc_conv_wgrad(_p(x), cin, _p(gout), cout, int(K), _p(k), _p(i), _p(o), k.shape[0], _p(gw))
+    return gw
+
+
+def transpose_map(km):
+    """Map of the transposed convolution that undoes `km` (in/out swapped, same k)."""
+    k, i, o = km
+    return k, o, i
+
+
+def canonical_order(coords):
+    """Row permutation that sorts coords lexicographically by (b,x,y,z) -- for set-equality checks."""
+    c = np.asarray(coords)
+    return np.lexsort((c[:, 3], c[:, 2], c[:, 1], c[:, 0]))
