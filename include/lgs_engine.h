@@ -1,0 +1,142 @@
+/*
+ * lgs_engine.h -- C-ABI of the MI355X-native sparse-voxel engine (liblgs_engine.so).
+ *
+ * This is the drop-in boundary UNDER the MinkowskiEngine Python operator surface that
+ * RozDavid/LanguageGroundedSemseg is written against.  The reference never binds native code
+ * for this path itself -- it calls MinkowskiEngine==0.5.4 (config/lg_semseg.yml:204) through
+ * Python -- so every entry point below cites the Python call site(s) of the reference whose
+ * work it performs.  The Python host code in languagegroundedsemseg_amd/me/ keeps the ME names
+ * (SparseTensor, MinkowskiConvolution, ...) and calls these functions through ctypes.
+ *
+ * Conventions
+ *   - plain C types only; no torch types.  All `const void*` / `void*` buffers are DEVICE
+ *     pointers owned by the caller (torch) and only borrowed for the duration of the call.
+ *   - every function enqueues on the HIP stream passed in `stream` (a hipStream_t cast to
+ *     void*; NULL = default stream) and does not synchronise, except the coordinate-map
+ *     builders that must return a row count to the host (documented per function).
+ *   - return value: 0 = OK, non-zero = error; lgs_last_error() returns the message of the
+ *     last failing call on this thread.  The Python side raises RuntimeError with it.
+ *   - a manager and everything it owns is not thread-safe; one manager per input batch
+ *     (ME semantics: maps/kernel maps are cached for exactly one forward+backward).
+ *   - coords are int32 [N,4] = (batch, x, y, z), batch in column 0
+ *     (/root/reference/lib/transforms.py:421, lib/train_test/pl_BaselineTrainer.py:294).
+ *     Supported range: batch in [0,1024), |x|,|y|,|z| < 131072 (checked; error otherwise).
+ *   - weights are float32 [K, Cin, Cout] (ME parameter layout), kernel-offset index
+ *     k enumerates the hypercube with the first spatial axis fastest; odd sizes centred, even
+ *     sizes one-sided.  1x1 convs use K = 1.
+ *   - features are row-major [N, C] in `dtype` (LGS_F32 or LGS_BF16); accumulation is fp32.
+ */
+#ifndef LGS_ENGINE_H
+#define LGS_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGS_ABI_VERSION 1
+
+enum lgs_dtype { LGS_F32 = 0, LGS_BF16 = 1 };
+
+typedef struct lgs_manager lgs_manager; /* coordinate manager: owns coordinate maps + kernel maps */
+typedef struct lgs_kmap lgs_kmap;       /* one cached kernel map (owned by its manager) */
+
+/* ---- library ---------------------------------------------------------------------------- */
+int lgs_abi_version(void);
+const char *lgs_last_error(void);
+
+/* ---- coordinate manager ------------------------------------------------------------------
+ * replaces: ME.SparseTensor(features, coordinates) -> CoordinateManager.insert_and_map
+ *   /root/reference/lib/train_test/pl_BaselineTrainer.py:300
+ *   /root/reference/lib/train_test/pl_RepresentationTrainer.py:183
+ *   /root/reference/downstream/insseg/lib/pl_Trainer.py:263                                  */
+int lgs_manager_create(int device, lgs_manager **out);
+int lgs_manager_destroy(lgs_manager *mgr);
+
+/* Insert coords[N,4] as the tensor-stride-1 map.  Dedups (first occurrence wins, surviving
+ * rows keep input order).  Writes the map key to *key and the unique-row count to *n_unique
+ * (host; this call synchronises `stream` once).
+ * unique_index (device int64[N], first n_unique valid) and inverse (device int64[N]) may be NULL. */
+int lgs_manager_insert(lgs_manager *mgr, const int32_t *coords, int64_t n, int64_t *unique_index,
+                       int64_t *inverse, void *stream, int *key, int64_t *n_unique);
+
+/* Coarsen map `in_key` by 2 per axis: unique floor(c / 2ts) * 2ts per batch.  Reuses the map if it
+ * already exists (ME: one map per tensor stride).  Synchronises `stream` once when it creates one.
+ * replaces: the output-coordinate generation inside conv(kernel_size=2, stride=2)
+ *   /root/reference/models/res16unet.py:49-56,66-73,83-90,100-107                              */
+int lgs_manager_stride2(lgs_manager *mgr, int in_key, void *stream, int *out_key, int64_t *n_out);
+
+/* Finer map that `key` was coarsened from (-1 if none); used by transposed convs to land on the
+ * cached map (/root/reference/models/res16unet.py:116-124 + me.cat at :237). */
+int lgs_manager_parent_of(lgs_manager *mgr, int key, int *fine_key);
+
+int lgs_manager_map_size(lgs_manager *mgr, int key, int64_t *n, int *tensor_stride);
+/* coords of map `key` into dst (device int32 [n,4]); replaces SparseTensor.C (pl_BaselineTrainer.py:384) */
+int lgs_manager_get_coords(lgs_manager *mgr, int key, int32_t *dst, void *stream);
+
+/* Kernel map between two maps of this manager (cached per (in_key,out_key,kernel_size)).
+ *   kernel_size 3, in_key == out_key            : 3x3x3 stride-1 (a4)
+ *   kernel_size 2, out_key == stride2(in_key)   : 2x2x2 stride-2 (a5); the transposed conv (a6)
+ *                                                 uses the same object with `transposed` views
+ *   kernel_size 1, in_key == out_key            : identity (a7)
+ * replaces: the implicit kernel-map construction in MinkowskiConvolution[Transpose].forward
+ *   /root/reference/models/modules/common.py:179-236                                           */
+int lgs_manager_kernel_map(lgs_manager *mgr, int in_key, int out_key, int kernel_size, void *stream,
+                           lgs_kmap **out);
+
+/* Export the map as (k, in_row, out_row) triples for set-equality parity tests.
+ * Pass NULL buffers to query *m only (synchronises). Buffers are device int32[*m]. */
+int lgs_kmap_export(lgs_kmap *km, int32_t *k, int32_t *in_row, int32_t *out_row, void *stream, int64_t *m);
+
+/* ---- sparse convolution --------------------------------------------------------------------
+ * replaces MinkowskiConvolution / MinkowskiConvolutionTranspose forward + autograd backward
+ *   /root/reference/models/modules/common.py:195-203 (conv), :228-236 (conv_tr)
+ *   call sites /root/reference/models/res16unet.py:196-270, models/modules/resnet_block.py:41-57
+ *
+ * `transposed` = 0: forward direction of the map (in rows -> out rows);
+ *                1: the transposed convolution (map's out rows -> map's in rows).
+ * `weight` is always the module's own parameter [K,Cin,Cout] (float32), Cin/Cout being THIS
+ * op's input/output channels.  `workspace` must hold lgs_conv_workspace_bytes(...) bytes. */
+int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype, int op /*0 fwd,1 dgrad,2 wgrad*/);
+
+/* out[n_out,cout] = conv(in[n_in,cin]) (+ bias[cout] if non-NULL) */
+int lgs_conv_forward(lgs_kmap *km, int transposed, const void *in, int cin, const float *weight, int cout,
+                     const float *bias, void *out, int dtype, void *workspace, void *stream);
+/* grad_in[n_in,cin] from grad_out[n_out,cout] */
+int lgs_conv_dgrad(lgs_kmap *km, int transposed, const void *grad_out, int cout, const float *weight, int cin,
+                   void *grad_in, int dtype, void *workspace, void *stream);
+/* grad_weight[K,cin,cout] (float32, overwritten) */
+int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const void *grad_out, int cout,
+                   float *grad_weight, int dtype, void *workspace, void *stream);
+
+/* ---- fused batch-norm / ReLU / residual ------------------------------------------------------
+ * replaces ME.MinkowskiBatchNorm (.bn = nn.BatchNorm1d over all rows) + MinkowskiReLU + `out += residual`
+ *   /root/reference/models/modules/common.py:17-19, models/modules/resnet_block.py:41-57
+ * Training-mode batch statistics over all n rows.  stats = float32 [2*C] workspace:
+ * on return mean[C], invstd[C].  running_mean/var (float32 [C]) updated with `momentum`
+ * (unbiased variance), may be NULL.  residual may be NULL.  y may alias x. */
+int lgs_bn_forward(const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps,
+                   float momentum, float *running_mean, float *running_var, const void *residual, int relu,
+                   void *y, float *stats, int dtype, void *stream);
+/* Backward of the fused op.  y is the forward OUTPUT (used for the ReLU mask), x the forward input.
+ * Writes dx, dgamma[C], dbeta[C]; if dresidual != NULL also the gradient flowing to the residual
+ * (= dy masked by ReLU).  stats = the forward's mean/invstd. */
+int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
+                    const float *stats, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta,
+                    int dtype, void *stream);
+
+/* ---- CLIP text-anchor contraction (MFMA) ----------------------------------------------------
+ * replaces ContrastiveLanguageLoss.feat_dist (cos) + feature_sim
+ *   /root/reference/lib/losses/ContrastiveLanguageLoss.py:73-95,185-192
+ *   /root/reference/lib/losses/utils.py:80-103
+ * S[n, n_anchor] = normalize(F)[n,c] . normalize(T)[n_anchor,c]^T, float32 out.
+ * inv_norm_f (float32 [n], may be NULL) receives 1/max(|f|,1e-12) for the backward. */
+int lgs_clip_similarity(const void *feat, int64_t n, int c, const float *anchors, int n_anchor, float *sim,
+                        float *inv_norm_f, int dtype, void *workspace, void *stream);
+int64_t lgs_clip_workspace_bytes(int c, int n_anchor, int dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LGS_ENGINE_H */

@@ -1,0 +1,11 @@
+"""languagegroundedsemseg_amd -- MI355X-native sparse-voxel engine behind the MinkowskiEngine
+operator surface used by RozDavid/LanguageGroundedSemseg's Res16UNet + CLIP-alignment hot path.
+
+Layout:
+  csrc/      hand-written HIP kernels + the C-ABI (include/lgs_engine.h)
+  engine.py  ctypes binding (fails loudly when the library is missing)
+  me/        host-side mirror of the MinkowskiEngine Python API (also importable as `MinkowskiEngine`)
+  models.py  the Res16UNet family reproduced on that surface (state-dict compatible)
+  losses.py  contrastive CLIP loss on the MFMA contraction
+"""
+__version__ = "0.1.0"

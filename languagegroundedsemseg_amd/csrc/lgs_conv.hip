@@ -1,0 +1,646 @@
+// lgs_conv.hip -- sparse convolution on gfx950: forward, dgrad, wgrad.
+//
+// Replaces the arithmetic of MinkowskiConvolution / MinkowskiConvolutionTranspose as called from
+//   /root/reference/models/modules/common.py:195-203,228-236  (conv(), conv_tr())
+//   /root/reference/models/modules/resnet_block.py:41-57       (BasicBlock.forward)
+//   /root/reference/models/res16unet.py:196-270                 (Res16UNetBase.forward)
+//
+// Formulation: OUTPUT-STATIONARY IMPLICIT GEMM.  A workgroup owns a tile of
+// Morton-consecutive output positions and a tile of output channels; for every kernel offset that has
+// any neighbour in the tile (wavefront-ballot bitmask built with the kernel map) it gathers the
+// neighbour rows straight from HBM into MFMA operand registers (16 B per lane, whole 32/64-byte row
+// pieces), multiplies by the offset's weight slice staged once per workgroup in LDS (pre-packed in
+// MFMA fragment order so the copy is linear and ds_read_b128 is conflict-free), and accumulates in
+// fp32.  Every output row is written exactly once: no atomics, deterministic.  dgrad is the same
+// kernel on transposed (and, for 3x3x3, mirrored) weights; transposed convs use the grouped view.
+//
+// MFMA use: v_mfma_f32_32x32x16_bf16 for bf16 storage, v_mfma_f32_32x32x2_f32 (exact fp32) for fp32.
+// Operands are swapped (weights = A, voxels = B) so a lane ends up owning 4 consecutive output
+// channels of one voxel -> 8/16-byte stores.  The reduction index (channel) is permuted identically on
+// both operands so every lane's load is 16 contiguous bytes.
+#include "lgs_common.h"
+
+namespace lgs {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+typedef uint16_t bf16_t;  // storage type tag for bf16 tensors
+
+template <typename T> struct Tr;
+template <> struct Tr<float> {
+  static constexpr int EPL = 4;  // elements per 16-byte load
+  static constexpr int LD = 4;   // 16-byte loads per lane per 32-channel chunk
+};
+template <> struct Tr<bf16_t> {
+  static constexpr int EPL = 8;
+  static constexpr int LD = 2;
+};
+
+__device__ inline float bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+__device__ inline uint16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ inline float ld_elem(const float *p) { return *p; }
+__device__ inline float ld_elem(const bf16_t *p) { return bf16_to_f32(*p); }
+
+// one 16-byte operand pair: bf16 = one 32x32x16 MFMA, fp32 = four 32x32x2 MFMAs
+template <typename T> __device__ inline void mma16(f32x16 &acc, const uint4 &w, const uint4 &f);
+template <> __device__ inline void mma16<bf16_t>(f32x16 &acc, const uint4 &w, const uint4 &f) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, f), acc, 0, 0, 0);
+}
+template <> __device__ inline void mma16<float>(f32x16 &acc, const uint4 &w, const uint4 &f) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(f.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(f.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(f.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(f.w), acc, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------ weight packing
+// dst[kd][c][nb][t][lane] (16 B each): element e of lane (j = lane&31, h = lane>>5) is
+//   Wsrc[g = c*32 + h*16 + t*EPL + e][o = nb*32 + j]   of weight matrix kd
+// where (g = gathered/reduction channel, o = output channel):
+//   plain      : Wsrc[g][o] = w[ks][g][o],        ks = kd
+//   transposed : Wsrc[g][o] = w[ks][o][g],        ks = mirror ? K-1-kd : kd      (dgrad)
+// Out-of-range g / o are zero (channel padding to multiples of 32).
+template <typename T>
+__global__ void k_pack_weights(const float *__restrict__ w, int K, int cin_w, int cout_w, int transposed, int mirror,
+                               int g_real, int o_real, int nc, int nb_total, uint4 *__restrict__ dst) {
+  constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)K * nc * nb_total * LD * 64;
+  if (idx >= total) return;
+  int lane = (int)(idx & 63);
+  int64_t r = idx >> 6;
+  int t = (int)(r % LD); r /= LD;
+  int nb = (int)(r % nb_total); r /= nb_total;
+  int c = (int)(r % nc);
+  int kd = (int)(r / nc);
+  int ks = (transposed && mirror) ? K - 1 - kd : kd;
+  int j = lane & 31, h = lane >> 5;
+  int o = nb * 32 + j;
+  float vals[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    int g = c * 32 + h * 16 + t * EPL + e;
+    float x = 0.f;
+    if (g < g_real && o < o_real)
+      x = transposed ? w[((int64_t)ks * cin_w + o) * cout_w + g] : w[((int64_t)ks * cin_w + g) * cout_w + o];
+    vals[e] = x;
+  }
+  uint4 out;
+  if constexpr (EPL == 4) {
+    out = make_uint4(__float_as_uint(vals[0]), __float_as_uint(vals[1]), __float_as_uint(vals[2]), __float_as_uint(vals[3]));
+  } else {
+    out.x = (uint32_t)f32_to_bf16(vals[0]) | ((uint32_t)f32_to_bf16(vals[1]) << 16);
+    out.y = (uint32_t)f32_to_bf16(vals[2]) | ((uint32_t)f32_to_bf16(vals[3]) << 16);
+    out.z = (uint32_t)f32_to_bf16(vals[4]) | ((uint32_t)f32_to_bf16(vals[5]) << 16);
+    out.w = (uint32_t)f32_to_bf16(vals[6]) | ((uint32_t)f32_to_bf16(vals[7]) << 16);
+  }
+  dst[idx] = out;
+}
+
+// pad rows [n, c] -> [n, cpad] (zero fill) for channel counts that are not a multiple of the load width
+template <typename T>
+__global__ void k_pad_rows(const T *__restrict__ src, int64_t n, int c, int cpad, T *__restrict__ dst) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * cpad) return;
+  int64_t r = i / cpad;
+  int ch = (int)(i % cpad);
+  dst[i] = ch < c ? src[r * c + ch] : (T)0;
+}
+
+// ------------------------------------------------------------------------------------ forward / dgrad
+// Tile: WM x WN waves; each wave owns RB*32 positions x NCB*32 output channels.
+template <typename T, int RB, int NCB, int WM, int WN>
+__global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__restrict__ in, int cin_real, int nc,
+                                                             const uint4 *__restrict__ wp, int nb_total,
+                                                             T *__restrict__ out, int cout_real,
+                                                             const float *__restrict__ bias,
+                                                             float *__restrict__ out_f32,
+                                                             const float *__restrict__ row_scale) {
+  constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = WM * RB * 32;
+  constexpr int WB = WN * NCB;            // weight blocks staged per step
+  constexpr int WCH = WB * LD * 64;       // uint4 per staged chunk
+  constexpr int WR = (WCH + NT - 1) / NT; // staging registers per thread
+  __shared__ uint4 lds[2][WCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int vx = lane & 31, h = lane >> 5;
+  const int64_t pos_wg = (int64_t)blockIdx.x * TM;
+  const int64_t pos_w = pos_wg + (int64_t)wm * RB * 32;
+  const int nb_wg = blockIdx.y * WB;  // first cout block of the workgroup
+  const int nb_w = nb_wg + wn * NCB;  // first cout block of this wave
+
+  // ---- which slots does this workgroup visit, with which weight matrix
+  uint32_t smask = 1;  // single slot
+  int kw_single = 0;
+  if (v.KS > 1) {
+    smask = 0;
+#pragma unroll
+    for (int g = 0; g < (TM + 63) / 64; ++g) smask |= v.mask64[pos_wg / 64 + g];
+  } else if (v.tile_k) {
+    kw_single = v.tile_k[pos_wg / 64];
+    if (kw_single < 0) return;  // padding group: nothing to write
+  }
+
+  f32x16 acc[RB][NCB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int nb = 0; nb < NCB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][nb][r] = 0.f;
+
+  // ---- issue-side iterator state
+  uint32_t rem = smask;           // slots not yet issued
+  int islot = -1, ichunk = nc;    // force "advance to first slot" on first call
+  int32_t idx_i[RB];              // gather rows of the slot being issued
+  auto load_idx = [&](int slot, int32_t (&dst)[RB]) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      int64_t p = pos_w + rb * 32 + vx;
+      dst[rb] = v.nbr ? v.nbr[(int64_t)slot * v.n_pad + p] : (p < v.n_in ? (int32_t)p : -1);
+    }
+  };
+  // advance to next (slot, chunk); returns false when exhausted
+  auto advance = [&]() -> bool {
+    if (++ichunk < nc) return true;
+    if (rem == 0) return false;
+    islot = __builtin_ctz(rem);
+    rem &= rem - 1;
+    ichunk = 0;
+    load_idx(islot, idx_i);
+    return true;
+  };
+  auto issue = [&](uint4 (&F)[RB][LD], uint4 (&wreg)[WR], uint32_t &act) {
+    act = 0;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const bool ok = idx_i[rb] >= 0;
+      if (__ballot(ok)) act |= 1u << rb;
+      const T *src = in + (int64_t)idx_i[rb] * cin_real + ichunk * 32 + h * 16;
+#pragma unroll
+      for (int t = 0; t < LD; ++t) {
+        const int ch = ichunk * 32 + h * 16 + t * EPL;
+        F[rb][t] = (ok && ch + EPL <= cin_real) ? *reinterpret_cast<const uint4 *>(src + t * EPL) : make_uint4(0, 0, 0, 0);
+      }
+    }
+    const int kw = v.KS > 1 ? (v.mirror ? v.K - 1 - islot : islot) : kw_single;
+    const uint4 *wsrc = wp + (((int64_t)kw * nc + ichunk) * nb_total + nb_wg) * (LD * 64);
+    const int wvalid = min(WB, nb_total - nb_wg) * LD * 64;
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+      int e = tid + i * NT;
+      wreg[i] = (e < wvalid) ? wsrc[e] : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto stage = [&](int buf, const uint4 (&wreg)[WR]) {
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+      int e = tid + i * NT;
+      if (e < WCH) lds[buf][e] = wreg[i];
+    }
+  };
+  auto compute = [&](int buf, const uint4 (&F)[RB][LD], uint32_t act) {
+    if (act == 0) return;
+#pragma unroll
+    for (int t = 0; t < LD; ++t) {
+      uint4 wf[NCB];
+#pragma unroll
+      for (int nb = 0; nb < NCB; ++nb) wf[nb] = lds[buf][((wn * NCB + nb) * LD + t) * 64 + lane];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        if (act & (1u << rb)) {
+#pragma unroll
+          for (int nb = 0; nb < NCB; ++nb) mma16<T>(acc[rb][nb], wf[nb], F[rb][t]);
+        }
+      }
+    }
+  };
+
+  uint4 F0[RB][LD], F1[RB][LD], wreg[WR];
+  uint32_t act0 = 0, act1 = 0;
+  bool more = advance();
+  if (more) {
+    issue(F0, wreg, act0);
+    stage(0, wreg);
+  }
+  __syncthreads();
+  while (more) {
+    // even phase: compute buffer 0 while buffer 1 fills
+    bool nxt = advance();
+    if (nxt) issue(F1, wreg, act1);
+    compute(0, F0, act0);
+    if (nxt) stage(1, wreg);
+    __syncthreads();
+    if (!nxt) break;
+    // odd phase
+    more = advance();
+    if (more) issue(F0, wreg, act0);
+    compute(1, F1, act1);
+    if (more) stage(0, wreg);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane (voxel vx, half h) owns channels nb*32 + 8q + 4h + {0..3}
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    int64_t p = pos_w + rb * 32 + vx;
+    int32_t orow = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
+    if (orow < 0) continue;
+    T *dst = out + (int64_t)orow * cout_real;
+    const float rs = (out_f32 && row_scale) ? row_scale[orow] : 1.f;
+#pragma unroll
+    for (int nb = 0; nb < NCB; ++nb) {
+      if (nb_w + nb >= nb_total) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int c0 = (nb_w + nb) * 32 + 8 * q + 4 * h;
+        if (c0 >= cout_real) continue;
+        float o0 = acc[rb][nb][4 * q + 0], o1 = acc[rb][nb][4 * q + 1], o2 = acc[rb][nb][4 * q + 2],
+              o3 = acc[rb][nb][4 * q + 3];
+        if (bias) { o0 += bias[c0]; o1 += bias[c0 + 1]; o2 += bias[c0 + 2]; o3 += bias[c0 + 3]; }
+        if (out_f32) {  // CLIP similarity: fp32 output, per-row scale (1/|f|)
+          *reinterpret_cast<float4 *>(out_f32 + (int64_t)orow * cout_real + c0) = make_float4(o0 * rs, o1 * rs, o2 * rs, o3 * rs);
+        } else if constexpr (EPL == 4) {
+          *reinterpret_cast<float4 *>(dst + c0) = make_float4(o0, o1, o2, o3);
+        } else {
+          uint2 pk;
+          pk.x = (uint32_t)f32_to_bf16(o0) | ((uint32_t)f32_to_bf16(o1) << 16);
+          pk.y = (uint32_t)f32_to_bf16(o2) | ((uint32_t)f32_to_bf16(o3) << 16);
+          *reinterpret_cast<uint2 *>(dst + c0) = pk;
+        }
+      }
+    }
+  }
+}
+
+// rows that no position of the view writes must still be defined: the forward output of a strided
+// map always covers every row, but a grouped view's padding never does -- nothing to do there.
+
+// ------------------------------------------------------------------------------------ wgrad (v1)
+// gw[k][ci][co] = sum over pairs (i,o) of offset k:  in[i][ci] * gout[o][co]
+// fp32 MFMA 32x32x2 (exact fp32 accumulate) for both storage types; pairs of a position chunk are
+// ballot-compacted into LDS in fixed wave order (deterministic), each wave owns one 32-channel ci block
+// and NCB co blocks, super-chunk partials are reduced by k_wgrad_reduce.
+constexpr int kWgChunk = 512;  // positions compacted per iteration
+
+template <typename T, int NCB>
+__global__ __launch_bounds__(256) void k_wgrad(View v, const T *__restrict__ in, int cin_real, const T *__restrict__ gout,
+                                               int cout_real, int cin_pad, int cout_pad, int64_t span,
+                                               float *__restrict__ partial) {
+  __shared__ int32_t l_in[kWgChunk], l_out[kWgChunk];
+  __shared__ int32_t l_cnt[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vx = lane & 31, h = lane >> 5;
+  const int k = blockIdx.y;
+  const int n_cot = cout_pad / (32 * NCB);
+  const int cot = blockIdx.z % n_cot, cig = blockIdx.z / n_cot;
+  const int cib = cig * 4 + wave;
+  const bool wave_active = cib * 32 < cin_pad;
+  const int slot = v.KS > 1 ? k : 0;
+
+  f32x16 acc[NCB];
+#pragma unroll
+  for (int nb = 0; nb < NCB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+  const int64_t p_begin = (int64_t)blockIdx.x * span;
+  const int64_t p_end = min(p_begin + span, v.n_pad);
+  for (int64_t base = p_begin; base < p_end; base += kWgChunk) {
+    // ---- compact valid pairs of this chunk (two positions per thread, fixed wave order)
+    int32_t my_in[2], my_out[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int64_t p = base + wave * 128 + u * 64 + lane;
+      int32_t i = -1, o = -1;
+      if (p < p_end) {
+        bool grp_ok = true;
+        if (v.KS > 1) grp_ok = (v.mask64[p >> 6] >> slot) & 1u;
+        else if (v.tile_k) grp_ok = v.tile_k[p >> 6] == k;
+        if (grp_ok) {
+          o = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
+          i = v.nbr ? v.nbr[(int64_t)slot * v.n_pad + p] : (p < v.n_in ? (int32_t)p : -1);
+        }
+      }
+      my_in[u] = (i >= 0 && o >= 0) ? i : -1;
+      my_out[u] = o;
+    }
+    unsigned long long bal0 = __ballot(my_in[0] >= 0), bal1 = __ballot(my_in[1] >= 0);
+    int c0 = (int)__builtin_popcountll(bal0), c1 = (int)__builtin_popcountll(bal1);
+    if (lane == 0) l_cnt[wave] = c0 + c1;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      int c = l_cnt[w];
+      if (w < wave) wbase += c;
+      total += c;
+    }
+    if (my_in[0] >= 0) {
+      int at = wbase + (int)__builtin_popcountll(bal0 & ((1ull << lane) - 1ull));
+      l_in[at] = my_in[0]; l_out[at] = my_out[0];
+    }
+    if (my_in[1] >= 0) {
+      int at = wbase + c0 + (int)__builtin_popcountll(bal1 & ((1ull << lane) - 1ull));
+      l_in[at] = my_in[1]; l_out[at] = my_out[1];
+    }
+    __syncthreads();
+    // ---- MFMA over the compacted pairs, two pairs (k = h) per 32x32x2 instruction
+    if (wave_active) {
+      const int ci = cib * 32 + vx;
+      for (int j = 0; j < total; j += 8) {
+        float a[4], b[4][NCB];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          int pr = j + 2 * u + h;
+          bool ok = pr < total;
+          int32_t irow = ok ? l_in[pr] : 0, orow = ok ? l_out[pr] : 0;
+          a[u] = (ok && ci < cin_real) ? ld_elem(in + (int64_t)irow * cin_real + ci) : 0.f;
+#pragma unroll
+          for (int nb = 0; nb < NCB; ++nb) {
+            int co = (cot * NCB + nb) * 32 + vx;
+            b[u][nb] = (ok && co < cout_real) ? ld_elem(gout + (int64_t)orow * cout_real + co) : 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int nb = 0; nb < NCB; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][nb], acc[nb], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (!wave_active) return;
+  // D[i = ci][j = co]: lane holds column j = vx, rows (r&3) + 8*(r>>2) + 4*h
+  float *dst = partial + (((int64_t)blockIdx.x * v.K + k) * cin_pad) * cout_pad;
+#pragma unroll
+  for (int nb = 0; nb < NCB; ++nb) {
+    int co = (cot * NCB + nb) * 32 + vx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int ci = cib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      dst[(int64_t)ci * cout_pad + co] = acc[nb][r];
+    }
+  }
+}
+
+__global__ void k_wgrad_reduce(const float *__restrict__ partial, int S, int K, int cin_pad, int cout_pad, int cin,
+                               int cout, float *__restrict__ gw) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)K * cin * cout;
+  if (idx >= total) return;
+  int co = (int)(idx % cout);
+  int ci = (int)((idx / cout) % cin);
+  int k = (int)(idx / ((int64_t)cout * cin));
+  float s = 0.f;
+  for (int x = 0; x < S; ++x) s += partial[(((int64_t)x * K + k) * cin_pad + ci) * cout_pad + co];
+  gw[idx] = s;
+}
+
+// ------------------------------------------------------------------------------------ host side
+inline int pad32(int c) { return (c + 31) / 32 * 32; }
+inline int esize(int dtype) { return dtype == LGS_BF16 ? 2 : 4; }
+inline int epl(int dtype) { return dtype == LGS_BF16 ? 8 : 4; }
+inline int64_t align256(int64_t b) { return (b + 255) / 256 * 256; }
+
+struct WgradPlan { int S; int64_t span; int cin_pad, cout_pad, ncb; };
+inline WgradPlan wgrad_plan(const View &v, int cin, int cout) {
+  WgradPlan p;
+  p.cin_pad = pad32(cin);
+  p.cout_pad = pad32(cout);
+  int nb = p.cout_pad / 32;
+  p.ncb = (nb % 4 == 0) ? 4 : (nb % 3 == 0) ? 3 : (nb % 2 == 0) ? 2 : 1;
+  int64_t chunks = (v.n_pad + kWgChunk - 1) / kWgChunk;
+  int64_t S = chunks / 4;
+  if (S < 1) S = 1;
+  if (S > 64) S = 64;
+  int64_t per = (int64_t)v.K * p.cin_pad * p.cout_pad * 4;
+  while (S > 1 && S * per > (1ll << 30)) S /= 2;
+  int64_t cps = (chunks + S - 1) / S;
+  p.span = cps * kWgChunk;
+  p.S = (int)((v.n_pad + p.span - 1) / p.span);
+  if (p.S < 1) p.S = 1;
+  return p;
+}
+
+template <typename T>
+int launch_gather(const View &v, const T *in, int cin_real, int nc, const uint4 *wp, int nb_total, T *out, int cout_real,
+                  const float *bias, hipStream_t s, float *out_f32 = nullptr, const float *row_scale = nullptr) {
+  if (v.n_pad == 0) return 0;
+  // Tile choice: big tiles (256 positions x up to 128 channels) when the map is large enough to
+  // fill 256 CUs, otherwise 64-position tiles with the channel dimension split over waves.
+  const bool big = v.n_pad >= 256 * 256;
+#define LGS_LAUNCH(RB, NCB, WM, WN)                                                                               \
+  do {                                                                                                            \
+    dim3 grid((unsigned)(v.n_pad / (WM * RB * 32)), (unsigned)((nb_total + WN * NCB - 1) / (WN * NCB)));         \
+    hipLaunchKernelGGL((k_conv_gather<T, RB, NCB, WM, WN>), grid, dim3(WM *WN * 64), 0, s, v, in, cin_real, nc, wp, \
+                       nb_total, out, cout_real, bias, out_f32, row_scale);                                       \
+  } while (0)
+  if (big) {
+    if (nb_total == 1) LGS_LAUNCH(2, 1, 4, 1);
+    else if (nb_total == 2) LGS_LAUNCH(2, 2, 4, 1);
+    else if (nb_total == 3 || nb_total % 3 == 0 && nb_total % 4 != 0) LGS_LAUNCH(2, 3, 4, 1);
+    else LGS_LAUNCH(2, 4, 4, 1);
+  } else {
+    if (nb_total == 1) LGS_LAUNCH(1, 1, 2, 1);
+    else LGS_LAUNCH(1, 1, 2, 2);
+  }
+#undef LGS_LAUNCH
+  LGS_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int conv_gather_op(const View &v, const void *in_v, int g_real, const float *weight, int K, int cin_w, int cout_w,
+                   int transposed_w, int o_real, const float *bias, void *out_v, void *workspace, hipStream_t s) {
+  constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
+  LGS_REQUIRE(o_real % 4 == 0, "sparse conv: output channel count must be a multiple of 4");
+  const int g_pad = pad32(g_real), nc = g_pad / 32, nb_total = pad32(o_real) / 32;
+  char *ws = reinterpret_cast<char *>(workspace);
+  uint4 *wp = reinterpret_cast<uint4 *>(ws);
+  int64_t wbytes = align256((int64_t)K * nc * nb_total * LD * 64 * 16);
+  const T *in = reinterpret_cast<const T *>(in_v);
+  int g_stride = g_real;
+  if (g_real % EPL != 0) {  // e.g. the 3-channel colour input of conv0p1s1
+    T *padded = reinterpret_cast<T *>(ws + wbytes);
+    int64_t tot = v.n_in * g_pad;
+    if (tot > 0) hipLaunchKernelGGL((k_pad_rows<T>), (unsigned)((tot + 255) / 256), 256, 0, s, in, v.n_in, g_real, g_pad, padded);
+    in = padded;
+    g_stride = g_pad;
+  }
+  int64_t total = (int64_t)K * nc * nb_total * LD * 64;
+  hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, weight, K, cin_w, cout_w, transposed_w,
+                     v.mirror, g_real, o_real, nc, nb_total, wp);
+  LGS_HIP(hipGetLastError());
+  return launch_gather<T>(v, in, g_stride, nc, wp, nb_total, reinterpret_cast<T *>(out_v), o_real, bias, s);
+}
+
+template <typename T>
+int conv_wgrad_op(const View &v, const void *in_v, int cin, const void *gout_v, int cout, float *gw, void *workspace,
+                  hipStream_t s) {
+  WgradPlan p = wgrad_plan(v, cin, cout);
+  float *partial = reinterpret_cast<float *>(workspace);
+  if (v.n_pad == 0) {
+    LGS_HIP(hipMemsetAsync(gw, 0, sizeof(float) * (size_t)v.K * cin * cout, s));
+    return 0;
+  }
+  const T *in = reinterpret_cast<const T *>(in_v);
+  const T *go = reinterpret_cast<const T *>(gout_v);
+  int n_cot = p.cout_pad / (32 * p.ncb);
+  int n_cig = (p.cin_pad / 32 + 3) / 4;
+  dim3 grid((unsigned)p.S, (unsigned)v.K, (unsigned)(n_cot * n_cig));
+  switch (p.ncb) {
+    case 4: hipLaunchKernelGGL((k_wgrad<T, 4>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
+    case 3: hipLaunchKernelGGL((k_wgrad<T, 3>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
+    case 2: hipLaunchKernelGGL((k_wgrad<T, 2>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
+    default: hipLaunchKernelGGL((k_wgrad<T, 1>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
+  }
+  int64_t total = (int64_t)v.K * cin * cout;
+  hipLaunchKernelGGL(k_wgrad_reduce, (unsigned)((total + 255) / 256), 256, 0, s, partial, p.S, v.K, p.cin_pad, p.cout_pad, cin,
+                     cout, gw);
+  LGS_HIP(hipGetLastError());
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------ CLIP contraction
+// S = normalize(F) . normalize(T)^T is the 1x1 "convolution" of the voxel features with the
+// normalised text anchors as the weight matrix, scaled per row by 1/|f|: it reuses the MFMA gather
+// kernel with the identity view.  (ContrastiveLanguageLoss.py:73-95, lib/losses/utils.py:80-103)
+template <typename T>
+__global__ void k_row_invnorm(const T *__restrict__ f, int64_t n, int c, float *__restrict__ inv) {
+  // one wavefront per row
+  int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  float s = 0.f;
+  for (int ch = lane; ch < c; ch += 64) { float x = ld_elem(f + row * c + ch); s += x * x; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) inv[row] = 1.f / fmaxf(sqrtf(s), 1e-12f);
+}
+__global__ void k_normalize_anchors(const float *__restrict__ a, int na, int c, float *__restrict__ out) {
+  int row = blockIdx.x;
+  int lane = threadIdx.x;
+  if (row >= na) return;
+  float s = 0.f;
+  for (int ch = lane; ch < c; ch += 64) { float x = a[(int64_t)row * c + ch]; s += x * x; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  float inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
+  for (int ch = lane; ch < c; ch += 64) out[(int64_t)row * c + ch] = a[(int64_t)row * c + ch] * inv;
+}
+
+template <typename T>
+int clip_similarity_t(const void *feat, int64_t n, int c, const float *anchors, int na, float *sim, float *inv_norm_f,
+                      void *workspace, hipStream_t s) {
+  constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
+  LGS_REQUIRE(c % EPL == 0, "lgs_clip_similarity: feature dim must be a multiple of the 16-byte load width");
+  LGS_REQUIRE(na % 4 == 0, "lgs_clip_similarity: anchor count must be a multiple of 4");
+  if (n == 0) return 0;
+  const int nc = pad32(c) / 32, nb_total = pad32(na) / 32;
+  char *ws = reinterpret_cast<char *>(workspace);
+  float *tn = reinterpret_cast<float *>(ws);
+  int64_t off = align256((int64_t)na * c * 4);
+  uint4 *wp = reinterpret_cast<uint4 *>(ws + off);
+  off += align256((int64_t)nc * nb_total * LD * 64 * 16);
+  float *inv = inv_norm_f ? inv_norm_f : reinterpret_cast<float *>(ws + off);
+  const T *f = reinterpret_cast<const T *>(feat);
+  hipLaunchKernelGGL(k_normalize_anchors, na, 64, 0, s, anchors, na, c, tn);
+  int64_t total = (int64_t)nc * nb_total * LD * 64;
+  // T^[a][c] read as w[o = a][g = c]  ("transposed" form of the packer with cin_w = na, cout_w = c)
+  hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, tn, 1, na, c, 1, 0, c, na, nc, nb_total, wp);
+  hipLaunchKernelGGL((k_row_invnorm<T>), (unsigned)((n * 64 + 255) / 256), 256, 0, s, f, n, c, inv);
+  View v;
+  v.n_pad = pad_rows(n); v.n_out = n; v.n_in = n; v.KS = 1; v.K = 1;
+  LGS_HIP(hipGetLastError());
+  return launch_gather<T>(v, f, c, nc, wp, nb_total, (T *)nullptr, na, nullptr, s, sim, inv);
+}
+
+}  // namespace lgs
+
+using namespace lgs;
+
+extern "C" {
+
+int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype, int op) {
+  if (!km) return -1;
+  const int e = esize(dtype);
+  if (op == 2) {
+    // the larger of the two views bounds the plan
+    WgradPlan a = wgrad_plan(km->fwd, cin, cout), b = wgrad_plan(km->bwd, cin, cout);
+    int64_t per = (int64_t)km->K * pad32(cin) * pad32(cout) * 4;
+    return align256((int64_t)(a.S > b.S ? a.S : b.S) * per) + 256;
+  }
+  int g = op == 0 ? cin : cout, o = op == 0 ? cout : cin;
+  int64_t bytes = align256((int64_t)km->K * pad32(g) * pad32(o) * e);
+  if (g % epl(dtype) != 0) {
+    int64_t nmax = km->fwd.n_in > km->bwd.n_in ? km->fwd.n_in : km->bwd.n_in;
+    bytes += align256(nmax * pad32(g) * e);
+  }
+  return bytes + 256;
+}
+
+int lgs_conv_forward(lgs_kmap *km, int transposed, const void *in, int cin, const float *weight, int cout,
+                     const float *bias, void *out, int dtype, void *workspace, void *stream) {
+  LGS_REQUIRE(km && weight && workspace, "lgs_conv_forward: null argument");
+  LGS_REQUIRE(!(transposed && km->ks == 3), "transposed 3x3x3 convolution is not part of the model family");
+  const View &v = transposed ? km->bwd : km->fwd;
+  View vv = v; vv.mirror = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LGS_F32) return conv_gather_op<float>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s);
+  if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s);
+  LGS_REQUIRE(false, "lgs_conv_forward: unknown dtype");
+}
+
+int lgs_conv_dgrad(lgs_kmap *km, int transposed, const void *grad_out, int cout, const float *weight, int cin,
+                   void *grad_in, int dtype, void *workspace, void *stream) {
+  LGS_REQUIRE(km && weight && workspace, "lgs_conv_dgrad: null argument");
+  LGS_REQUIRE(!(transposed && km->ks == 3), "transposed 3x3x3 convolution is not part of the model family");
+  const View &v = transposed ? km->fwd : km->bwd;  // the opposite direction of the forward
+  View vv = v; vv.mirror = (km->ks == 3) ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LGS_F32) return conv_gather_op<float>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s);
+  if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s);
+  LGS_REQUIRE(false, "lgs_conv_dgrad: unknown dtype");
+}
+
+int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const void *grad_out, int cout,
+                   float *grad_weight, int dtype, void *workspace, void *stream) {
+  LGS_REQUIRE(km && grad_weight && workspace, "lgs_conv_wgrad: null argument");
+  LGS_REQUIRE(!(transposed && km->ks == 3), "transposed 3x3x3 convolution is not part of the model family");
+  const View &v = transposed ? km->bwd : km->fwd;  // same view as the forward
+  View vv = v; vv.mirror = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LGS_F32) return conv_wgrad_op<float>(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
+  if (dtype == LGS_BF16) return conv_wgrad_op<bf16_t>(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
+  LGS_REQUIRE(false, "lgs_conv_wgrad: unknown dtype");
+}
+
+}  // extern "C"
+
+extern "C" {
+
+int64_t lgs_clip_workspace_bytes(int c, int n_anchor, int dtype) {
+  int64_t b = align256((int64_t)n_anchor * c * 4) + align256((int64_t)pad32(c) * pad32(n_anchor) * esize(dtype));
+  return b + 256;
+}
+
+int lgs_clip_similarity(const void *feat, int64_t n, int c, const float *anchors, int n_anchor, float *sim,
+                        float *inv_norm_f, int dtype, void *workspace, void *stream) {
+  LGS_REQUIRE(feat && anchors && sim && workspace && inv_norm_f, "lgs_clip_similarity: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LGS_F32) return clip_similarity_t<float>(feat, n, c, anchors, n_anchor, sim, inv_norm_f, workspace, s);
+  if (dtype == LGS_BF16) return clip_similarity_t<bf16_t>(feat, n, c, anchors, n_anchor, sim, inv_norm_f, workspace, s);
+  LGS_REQUIRE(false, "lgs_clip_similarity: unknown dtype");
+}
+
+}  // extern "C"

@@ -1,0 +1,621 @@
+// lgs_manager.hip -- coordinate manager + kernel-map construction for gfx950.
+//
+// Replaces (functionally) MinkowskiEngine's CoordinateManager as used by the reference:
+//   SparseTensor(feats, coords)            /root/reference/lib/train_test/pl_BaselineTrainer.py:300
+//   stride-2 output maps                    /root/reference/models/res16unet.py:49-107
+//   kernel maps for k in {1,2,3}            /root/reference/models/modules/common.py:179-236
+//
+// Design: every coordinate is packed into ONE 64-bit Morton key
+//   key = batch << 54 | interleave3(x + 2^17, y + 2^17, z + 2^17)
+// Level-0 rows keep the caller's order (logits stay row-aligned with the input), but every map also
+// carries its rows in Morton order (`order`: sorted position -> row).  Consequences:
+//   * coarsening by 2 is a bit-mask on the key and preserves the sort, so a strided map and its
+//     2x2x2 kernel map come from one flag+scan over the sorted keys -- no hashing;
+//   * 3x3x3 maps come from 27 probes per voxel into an open-addressing hash (64-bit atomicCAS build);
+//   * conv tiles are runs of 64 Morton-consecutive voxels, so a wavefront ballot gives the per-tile
+//     bitmask of kernel offsets that have any neighbour at all (planar surfaces miss most
+//     out-of-plane offsets), which the conv kernels use to skip work.
+#include "lgs_common.h"
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+namespace lgs {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+constexpr int kCoordBits = 18;
+constexpr int kBias = 1 << (kCoordBits - 1);  // 131072
+constexpr uint64_t kEmpty = ~0ull;
+
+__host__ __device__ inline uint64_t spread3(uint64_t x) {
+  x &= 0x1fffff;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+__host__ __device__ inline uint32_t compact3(uint64_t x) {
+  x &= 0x1249249249249249ull;
+  x = (x ^ (x >> 2)) & 0x10c30c30c30c30c3ull;
+  x = (x ^ (x >> 4)) & 0x100f00f00f00f00full;
+  x = (x ^ (x >> 8)) & 0x1f0000ff0000ffull;
+  x = (x ^ (x >> 16)) & 0x1f00000000ffffull;
+  x = (x ^ (x >> 32)) & 0x1fffff;
+  return (uint32_t)x;
+}
+__device__ inline uint64_t pack_key(int b, int xb, int yb, int zb) {  // biased coords
+  return ((uint64_t)b << 54) | spread3((uint64_t)xb) | (spread3((uint64_t)yb) << 1) | (spread3((uint64_t)zb) << 2);
+}
+__device__ inline void unpack_key(uint64_t key, int &b, int &xb, int &yb, int &zb) {
+  b = (int)(key >> 54);
+  uint64_t m = key & ((1ull << 54) - 1);
+  xb = (int)compact3(m);
+  yb = (int)compact3(m >> 1);
+  zb = (int)compact3(m >> 2);
+}
+__device__ inline uint64_t hash64(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return k;
+}
+
+// ------------------------------------------------------------------------------------------- kernels
+__global__ void k_pack_keys(const int32_t *coords, int64_t n, uint64_t *keys, int32_t *vals, int *err) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = reinterpret_cast<const int4 *>(coords)[i];
+  bool ok = c.x >= 0 && c.x < 1024 && c.y > -kBias && c.y < kBias - 64 && c.z > -kBias && c.z < kBias - 64 &&
+            c.w > -kBias && c.w < kBias - 64;
+  if (!ok) { atomicOr(err, 1); c = make_int4(0, 0, 0, 0); }
+  keys[i] = pack_key(c.x, c.y + kBias, c.z + kBias, c.w + kBias);
+  vals[i] = (int32_t)i;
+}
+
+// head[p] = 1 if sorted key p starts a new run of (key & keep_mask)
+__global__ void k_heads(const uint64_t *skeys, int64_t n, uint64_t keep_mask, int32_t *head) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  uint64_t k = skeys[p] & keep_mask;
+  head[p] = (p == 0 || (skeys[p - 1] & keep_mask) != k) ? 1 : 0;
+}
+
+// insert step: flag (by input index) the first occurrence of every distinct coordinate
+__global__ void k_mark_first(const int32_t *svals, const int32_t *head, int64_t n, int32_t *is_first) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  is_first[svals[p]] = head[p];
+}
+// urow = exclusive scan of is_first over input order; write coords/unique_index of surviving rows,
+// and the sorted-order arrays of the deduplicated map
+__global__ void k_emit_unique(const int32_t *coords, const int32_t *is_first, const int32_t *urow, int64_t n,
+                              int32_t *ucoords, int64_t *unique_index) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !is_first[i]) return;
+  int32_t u = urow[i];
+  reinterpret_cast<int4 *>(ucoords)[u] = reinterpret_cast<const int4 *>(coords)[i];
+  if (unique_index) unique_index[u] = i;
+}
+__global__ void k_emit_sorted(const uint64_t *skeys, const int32_t *svals, const int32_t *head,
+                              const int32_t *runid_incl, const int32_t *urow, int64_t n, uint64_t *ukeys,
+                              int32_t *order) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n || !head[p]) return;
+  int32_t q = runid_incl[p] - 1;
+  ukeys[q] = skeys[p];
+  order[q] = urow[svals[p]];
+}
+__global__ void k_emit_inverse(const int32_t *svals, const int32_t *runid_incl, const int32_t *order, int64_t n,
+                               int64_t *inverse) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  inverse[svals[p]] = order[runid_incl[p] - 1];
+}
+
+// stride-2: coarse rows are created in Morton order (row == sorted position)
+__global__ void k_emit_coarse(const uint64_t *fkeys, const int32_t *head, const int32_t *cidx_incl, int64_t n,
+                              uint64_t keep_mask, uint64_t *ckeys, int32_t *ccoords, int32_t *cstart,
+                              int32_t *fine_cidx) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  int32_t q = cidx_incl[p] - 1;
+  fine_cidx[p] = q;
+  if (head[p]) {
+    uint64_t k = fkeys[p] & keep_mask;
+    ckeys[q] = k;
+    cstart[q] = (int32_t)p;
+    int b, x, y, z;
+    unpack_key(k, b, x, y, z);
+    reinterpret_cast<int4 *>(ccoords)[q] = make_int4(b, x - kBias, y - kBias, z - kBias);
+  }
+  if (p == n - 1) cstart[q + 1] = (int32_t)n;
+}
+
+__global__ void k_hash_fill(uint64_t *hkeys, int64_t cap) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap) hkeys[i] = kEmpty;
+}
+__global__ void k_hash_insert(const uint64_t *skeys, const int32_t *order, int64_t n, uint64_t *hkeys,
+                              int32_t *hvals, uint64_t capm1) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  uint64_t key = skeys[p];
+  uint64_t s = hash64(key) & capm1;
+  for (;;) {
+    unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(hkeys + s), (unsigned long long)kEmpty,
+                                        (unsigned long long)key);
+    if (prev == kEmpty) { hvals[s] = order ? order[p] : (int32_t)p; return; }
+    s = (s + 1) & capm1;  // keys are unique here, no equality case
+  }
+}
+
+// 3x3x3 stride-1 map: one thread per sorted position, 27 probes; nbr is offset-major [27][n_pad]
+__global__ void k_build_map3(const uint64_t *skeys, int64_t n, int64_t n_pad, int ts, const uint64_t *hkeys,
+                             const int32_t *hvals, uint64_t capm1, int32_t *nbr, uint32_t *mask64) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // blockDim multiple of 64; p < n_pad by grid
+  bool live = p < n;
+  int b = 0, x = 0, y = 0, z = 0;
+  if (live) unpack_key(skeys[p], b, x, y, z);
+  uint32_t m = 0;
+  for (int k = 0; k < 27; ++k) {
+    int dx = (k % 3 - 1) * ts, dy = ((k / 3) % 3 - 1) * ts, dz = (k / 9 - 1) * ts;
+    int32_t r = -1;
+    if (live) {
+      int xx = x + dx, yy = y + dy, zz = z + dz;
+      if (((unsigned)xx | (unsigned)yy | (unsigned)zz) < (1u << kCoordBits)) {
+        uint64_t key = pack_key(b, xx, yy, zz);
+        uint64_t s = hash64(key) & capm1;
+        for (;;) {
+          uint64_t hk = hkeys[s];
+          if (hk == key) { r = hvals[s]; break; }
+          if (hk == kEmpty) break;
+          s = (s + 1) & capm1;
+        }
+      }
+    }
+    nbr[(int64_t)k * n_pad + p] = r;
+    unsigned long long bal = __ballot(r >= 0);
+    if (bal) m |= 1u << k;
+  }
+  if ((threadIdx.x & 63) == 0) mask64[p >> 6] = m;
+}
+
+// 2x2x2 stride-2, coarse-stationary view: nbr8[k][q] = fine row of child k of coarse row q
+__global__ void k_build_map2_coarse(const uint64_t *fkeys, const int32_t *forder, const int32_t *cstart,
+                                    int64_t n_c, int64_t nc_pad, int shift, int32_t *nbr8, uint32_t *mask64) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int32_t child[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) child[k] = -1;
+  if (q < n_c) {
+    int32_t s = cstart[q], e = cstart[q + 1];
+    for (int32_t p = s; p < e; ++p) {
+      int k = (int)((fkeys[p] >> shift) & 7);
+      int32_t row = forder ? forder[p] : p;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j == k) child[j] = row;
+    }
+  }
+  uint32_t m = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    nbr8[(int64_t)k * nc_pad + q] = child[k];
+    if (__ballot(child[k] >= 0)) m |= 1u << k;
+  }
+  if ((threadIdx.x & 63) == 0) mask64[q >> 6] = m;
+}
+
+// fine-grouped (degree-1) view: fine positions sorted by child index k, each group padded to 256
+__global__ void k_child_keys(const uint64_t *fkeys, int64_t n, int shift, uint32_t *kk, int32_t *pp, int32_t *cnt) {
+  __shared__ int32_t h[8];
+  if (threadIdx.x < 8) h[threadIdx.x] = 0;
+  __syncthreads();
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) {
+    uint32_t k = (uint32_t)((fkeys[p] >> shift) & 7);
+    kk[p] = k;
+    pp[p] = (int32_t)p;
+    atomicAdd(&h[k], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && h[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void k_group_offsets(const int32_t *cnt, int32_t *goff /*[9] padded starts*/, int32_t *gsrc /*[9] plain starts*/) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int32_t a = 0, b = 0;
+    for (int k = 0; k < 8; ++k) {
+      goff[k] = a; gsrc[k] = b;
+      a += (cnt[k] + kPadRows - 1) / kPadRows * kPadRows;
+      b += cnt[k];
+    }
+    goff[8] = a; gsrc[8] = b;
+  }
+}
+__global__ void k_fill_i32(int32_t *p, int64_t n, int32_t v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void k_build_map2_fine(const uint32_t *kk_sorted, const int32_t *pp_sorted, int64_t n, const int32_t *goff,
+                                  const int32_t *gsrc, const int32_t *fine_cidx, const int32_t *forder,
+                                  int32_t *g_nbr, int32_t *g_out, int32_t *tile_k) {
+  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  int k = (int)kk_sorted[s];
+  int32_t p = pp_sorted[s];
+  int32_t slot = goff[k] + ((int32_t)s - gsrc[k]);
+  g_nbr[slot] = fine_cidx[p];
+  g_out[slot] = forder ? forder[p] : p;
+  if (((s - gsrc[k]) & (kGroup - 1)) == 0) tile_k[slot >> 6] = k;
+}
+
+// export helpers (parity tests): count pairs of a view then write (k, in, out) triples
+__global__ void k_view_count(View v, int32_t *count) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= v.n_pad) return;
+  int32_t orow = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
+  int c = 0;
+  if (orow >= 0) {
+    if (!v.nbr) c = 1;
+    else
+      for (int s = 0; s < v.KS; ++s) c += v.nbr[(int64_t)s * v.n_pad + p] >= 0;
+  }
+  if (c) atomicAdd(count, c);
+}
+__global__ void k_view_export(View v, int32_t *cursor, int32_t *ek, int32_t *ein, int32_t *eout) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= v.n_pad) return;
+  int32_t orow = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
+  if (orow < 0) return;
+  for (int s = 0; s < v.KS; ++s) {
+    int32_t i = v.nbr ? v.nbr[(int64_t)s * v.n_pad + p] : (int32_t)p;
+    if (i < 0) continue;
+    int k = v.tile_k ? v.tile_k[p >> 6] : (v.mirror ? v.K - 1 - s : s);
+    int32_t at = atomicAdd(cursor, 1);
+    ek[at] = k; ein[at] = i; eout[at] = orow;
+  }
+}
+
+struct CoordMap {
+  int ts = 1, log2ts = 0;
+  int64_t n = 0, n_pad = 0;
+  int32_t *coords = nullptr;  // [n,4]
+  int32_t *order = nullptr;   // sorted position -> row; nullptr = identity
+  uint64_t *skeys = nullptr;  // sorted Morton keys [n]
+  uint64_t *hkeys = nullptr;  // hash (lazy)
+  int32_t *hvals = nullptr;
+  int64_t hcap = 0;
+  int fine_key = -1, coarse_key = -1;
+  int32_t *cstart = nullptr;     // [n+1] first fine sorted position of each row (maps made by stride2)
+  int32_t *fine_cidx = nullptr;  // [n_fine] coarse row of each fine sorted position
+};
+
+}  // namespace lgs
+
+using namespace lgs;
+
+struct lgs_manager {
+  int device = 0;
+  hipStream_t last_stream = nullptr;
+  std::vector<CoordMap> maps;
+  std::vector<lgs_kmap *> kmaps;
+  std::vector<void *> allocs;
+  int *d_err = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int dalloc(lgs_manager *m, T **p, int64_t count, hipStream_t s) {
+  void *q = nullptr;
+  size_t bytes = sizeof(T) * (size_t)(count > 0 ? count : 1);
+  LGS_HIP(hipMallocAsync(&q, bytes, s));
+  m->allocs.push_back(q);
+  *p = reinterpret_cast<T *>(q);
+  return 0;
+}
+int dfree_now(lgs_manager *m, void *q, hipStream_t s) {  // temp buffer: release early
+  for (size_t i = 0; i < m->allocs.size(); ++i)
+    if (m->allocs[i] == q) { m->allocs[i] = m->allocs.back(); m->allocs.pop_back(); break; }
+  LGS_HIP(hipFreeAsync(q, s));
+  return 0;
+}
+inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t > 0 ? (n + t - 1) / t : 1); }
+
+int ensure_hash(lgs_manager *m, CoordMap &cm, hipStream_t s) {
+  if (cm.hkeys) return 0;
+  int64_t cap = 1024;
+  while (cap < 2 * cm.n) cap <<= 1;
+  cm.hcap = cap;
+  if (dalloc(m, &cm.hkeys, cap, s)) return 1;
+  if (dalloc(m, &cm.hvals, cap, s)) return 1;
+  hipLaunchKernelGGL(k_hash_fill, nblk(cap), 256, 0, s, cm.hkeys, cap);
+  if (cm.n > 0)
+    hipLaunchKernelGGL(k_hash_insert, nblk(cm.n), 256, 0, s, cm.skeys, cm.order, cm.n, cm.hkeys, cm.hvals,
+                       (uint64_t)(cap - 1));
+  LGS_HIP(hipGetLastError());
+  return 0;
+}
+
+int scan_incl(lgs_manager *m, const int32_t *in, int32_t *out, int64_t n, hipStream_t s) {
+  size_t tb = 0;
+  LGS_HIP(rocprim::inclusive_scan(nullptr, tb, in, out, (size_t)n, rocprim::plus<int32_t>(), s));
+  void *tmp = nullptr;
+  LGS_HIP(hipMallocAsync(&tmp, tb ? tb : 16, s));
+  LGS_HIP(rocprim::inclusive_scan(tmp, tb, in, out, (size_t)n, rocprim::plus<int32_t>(), s));
+  LGS_HIP(hipFreeAsync(tmp, s));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lgs_abi_version(void) { return LGS_ABI_VERSION; }
+const char *lgs_last_error(void) { return g_err.c_str(); }
+
+int lgs_manager_create(int device, lgs_manager **out) {
+  LGS_REQUIRE(out != nullptr, "lgs_manager_create: null out");
+  LGS_HIP(hipSetDevice(device));
+  hipMemPool_t pool;
+  LGS_HIP(hipDeviceGetDefaultMemPool(&pool, device));
+  uint64_t thr = UINT64_MAX;  // keep freed blocks cached: the maps of step t+1 reuse step t's memory
+  LGS_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr));
+  lgs_manager *m = new lgs_manager();
+  m->device = device;
+  *out = m;
+  return 0;
+}
+
+int lgs_manager_destroy(lgs_manager *m) {
+  if (!m) return 0;
+  (void)hipSetDevice(m->device);
+  for (void *p : m->allocs) (void)hipFreeAsync(p, m->last_stream);
+  for (lgs_kmap *k : m->kmaps) delete k;
+  delete m;
+  return 0;
+}
+
+int lgs_manager_insert(lgs_manager *m, const int32_t *coords, int64_t n, int64_t *unique_index, int64_t *inverse,
+                       void *stream, int *key, int64_t *n_unique) {
+  LGS_REQUIRE(m && key && n_unique, "lgs_manager_insert: null argument");
+  LGS_REQUIRE(m->maps.empty(), "lgs_manager_insert: manager already holds a stride-1 map");
+  LGS_REQUIRE(n >= 0 && n < (1ll << 31) - 1024, "lgs_manager_insert: row count out of range");
+  hipStream_t s = (hipStream_t)stream;
+  LGS_HIP(hipSetDevice(m->device));
+  m->last_stream = s;
+  CoordMap cm;
+  if (n == 0) {
+    cm.n = 0; cm.n_pad = 0;
+    m->maps.push_back(cm);
+    *key = 0; *n_unique = 0;
+    return 0;
+  }
+  if (!m->d_err) { if (dalloc(m, &m->d_err, 1, s)) return 1; }
+  LGS_HIP(hipMemsetAsync(m->d_err, 0, sizeof(int), s));
+  uint64_t *keys, *skeys; int32_t *vals, *svals, *head, *runid, *is_first, *urow;
+  if (dalloc(m, &keys, n, s) || dalloc(m, &skeys, n, s) || dalloc(m, &vals, n, s) || dalloc(m, &svals, n, s) ||
+      dalloc(m, &head, n, s) || dalloc(m, &runid, n, s) || dalloc(m, &is_first, n, s) || dalloc(m, &urow, n + 1, s))
+    return 1;
+  hipLaunchKernelGGL(k_pack_keys, nblk(n), 256, 0, s, coords, n, keys, vals, m->d_err);
+  {
+    size_t tb = 0;
+    LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, skeys, vals, svals, (size_t)n, 0, 64, s));
+    void *tmp = nullptr;
+    LGS_HIP(hipMallocAsync(&tmp, tb ? tb : 16, s));
+    LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, keys, skeys, vals, svals, (size_t)n, 0, 64, s));
+    LGS_HIP(hipFreeAsync(tmp, s));
+  }
+  hipLaunchKernelGGL(k_heads, nblk(n), 256, 0, s, skeys, n, ~0ull, head);
+  hipLaunchKernelGGL(k_mark_first, nblk(n), 256, 0, s, svals, head, n, is_first);
+  if (scan_incl(m, head, runid, n, s)) return 1;
+  {  // exclusive scan of is_first = inclusive shifted: urow[0]=0, urow[i+1] = incl[i]
+    LGS_HIP(hipMemsetAsync(urow, 0, sizeof(int32_t), s));
+    if (scan_incl(m, is_first, urow + 1, n, s)) return 1;
+  }
+  int32_t h_nu = 0; int h_err = 0;
+  LGS_HIP(hipMemcpyAsync(&h_nu, urow + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  LGS_HIP(hipMemcpyAsync(&h_err, m->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+  LGS_HIP(hipStreamSynchronize(s));
+  LGS_REQUIRE(h_err == 0,
+              "lgs_manager_insert: coordinate out of range (batch must be in [0,1024), |x|,|y|,|z| < 131008)");
+  int64_t nu = h_nu;
+  cm.n = nu; cm.n_pad = pad_rows(nu);
+  if (dalloc(m, &cm.coords, nu * 4, s) || dalloc(m, &cm.order, nu, s) || dalloc(m, &cm.skeys, nu, s)) return 1;
+  hipLaunchKernelGGL(k_emit_unique, nblk(n), 256, 0, s, coords, is_first, urow, n, cm.coords, unique_index);
+  hipLaunchKernelGGL(k_emit_sorted, nblk(n), 256, 0, s, skeys, svals, head, runid, urow, n, cm.skeys, cm.order);
+  if (inverse) hipLaunchKernelGGL(k_emit_inverse, nblk(n), 256, 0, s, svals, runid, cm.order, n, inverse);
+  LGS_HIP(hipGetLastError());
+  if (dfree_now(m, keys, s) || dfree_now(m, skeys, s) || dfree_now(m, vals, s) || dfree_now(m, svals, s) ||
+      dfree_now(m, head, s) || dfree_now(m, runid, s) || dfree_now(m, is_first, s) || dfree_now(m, urow, s))
+    return 1;
+  m->maps.push_back(cm);
+  *key = 0; *n_unique = nu;
+  return 0;
+}
+
+int lgs_manager_stride2(lgs_manager *m, int in_key, void *stream, int *out_key, int64_t *n_out) {
+  LGS_REQUIRE(m && out_key && n_out, "lgs_manager_stride2: null argument");
+  LGS_REQUIRE(in_key >= 0 && in_key < (int)m->maps.size(), "lgs_manager_stride2: bad key");
+  hipStream_t s = (hipStream_t)stream;
+  LGS_HIP(hipSetDevice(m->device));
+  m->last_stream = s;
+  if (m->maps[in_key].coarse_key >= 0) {
+    *out_key = m->maps[in_key].coarse_key; *n_out = m->maps[*out_key].n;
+    return 0;
+  }
+  CoordMap f = m->maps[in_key];
+  LGS_REQUIRE(f.log2ts < 12, "lgs_manager_stride2: tensor stride too large");
+  CoordMap c;
+  c.ts = f.ts * 2; c.log2ts = f.log2ts + 1; c.fine_key = in_key;
+  int64_t n = f.n;
+  if (n == 0) {
+    m->maps.push_back(c);
+    m->maps[in_key].coarse_key = (int)m->maps.size() - 1;
+    *out_key = m->maps[in_key].coarse_key; *n_out = 0;
+    return 0;
+  }
+  uint64_t keep = ~(7ull << (3 * f.log2ts));
+  int32_t *head, *cincl;
+  if (dalloc(m, &head, n, s) || dalloc(m, &cincl, n, s)) return 1;
+  hipLaunchKernelGGL(k_heads, nblk(n), 256, 0, s, f.skeys, n, keep, head);
+  if (scan_incl(m, head, cincl, n, s)) return 1;
+  int32_t h_nc = 0;
+  LGS_HIP(hipMemcpyAsync(&h_nc, cincl + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  LGS_HIP(hipStreamSynchronize(s));
+  int64_t nc = h_nc;
+  c.n = nc; c.n_pad = pad_rows(nc);
+  if (dalloc(m, &c.coords, nc * 4, s) || dalloc(m, &c.skeys, nc, s) || dalloc(m, &c.cstart, nc + 1, s) ||
+      dalloc(m, &c.fine_cidx, n, s))
+    return 1;
+  hipLaunchKernelGGL(k_emit_coarse, nblk(n), 256, 0, s, f.skeys, head, cincl, n, keep, c.skeys, c.coords, c.cstart,
+                     c.fine_cidx);
+  LGS_HIP(hipGetLastError());
+  if (dfree_now(m, head, s) || dfree_now(m, cincl, s)) return 1;
+  m->maps.push_back(c);
+  int ck = (int)m->maps.size() - 1;
+  m->maps[in_key].coarse_key = ck;
+  *out_key = ck; *n_out = nc;
+  return 0;
+}
+
+int lgs_manager_parent_of(lgs_manager *m, int key, int *fine_key) {
+  LGS_REQUIRE(m && fine_key && key >= 0 && key < (int)m->maps.size(), "lgs_manager_parent_of: bad argument");
+  *fine_key = m->maps[key].fine_key;
+  return 0;
+}
+
+int lgs_manager_map_size(lgs_manager *m, int key, int64_t *n, int *tensor_stride) {
+  LGS_REQUIRE(m && key >= 0 && key < (int)m->maps.size(), "lgs_manager_map_size: bad key");
+  if (n) *n = m->maps[key].n;
+  if (tensor_stride) *tensor_stride = m->maps[key].ts;
+  return 0;
+}
+
+int lgs_manager_get_coords(lgs_manager *m, int key, int32_t *dst, void *stream) {
+  LGS_REQUIRE(m && key >= 0 && key < (int)m->maps.size(), "lgs_manager_get_coords: bad key");
+  const CoordMap &cm = m->maps[key];
+  if (cm.n > 0)
+    LGS_HIP(hipMemcpyAsync(dst, cm.coords, sizeof(int32_t) * 4 * (size_t)cm.n, hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+  return 0;
+}
+
+int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void *stream, lgs_kmap **out) {
+  LGS_REQUIRE(m && out, "lgs_manager_kernel_map: null argument");
+  int nm = (int)m->maps.size();
+  LGS_REQUIRE(in_key >= 0 && in_key < nm && out_key >= 0 && out_key < nm, "lgs_manager_kernel_map: bad key");
+  for (lgs_kmap *k : m->kmaps)
+    if (k->in_key == in_key && k->out_key == out_key && k->ks == ks) { *out = k; return 0; }
+  hipStream_t s = (hipStream_t)stream;
+  LGS_HIP(hipSetDevice(m->device));
+  m->last_stream = s;
+  lgs_kmap *km = new lgs_kmap();
+  km->mgr = m; km->in_key = in_key; km->out_key = out_key; km->ks = ks;
+  CoordMap &ci = m->maps[in_key];
+  if (ks == 1) {
+    LGS_REQUIRE(in_key == out_key, "kernel_size 1 needs in_key == out_key");
+    km->K = 1;
+    View v; v.n_pad = ci.n_pad; v.n_out = ci.n; v.n_in = ci.n; v.KS = 1; v.K = 1;
+    km->fwd = v; km->bwd = v;
+  } else if (ks == 3) {
+    LGS_REQUIRE(in_key == out_key, "kernel_size 3 is supported for stride 1 (in_key == out_key) only");
+    km->K = 27;
+    int32_t *nbr = nullptr; uint32_t *mask = nullptr;
+    if (ci.n > 0) {
+      if (ensure_hash(m, ci, s)) return 1;
+      if (dalloc(m, &nbr, 27 * ci.n_pad, s) || dalloc(m, &mask, ci.n_pad / kGroup, s)) return 1;
+      hipLaunchKernelGGL(k_build_map3, (unsigned)(ci.n_pad / 256), 256, 0, s, ci.skeys, ci.n, ci.n_pad, ci.ts, ci.hkeys,
+                         ci.hvals, (uint64_t)(ci.hcap - 1), nbr, mask);
+      LGS_HIP(hipGetLastError());
+    }
+    View v; v.nbr = nbr; v.mask64 = mask; v.out_row = ci.order; v.n_pad = ci.n_pad; v.n_out = ci.n; v.n_in = ci.n;
+    v.KS = 27; v.K = 27;
+    if (ci.order) {  // padded copy of `order` so positions >= n read -1
+      int32_t *orow;
+      if (dalloc(m, &orow, ci.n_pad > 0 ? ci.n_pad : 1, s)) return 1;
+      if (ci.n_pad > 0) {
+        hipLaunchKernelGGL(k_fill_i32, nblk(ci.n_pad), 256, 0, s, orow, ci.n_pad, -1);
+        LGS_HIP(hipMemcpyAsync(orow, ci.order, sizeof(int32_t) * (size_t)ci.n, hipMemcpyDeviceToDevice, s));
+      }
+      v.out_row = orow;
+    }
+    km->fwd = v;
+    km->bwd = v; km->bwd.mirror = 1;
+  } else if (ks == 2) {
+    CoordMap &co = m->maps[out_key];
+    LGS_REQUIRE(co.fine_key == in_key, "kernel_size 2 needs out_key == stride2(in_key)");
+    km->K = 8;
+    int shift = 3 * ci.log2ts;
+    View vf, vb;
+    vf.KS = 8; vf.K = 8; vf.n_pad = co.n_pad; vf.n_out = co.n; vf.n_in = ci.n;
+    vb.KS = 1; vb.K = 8; vb.n_out = ci.n; vb.n_in = co.n;
+    if (ci.n > 0) {
+      int32_t *nbr8; uint32_t *mask;
+      if (dalloc(m, &nbr8, 8 * co.n_pad, s) || dalloc(m, &mask, co.n_pad / kGroup, s)) return 1;
+      hipLaunchKernelGGL(k_build_map2_coarse, (unsigned)(co.n_pad / 256), 256, 0, s, ci.skeys, ci.order, co.cstart, co.n,
+                         co.n_pad, shift, nbr8, mask);
+      vf.nbr = nbr8; vf.mask64 = mask;
+      // grouped fine view
+      int64_t n = ci.n, gp = pad_rows(n + 8 * kPadRows);
+      uint32_t *kk, *kks; int32_t *pp, *pps, *cnt, *goff, *gsrc, *g_nbr, *g_out, *tile_k;
+      if (dalloc(m, &kk, n, s) || dalloc(m, &kks, n, s) || dalloc(m, &pp, n, s) || dalloc(m, &pps, n, s) ||
+          dalloc(m, &cnt, 8, s) || dalloc(m, &goff, 9, s) || dalloc(m, &gsrc, 9, s) || dalloc(m, &g_nbr, gp, s) ||
+          dalloc(m, &g_out, gp, s) || dalloc(m, &tile_k, gp / kGroup, s))
+        return 1;
+      LGS_HIP(hipMemsetAsync(cnt, 0, 8 * sizeof(int32_t), s));
+      hipLaunchKernelGGL(k_child_keys, nblk(n), 256, 0, s, ci.skeys, n, shift, kk, pp, cnt);
+      {
+        size_t tb = 0;
+        LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, kk, kks, pp, pps, (size_t)n, 0, 3, s));
+        void *tmp = nullptr;
+        LGS_HIP(hipMallocAsync(&tmp, tb ? tb : 16, s));
+        LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, kk, kks, pp, pps, (size_t)n, 0, 3, s));
+        LGS_HIP(hipFreeAsync(tmp, s));
+      }
+      hipLaunchKernelGGL(k_group_offsets, 1, 64, 0, s, cnt, goff, gsrc);
+      hipLaunchKernelGGL(k_fill_i32, nblk(gp), 256, 0, s, g_nbr, gp, -1);
+      hipLaunchKernelGGL(k_fill_i32, nblk(gp), 256, 0, s, g_out, gp, -1);
+      hipLaunchKernelGGL(k_fill_i32, nblk(gp / kGroup), 256, 0, s, tile_k, gp / kGroup, -1);
+      hipLaunchKernelGGL(k_build_map2_fine, nblk(n), 256, 0, s, kks, pps, n, goff, gsrc, co.fine_cidx, ci.order, g_nbr,
+                         g_out, tile_k);
+      LGS_HIP(hipGetLastError());
+      vb.nbr = g_nbr; vb.out_row = g_out; vb.tile_k = tile_k; vb.n_pad = gp;
+      if (dfree_now(m, kk, s) || dfree_now(m, kks, s) || dfree_now(m, pp, s) || dfree_now(m, pps, s) ||
+          dfree_now(m, cnt, s) || dfree_now(m, goff, s) || dfree_now(m, gsrc, s))
+        return 1;
+    }
+    km->fwd = vf; km->bwd = vb;
+  } else {
+    delete km;
+    LGS_REQUIRE(false, "unsupported kernel_size (the model family uses 1, 2 and 3 only)");
+  }
+  m->kmaps.push_back(km);
+  *out = km;
+  return 0;
+}
+
+int lgs_kmap_export(lgs_kmap *km, int32_t *ek, int32_t *ein, int32_t *eout, void *stream, int64_t *mcount) {
+  LGS_REQUIRE(km && mcount, "lgs_kmap_export: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  lgs_manager *m = km->mgr;
+  LGS_HIP(hipSetDevice(m->device));
+  const View &v = km->fwd;
+  int32_t *cnt;
+  LGS_HIP(hipMallocAsync((void **)&cnt, sizeof(int32_t), s));
+  LGS_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), s));
+  if (v.n_pad > 0) {
+    if (ek) hipLaunchKernelGGL(k_view_export, nblk(v.n_pad), 256, 0, s, v, cnt, ek, ein, eout);
+    else hipLaunchKernelGGL(k_view_count, nblk(v.n_pad), 256, 0, s, v, cnt);
+  }
+  int32_t h = 0;
+  LGS_HIP(hipMemcpyAsync(&h, cnt, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  LGS_HIP(hipStreamSynchronize(s));
+  LGS_HIP(hipFreeAsync(cnt, s));
+  *mcount = h;
+  return 0;
+}
+
+}  // extern "C"

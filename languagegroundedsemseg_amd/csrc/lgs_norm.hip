@@ -1,0 +1,286 @@
+// lgs_norm.hip -- fused BatchNorm (+ residual add) (+ ReLU) over sparse-tensor rows, gfx950.
+//
+// Replaces ME.MinkowskiBatchNorm (.bn = nn.BatchNorm1d on .F), MinkowskiReLU and `out += residual`
+//   /root/reference/models/modules/common.py:17-19          get_norm()
+//   /root/reference/models/modules/resnet_block.py:41-57     conv -> norm -> relu -> conv -> norm -> += -> relu
+//   /root/reference/models/res16unet.py:196-270              conv -> bn -> relu chains
+//
+// Pure HBM-bound streaming work: features are [N, C] row-major with C in
+// {32..512}; a thread owns a fixed group of 4 (fp32) or 8 (bf16) adjacent channels = one 16-byte
+// access and walks rows, so every wave instruction is a fully coalesced 1 KiB access.  Statistics
+// are reduced per block in LDS, then across blocks through a [blocks, 2C] fp32 scratch that the last
+// block (agent-scope ticket) folds in a fixed order -> deterministic, no float atomics.
+#include "lgs_common.h"
+
+namespace lgs {
+
+typedef uint16_t bf16_t;
+__device__ inline float bf2f(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+__device__ inline uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+  static constexpr int W = 4;
+  __device__ static void load(const float *p, float (&v)[4]) {
+    float4 x = *reinterpret_cast<const float4 *>(p);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  }
+  __device__ static void store(float *p, const float (&v)[4]) {
+    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct Vec<bf16_t> {
+  static constexpr int W = 8;
+  __device__ static void load(const bf16_t *p, float (&v)[8]) {
+    uint4 x = *reinterpret_cast<const uint4 *>(p);
+    uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = bf2f((uint16_t)(w[i] & 0xffff)); v[2 * i + 1] = bf2f((uint16_t)(w[i] >> 16)); }
+  }
+  __device__ static void store(bf16_t *p, const float (&v)[8]) {
+    uint4 x;
+    x.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    x.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    x.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+    x.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    *reinterpret_cast<uint4 *>(p) = x;
+  }
+};
+
+constexpr int kNT = 256;
+
+// Column reduction of up to two per-element quantities.  MODE 0: (x, x*x)  [forward statistics]
+// MODE 1: (dy', dy' * xhat) where dy' = dy masked by (y > 0) when relu  [backward reductions]
+// Each block handles a contiguous slab of rows; thread layout: cg = tid % G channel groups, rl = tid / G.
+// out: scratch[blocks][2][C]
+template <typename T, int MODE>
+__global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy,
+                                                   const float *__restrict__ stats, int64_t n, int c, int relu,
+                                                   int64_t rows_per_block, float *__restrict__ scratch) {
+  constexpr int W = Vec<T>::W;
+  const int G = c / W;              // channel groups per row
+  const int RL = kNT / G;           // rows in flight per block iteration (G <= 256)
+  const int cg = threadIdx.x % G, rl = threadIdx.x / G;
+  const bool active = rl < RL;
+  float s0[W], s1[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) s0[i] = s1[i] = 0.f;
+  float mean[W], istd[W];
+  if (MODE == 1) {
+#pragma unroll
+    for (int i = 0; i < W; ++i) { mean[i] = stats[cg * W + i]; istd[i] = stats[c + cg * W + i]; }
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(r0 + rows_per_block, n);
+  if (active) {
+    for (int64_t r = r0 + rl; r < r1; r += RL) {
+      float xv[W];
+      Vec<T>::load(x + r * c + cg * W, xv);
+      if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < W; ++i) { s0[i] += xv[i]; s1[i] += xv[i] * xv[i]; }
+      } else {
+        float gv[W];
+        Vec<T>::load(dy + r * c + cg * W, gv);
+        if (relu) {
+          float yv[W];
+          Vec<T>::load(y + r * c + cg * W, yv);
+#pragma unroll
+          for (int i = 0; i < W; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < W; ++i) { s0[i] += gv[i]; s1[i] += gv[i] * (xv[i] - mean[i]) * istd[i]; }
+      }
+    }
+  }
+  // block reduction over rl through LDS
+  __shared__ float red[2][kNT][8];
+#pragma unroll
+  for (int i = 0; i < W; ++i) { red[0][threadIdx.x][i] = s0[i]; red[1][threadIdx.x][i] = s1[i]; }
+  __syncthreads();
+  if (rl == 0) {
+    for (int j = 1; j < RL; ++j) {
+#pragma unroll
+      for (int i = 0; i < W; ++i) { s0[i] += red[0][j * G + cg][i]; s1[i] += red[1][j * G + cg][i]; }
+    }
+    float *dst = scratch + (int64_t)blockIdx.x * 2 * c;
+#pragma unroll
+    for (int i = 0; i < W; ++i) { dst[cg * W + i] = s0[i]; dst[c + cg * W + i] = s1[i]; }
+  }
+}
+
+// fold the per-block partials (fixed order) and finish: forward -> mean / invstd / running stats,
+// backward -> dbeta = sum dy', dgamma = sum dy' xhat  (kept in `out` as [2][C])
+__global__ void k_fold_fwd(const float *__restrict__ scratch, int nblocks, int c, int64_t n, float eps, float momentum,
+                           float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ stats) {
+  int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nblocks; ++b) { s += scratch[(int64_t)b * 2 * c + ch]; ss += scratch[(int64_t)b * 2 * c + c + ch]; }
+  double mean = n > 0 ? s / (double)n : 0.0;
+  double var = n > 0 ? ss / (double)n - mean * mean : 0.0;
+  if (var < 0.0) var = 0.0;
+  stats[ch] = (float)mean;
+  stats[c + ch] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
+    running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+    running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+  }
+}
+__global__ void k_fold_bwd(const float *__restrict__ scratch, int nblocks, int c, float *__restrict__ dgamma,
+                           float *__restrict__ dbeta, float *__restrict__ sums) {
+  int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nblocks; ++b) { s += scratch[(int64_t)b * 2 * c + ch]; ss += scratch[(int64_t)b * 2 * c + c + ch]; }
+  dbeta[ch] = (float)s;
+  dgamma[ch] = (float)ss;
+  sums[ch] = (float)s;
+  sums[c + ch] = (float)ss;
+}
+
+// y = relu?( (x - mean) * invstd * gamma + beta (+ residual) )
+template <typename T>
+__global__ __launch_bounds__(kNT) void k_bn_apply(const T *__restrict__ x, const T *__restrict__ res, int64_t n, int c,
+                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                  const float *__restrict__ stats, int relu, T *__restrict__ y) {
+  constexpr int W = Vec<T>::W;
+  const int64_t total = n * (int64_t)(c / W);
+  for (int64_t i = (int64_t)blockIdx.x * kNT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kNT) {
+    const int cg = (int)(i % (c / W));
+    float xv[W], rv[W];
+    Vec<T>::load(x + i * W, xv);
+    if (res) Vec<T>::load(res + i * W, rv);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const int ch = cg * W + k;
+      float sc = stats[c + ch] * gamma[ch];
+      float o = (xv[k] - stats[ch]) * sc + beta[ch];
+      if (res) o += rv[k];
+      xv[k] = (relu && o < 0.f) ? 0.f : o;
+    }
+    Vec<T>::store(y + i * W, xv);
+  }
+}
+
+// dx = gamma*invstd * (dy' - mean(dy') - xhat * mean(dy' xhat));  dres = dy'
+template <typename T>
+__global__ __launch_bounds__(kNT) void k_bn_bwd_apply(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy,
+                                                      int64_t n, int c, const float *__restrict__ gamma,
+                                                      const float *__restrict__ stats, const float *__restrict__ sums,
+                                                      int relu, T *__restrict__ dx, T *__restrict__ dres) {
+  constexpr int W = Vec<T>::W;
+  const int64_t total = n * (int64_t)(c / W);
+  const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * kNT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kNT) {
+    const int cg = (int)(i % (c / W));
+    float xv[W], gv[W];
+    Vec<T>::load(x + i * W, xv);
+    Vec<T>::load(dy + i * W, gv);
+    if (relu) {
+      float yv[W];
+      Vec<T>::load(y + i * W, yv);
+#pragma unroll
+      for (int k = 0; k < W; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
+    }
+    if (dres) Vec<T>::store(dres + i * W, gv);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const int ch = cg * W + k;
+      const float istd = stats[c + ch];
+      const float xh = (xv[k] - stats[ch]) * istd;
+      xv[k] = gamma[ch] * istd * (gv[k] - sums[ch] * inv_n - xh * sums[c + ch] * inv_n);
+    }
+    Vec<T>::store(dx + i * W, xv);
+  }
+}
+
+inline int reduce_blocks(int64_t n, int64_t *rows_per_block) {
+  int64_t nb = (n + 511) / 512;
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  *rows_per_block = (n + nb - 1) / nb;
+  if (*rows_per_block < 1) *rows_per_block = 1;
+  return (int)((n + *rows_per_block - 1) / *rows_per_block > 0 ? (n + *rows_per_block - 1) / *rows_per_block : 1);
+}
+
+template <typename T>
+int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const float *beta, float eps, float momentum,
+                 float *rm, float *rv, const void *res, int relu, void *yv, float *stats, hipStream_t s) {
+  constexpr int W = Vec<T>::W;
+  LGS_REQUIRE(c % W == 0 && c / W <= kNT && c <= 2048, "lgs_bn_forward: channel count unsupported");
+  int64_t rpb;
+  int nb = reduce_blocks(n, &rpb);
+  float *scratch = nullptr;
+  LGS_HIP(hipMallocAsync((void **)&scratch, sizeof(float) * 2 * (size_t)c * nb, s));
+  const T *x = reinterpret_cast<const T *>(xv);
+  hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, n, c, 0,
+                     rpb, scratch);
+  hipLaunchKernelGGL(k_fold_fwd, (c + 63) / 64, 64, 0, s, scratch, nb, c, n, eps, momentum, rm, rv, stats);
+  int64_t total = n * (int64_t)(c / W);
+  if (total > 0) {
+    int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
+    hipLaunchKernelGGL((k_bn_apply<T>), grid, kNT, 0, s, x, reinterpret_cast<const T *>(res), n, c, gamma, beta, stats, relu,
+                       reinterpret_cast<T *>(yv));
+  }
+  LGS_HIP(hipGetLastError());
+  LGS_HIP(hipFreeAsync(scratch, s));
+  return 0;
+}
+
+template <typename T>
+int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *gamma, const float *stats,
+                  int relu, void *dxv, void *dresv, float *dgamma, float *dbeta, hipStream_t s) {
+  constexpr int W = Vec<T>::W;
+  LGS_REQUIRE(c % W == 0 && c / W <= kNT && c <= 2048, "lgs_bn_backward: channel count unsupported");
+  int64_t rpb;
+  int nb = reduce_blocks(n, &rpb);
+  float *scratch = nullptr;
+  LGS_HIP(hipMallocAsync((void **)&scratch, sizeof(float) * 2 * (size_t)c * (nb + 1), s));
+  float *sums = scratch + (size_t)2 * c * nb;
+  const T *x = reinterpret_cast<const T *>(xv), *y = reinterpret_cast<const T *>(yv), *dy = reinterpret_cast<const T *>(dyv);
+  hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, x, y, dy, stats, n, c, relu, rpb, scratch);
+  hipLaunchKernelGGL(k_fold_bwd, (c + 63) / 64, 64, 0, s, scratch, nb, c, dgamma, dbeta, sums);
+  int64_t total = n * (int64_t)(c / W);
+  if (total > 0) {
+    int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
+    hipLaunchKernelGGL((k_bn_bwd_apply<T>), grid, kNT, 0, s, x, y, dy, n, c, gamma, stats, sums, relu, reinterpret_cast<T *>(dxv),
+                       reinterpret_cast<T *>(dresv));
+  }
+  LGS_HIP(hipGetLastError());
+  LGS_HIP(hipFreeAsync(scratch, s));
+  return 0;
+}
+
+}  // namespace lgs
+
+using namespace lgs;
+
+extern "C" {
+
+int lgs_bn_forward(const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps, float momentum,
+                   float *running_mean, float *running_var, const void *residual, int relu, void *y, float *stats,
+                   int dtype, void *stream) {
+  LGS_REQUIRE(x && y && gamma && beta && stats, "lgs_bn_forward: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LGS_F32) return bn_forward_t<float>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, y, stats, s);
+  if (dtype == LGS_BF16) return bn_forward_t<bf16_t>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, y, stats, s);
+  LGS_REQUIRE(false, "lgs_bn_forward: unknown dtype");
+}
+
+int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma, const float *stats,
+                    int relu, void *dx, void *dresidual, float *dgamma, float *dbeta, int dtype, void *stream) {
+  LGS_REQUIRE(x && dy && dx && gamma && stats && dgamma && dbeta, "lgs_bn_backward: null argument");
+  LGS_REQUIRE(!relu || y, "lgs_bn_backward: relu needs the forward output");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LGS_F32) return bn_backward_t<float>(x, y, dy, n, c, gamma, stats, relu, dx, dresidual, dgamma, dbeta, s);
+  if (dtype == LGS_BF16) return bn_backward_t<bf16_t>(x, y, dy, n, c, gamma, stats, relu, dx, dresidual, dgamma, dbeta, s);
+  LGS_REQUIRE(false, "lgs_bn_backward: unknown dtype");
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+"""ctypes binding of the C-ABI in include/lgs_engine.h (liblgs_engine.so).
+
+This is the only place the product path touches native code, and it FAILS LOUDLY: if the
+library is missing or a call returns non-zero a RuntimeError is raised -- there is no CPU or
+PyTorch fallback anywhere in this package.
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+LGS_F32, LGS_BF16 = 0, 1
+
+_lib = None
+
+# every symbol include/lgs_engine.h declares; tests check the built library exports all of them
+EXPORTS = [
+    "lgs_abi_version", "lgs_last_error",
+    "lgs_manager_create", "lgs_manager_destroy", "lgs_manager_insert", "lgs_manager_stride2",
+    "lgs_manager_parent_of", "lgs_manager_map_size", "lgs_manager_get_coords", "lgs_manager_kernel_map",
+    "lgs_kmap_export",
+    "lgs_conv_workspace_bytes", "lgs_conv_forward", "lgs_conv_dgrad", "lgs_conv_wgrad",
+    "lgs_bn_forward", "lgs_bn_backward",
+    "lgs_clip_similarity", "lgs_clip_workspace_bytes",
+]
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def lib():
+    """Load (once) the engine. Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "liblgs_engine.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or languagegroundedsemseg_amd.build.build()). There is no fallback path." % path)
+    L = ctypes.CDLL(path)
+    vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    pi, pi64, pvp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_void_p)
+    cf = ctypes.c_float
+    L.lgs_abi_version.restype = ci
+    L.lgs_abi_version.argtypes = []
+    L.lgs_last_error.restype = ctypes.c_char_p
+    L.lgs_last_error.argtypes = []
+    sig = {
+        "lgs_manager_create": [ci, pvp],
+        "lgs_manager_destroy": [vp],
+        "lgs_manager_insert": [vp, vp, i64, vp, vp, vp, pi, pi64],
+        "lgs_manager_stride2": [vp, ci, vp, pi, pi64],
+        "lgs_manager_parent_of": [vp, ci, pi],
+        "lgs_manager_map_size": [vp, ci, pi64, pi],
+        "lgs_manager_get_coords": [vp, ci, vp, vp],
+        "lgs_manager_kernel_map": [vp, ci, ci, ci, vp, pvp],
+        "lgs_kmap_export": [vp, vp, vp, vp, vp, pi64],
+        "lgs_conv_forward": [vp, ci, vp, ci, vp, ci, vp, vp, ci, vp, vp],
+        "lgs_conv_dgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp],
+        "lgs_conv_wgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp],
+        "lgs_bn_forward": [vp, i64, ci, vp, vp, cf, cf, vp, vp, vp, ci, vp, vp, ci, vp],
+        "lgs_bn_backward": [vp, vp, vp, i64, ci, vp, vp, ci, vp, vp, vp, vp, ci, vp],
+        "lgs_clip_similarity": [vp, i64, ci, vp, ci, vp, vp, ci, vp, vp],
+    }
+    for name, args in sig.items():
+        f = getattr(L, name)
+        f.restype = ci
+        f.argtypes = args
+    L.lgs_conv_workspace_bytes.restype = i64
+    L.lgs_conv_workspace_bytes.argtypes = [vp, ci, ci, ci, ci]
+    L.lgs_clip_workspace_bytes.restype = i64
+    L.lgs_clip_workspace_bytes.argtypes = [ci, ci, ci]
+    if L.lgs_abi_version() != 1:
+        raise RuntimeError("liblgs_engine.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().lgs_last_error()
+        raise RuntimeError("lgs_engine: " + (msg.decode(errors="replace") if msg else "error %d" % rc))

@@ -1,0 +1,237 @@
+"""HIP backend: the product path.  Every call goes through the C-ABI (include/lgs_engine.h).
+
+Tensors stay owned by torch; the engine borrows raw device pointers for the duration of a call and
+enqueues on torch's current HIP stream.  There is no fallback: a CPU tensor or a missing library
+raises RuntimeError.
+"""
+import ctypes
+
+import torch
+
+from .. import engine
+
+_vp = ctypes.c_void_p
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return _vp(t.data_ptr()) if t is not None else _vp(None)
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return engine.LGS_F32
+    if t.dtype == torch.bfloat16:
+        return engine.LGS_BF16
+    raise RuntimeError("lgs_engine supports float32 and bfloat16 features, got %s" % t.dtype)
+
+
+def _require_dev(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on a HIP device (got %s): the MI355X engine has no CPU fallback"
+                           % (what, t.device))
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+class HipKernelMap:
+    def __init__(self, mgr, handle, in_key, out_key, ks):
+        self.mgr, self.h, self.in_key, self.out_key, self.ks = mgr, handle, in_key, out_key, ks
+        self.K = ks ** 3
+
+    def export(self):
+        L = engine.lib()
+        m = ctypes.c_int64(0)
+        with torch.cuda.device(self.mgr.device):
+            engine.check(L.lgs_kmap_export(self.h, None, None, None, _stream(), ctypes.byref(m)))
+            n = m.value
+            k = torch.empty(n, dtype=torch.int32, device=self.mgr.device)
+            i = torch.empty_like(k)
+            o = torch.empty_like(k)
+            if n:
+                engine.check(L.lgs_kmap_export(self.h, _ptr(k), _ptr(i), _ptr(o), _stream(), ctypes.byref(m)))
+        return k, i, o
+
+    def _rows(self, transposed):
+        n_in = self.mgr.map_size(self.in_key)
+        n_out = self.mgr.map_size(self.out_key)
+        return (n_out, n_in) if transposed else (n_in, n_out)
+
+    def conv_forward(self, x, weight, bias, transposed):
+        _require_dev(x, "features")
+        L = engine.lib()
+        x = x.contiguous()
+        w = weight.detach().reshape(self.K, -1, weight.shape[-1]).contiguous().float()
+        cin, cout = w.shape[1], w.shape[2]
+        n_in, n_out = self._rows(transposed)
+        assert x.shape[0] == n_in and x.shape[1] == cin, (x.shape, n_in, cin)
+        dt = _dtype_code(x)
+        with torch.cuda.device(x.device):
+            out = torch.empty((n_out, cout), dtype=x.dtype, device=x.device)
+            ws = _ws(L.lgs_conv_workspace_bytes(self.h, cin, cout, dt, 0), x.device)
+            b = bias.detach().reshape(-1).contiguous().float() if bias is not None else None
+            engine.check(L.lgs_conv_forward(self.h, int(transposed), _ptr(x), cin, _ptr(w), cout, _ptr(b), _ptr(out), dt,
+                                            _ptr(ws), _stream()))
+        return out
+
+    def conv_dgrad(self, gout, weight, transposed):
+        L = engine.lib()
+        gout = gout.contiguous()
+        w = weight.detach().reshape(self.K, -1, weight.shape[-1]).contiguous().float()
+        cin, cout = w.shape[1], w.shape[2]
+        n_in, n_out = self._rows(transposed)
+        assert gout.shape[0] == n_out and gout.shape[1] == cout
+        dt = _dtype_code(gout)
+        with torch.cuda.device(gout.device):
+            gin = torch.empty((n_in, cin), dtype=gout.dtype, device=gout.device)
+            ws = _ws(L.lgs_conv_workspace_bytes(self.h, cin, cout, dt, 1), gout.device)
+            engine.check(L.lgs_conv_dgrad(self.h, int(transposed), _ptr(gout), cout, _ptr(w), cin, _ptr(gin), dt, _ptr(ws),
+                                          _stream()))
+        return gin
+
+    def conv_wgrad(self, x, gout, transposed):
+        L = engine.lib()
+        x, gout = x.contiguous(), gout.contiguous()
+        cin, cout = x.shape[1], gout.shape[1]
+        dt = _dtype_code(x)
+        assert gout.dtype == x.dtype
+        with torch.cuda.device(x.device):
+            gw = torch.empty((self.K, cin, cout), dtype=torch.float32, device=x.device)
+            ws = _ws(L.lgs_conv_workspace_bytes(self.h, cin, cout, dt, 2), x.device)
+            engine.check(L.lgs_conv_wgrad(self.h, int(transposed), _ptr(x), cin, _ptr(gout), cout, _ptr(gw), dt, _ptr(ws),
+                                          _stream()))
+        return gw
+
+
+class HipManager:
+    """One per input batch (ME semantics); owns the coordinate maps and kernel maps on the device."""
+
+    def __init__(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("the MI355X engine needs a HIP device, got %s (no CPU fallback)" % device)
+        self.device = device if device.index is not None else torch.device("cuda", torch.cuda.current_device())
+        h = _vp(None)
+        engine.check(engine.lib().lgs_manager_create(self.device.index, ctypes.byref(h)))
+        self.h = h
+        self._sizes = {}
+        self._kmaps = {}
+        self._coords = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                engine.lib().lgs_manager_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def insert(self, coords):
+        _require_dev(coords, "coordinates")
+        L = engine.lib()
+        coords = coords.to(torch.int32).contiguous()
+        n = coords.shape[0]
+        key, nu = ctypes.c_int(0), ctypes.c_int64(0)
+        with torch.cuda.device(self.device):
+            ui = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+            inv = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+            engine.check(L.lgs_manager_insert(self.h, _ptr(coords), n, _ptr(ui), _ptr(inv), _stream(), ctypes.byref(key),
+                                              ctypes.byref(nu)))
+        self._sizes[key.value] = (nu.value, 1)
+        return key.value, nu.value, ui[:nu.value], inv[:n]
+
+    def stride2(self, key):
+        L = engine.lib()
+        ok, n = ctypes.c_int(0), ctypes.c_int64(0)
+        with torch.cuda.device(self.device):
+            engine.check(L.lgs_manager_stride2(self.h, key, _stream(), ctypes.byref(ok), ctypes.byref(n)))
+        self._sizes[ok.value] = (n.value, self._sizes[key][1] * 2)
+        return ok.value
+
+    def parent_of(self, key):
+        fk = ctypes.c_int(-1)
+        engine.check(engine.lib().lgs_manager_parent_of(self.h, key, ctypes.byref(fk)))
+        return fk.value
+
+    def map_size(self, key):
+        return self._sizes[key][0]
+
+    def tensor_stride(self, key):
+        return self._sizes[key][1]
+
+    def coords(self, key):
+        if key not in self._coords:
+            n = self.map_size(key)
+            with torch.cuda.device(self.device):
+                c = torch.empty((n, 4), dtype=torch.int32, device=self.device)
+                engine.check(engine.lib().lgs_manager_get_coords(self.h, key, _ptr(c), _stream()))
+            self._coords[key] = c
+        return self._coords[key]
+
+    def kernel_map(self, in_key, out_key, ks):
+        k = (in_key, out_key, ks)
+        if k not in self._kmaps:
+            h = _vp(None)
+            with torch.cuda.device(self.device):
+                engine.check(engine.lib().lgs_manager_kernel_map(self.h, in_key, out_key, ks, _stream(), ctypes.byref(h)))
+            self._kmaps[k] = HipKernelMap(self, h, in_key, out_key, ks)
+        return self._kmaps[k]
+
+
+class HipBackend:
+    name = "hip"
+
+    def new_manager(self, device):
+        return HipManager(device)
+
+    # ---- fused BN(+residual)(+ReLU): lgs_bn_forward / lgs_bn_backward
+    def bn_forward(self, x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu):
+        _require_dev(x, "features")
+        L = engine.lib()
+        x = x.contiguous()
+        n, c = x.shape
+        dt = _dtype_code(x)
+        with torch.cuda.device(x.device):
+            y = torch.empty_like(x)
+            stats = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+            res = residual.contiguous() if residual is not None else None
+            engine.check(L.lgs_bn_forward(_ptr(x), n, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
+                                          _ptr(running_mean), _ptr(running_var), _ptr(res), int(relu), _ptr(y),
+                                          _ptr(stats), dt, _stream()))
+        return y, stats
+
+    def bn_backward(self, x, y, dy, gamma, stats, relu, want_residual):
+        L = engine.lib()
+        dy = dy.contiguous()
+        n, c = x.shape
+        dt = _dtype_code(x)
+        with torch.cuda.device(x.device):
+            dx = torch.empty_like(x)
+            dres = torch.empty_like(x) if want_residual else None
+            dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+            dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+            engine.check(L.lgs_bn_backward(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(stats), int(relu), _ptr(dx),
+                                           _ptr(dres), _ptr(dgamma), _ptr(dbeta), dt, _stream()))
+        return dx, dres, dgamma, dbeta
+
+    # ---- CLIP contraction: lgs_clip_similarity
+    def clip_similarity(self, feats, anchors):
+        _require_dev(feats, "features")
+        L = engine.lib()
+        feats = feats.contiguous()
+        anchors = anchors.detach().contiguous().float()
+        n, c = feats.shape
+        na = anchors.shape[0]
+        dt = _dtype_code(feats)
+        with torch.cuda.device(feats.device):
+            sim = torch.empty((n, na), dtype=torch.float32, device=feats.device)
+            inv = torch.empty(max(n, 1), dtype=torch.float32, device=feats.device)
+            ws = _ws(L.lgs_clip_workspace_bytes(c, na, dt), feats.device)
+            engine.check(L.lgs_clip_similarity(_ptr(feats), n, c, _ptr(anchors), na, _ptr(sim), _ptr(inv), dt, _ptr(ws),
+                                               _stream()))
+        return sim, inv[:n]

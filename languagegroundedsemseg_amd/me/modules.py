@@ -1,0 +1,370 @@
+"""Module surface: MinkowskiConvolution[Transpose], MinkowskiBatchNorm, MinkowskiSyncBatchNorm,
+MinkowskiReLU, MinkowskiNetwork ... with the constructor signatures, parameter names and shapes the
+reference relies on:
+  kernel [K,Cin,Cout] ([Cin,Cout] for 1x1 stride 1), bias [1,Cout]     common.py:195-203,228-236
+  MinkowskiBatchNorm.bn = nn.BatchNorm1d                               common.py:19, resnet.py:80-82
+so released checkpoints' state-dict keys/shapes load (lib/utils.py:17-45).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .core import SparseTensor, get_backend
+from .kernel import KernelGenerator, RegionType, convert_to_int_list
+
+
+class MinkowskiModuleBase(nn.Module):
+    pass
+
+
+class MinkowskiNetwork(nn.Module):
+    """models/model.py:4-16 subclasses this and stores D."""
+
+    def __init__(self, D):
+        super().__init__()
+        self.D = D
+
+
+# ------------------------------------------------------------------------------------------ convolution
+class MinkowskiConvolutionFunction(torch.autograd.Function):
+    """out = conv(in) over a cached kernel map; backward = dgrad + wgrad (+ bias grad) on the same map."""
+
+    @staticmethod
+    def forward(ctx, feats, kernel, bias, kmap, transposed):
+        ctx.kmap, ctx.transposed, ctx.has_bias = kmap, transposed, bias is not None
+        ctx.kshape = kernel.shape
+        ctx.save_for_backward(feats, kernel)
+        return kmap.conv_forward(feats, kernel, bias, transposed)
+
+    @staticmethod
+    def backward(ctx, gout):
+        feats, kernel = ctx.saved_tensors
+        gout = gout.contiguous()
+        gin = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gin = ctx.kmap.conv_dgrad(gout, kernel, ctx.transposed)
+        if ctx.needs_input_grad[1]:
+            gw = ctx.kmap.conv_wgrad(feats, gout, ctx.transposed).reshape(ctx.kshape).to(kernel.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gout.float().sum(0, keepdim=True)
+        return gin, gw, gb, None, None
+
+
+MinkowskiConvolutionTransposeFunction = MinkowskiConvolutionFunction
+
+
+class MinkowskiConvolutionBase(MinkowskiModuleBase):
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False, kernel_generator=None,
+                 is_transpose=False, expand_coordinates=False, convolution_mode=None, dimension=-1):
+        super().__init__()
+        assert dimension > 0, "dimension must be a positive integer"
+        if kernel_generator is None:
+            kernel_generator = KernelGenerator(kernel_size=kernel_size, stride=stride, dilation=dilation,
+                                               expand_coordinates=expand_coordinates, dimension=dimension)
+        self.is_transpose = is_transpose
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_generator = kernel_generator
+        self.dimension = dimension
+        self.use_mm = False
+        self.kernel_size = kernel_generator.kernel_size
+        self.stride = kernel_generator.kernel_stride
+        self.dilation = kernel_generator.kernel_dilation
+        if kernel_generator.region_type != RegionType.HYPER_CUBE:
+            raise NotImplementedError("only HYPER_CUBE regions are part of the D=3 model family")
+        if any(d != 1 for d in self.dilation):
+            raise NotImplementedError("dilation != 1 is not used by the model family")
+        if len(set(self.kernel_size)) != 1 or len(set(self.stride)) != 1:
+            raise NotImplementedError("anisotropic kernels/strides are not used on D=3")
+        ks, st = self.kernel_size[0], self.stride[0]
+        if not ((ks == 3 and st == 1) or (ks == 2 and st == 2) or (ks == 1 and st == 1)):
+            raise NotImplementedError("kernel_size/stride combination (%d,%d) is not part of the model family" % (ks, st))
+        self.kernel_volume = kernel_generator.kernel_volume
+        if self.kernel_volume == 1 and st == 1:
+            self.use_mm = True
+            kshape = (in_channels, out_channels)
+        else:
+            kshape = (self.kernel_volume, in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(kshape, dtype=torch.float32))
+        self.bias = nn.Parameter(torch.empty((1, out_channels), dtype=torch.float32)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self, is_transpose=None):
+        is_transpose = self.is_transpose if is_transpose is None else is_transpose
+        with torch.no_grad():
+            n = (self.out_channels if is_transpose else self.in_channels) * self.kernel_volume
+            stdv = 1.0 / math.sqrt(n)
+            self.kernel.data.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.data.uniform_(-stdv, stdv)
+
+    def forward(self, input, coordinates=None):
+        assert isinstance(input, SparseTensor)
+        assert input.F.shape[1] == self.in_channels, "Channel size mismatch %d != %d" % (input.F.shape[1], self.in_channels)
+        mgr = input.coordinate_manager
+        ks, st = self.kernel_size[0], self.stride[0]
+        in_key = input.coordinate_map_key
+        if not self.is_transpose:
+            out_key = in_key if st == 1 else mgr.stride(in_key, st)
+            kmap = mgr.kernel_map_handle(in_key, out_key, ks)
+            transposed = False
+        else:
+            out_key = in_key if st == 1 else mgr.finer_key(in_key)
+            # the transposed conv reuses the forward map of the matching strided conv, in/out swapped
+            kmap = mgr.kernel_map_handle(out_key, in_key, ks)
+            transposed = True
+        out = MinkowskiConvolutionFunction.apply(input.F, self.kernel, self.bias, kmap, transposed)
+        return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
+
+    def __repr__(self):
+        return "%s(in=%d, out=%d, kernel_size=%s, stride=%s, dilation=%s)" % (
+            self.__class__.__name__, self.in_channels, self.out_channels, self.kernel_size, self.stride, self.dilation)
+
+
+class MinkowskiConvolution(MinkowskiConvolutionBase):
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False, kernel_generator=None,
+                 expand_coordinates=False, convolution_mode=None, dimension=None):
+        super().__init__(in_channels, out_channels, kernel_size, stride, dilation, bias, kernel_generator,
+                         is_transpose=False, expand_coordinates=expand_coordinates, convolution_mode=convolution_mode,
+                         dimension=dimension)
+
+
+class MinkowskiConvolutionTranspose(MinkowskiConvolutionBase):
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False, kernel_generator=None,
+                 expand_coordinates=False, convolution_mode=None, dimension=None):
+        super().__init__(in_channels, out_channels, kernel_size, stride, dilation, bias, kernel_generator,
+                         is_transpose=True, expand_coordinates=expand_coordinates, convolution_mode=convolution_mode,
+                         dimension=dimension)
+
+
+# ------------------------------------------------------------------------------------------ normalisation
+class FusedBatchNormFunction(torch.autograd.Function):
+    """y = relu?(BN(x) (+ residual)) with batch statistics, one engine call each way."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, backend):
+        y, stats = backend.bn_forward(x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu)
+        ctx.backend, ctx.relu, ctx.has_res = backend, relu, residual is not None
+        if relu:
+            ctx.save_for_backward(x, gamma, stats, y)
+        else:
+            ctx.save_for_backward(x, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        saved = ctx.saved_tensors
+        x, gamma, stats = saved[0], saved[1], saved[2]
+        y = saved[3] if ctx.relu else None
+        dx, dres, dgamma, dbeta = ctx.backend.bn_backward(x, y, dy, gamma, stats, ctx.relu,
+                                                          ctx.has_res and ctx.needs_input_grad[3])
+        return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), dres, None, None, None, None, None, None
+
+
+class MinkowskiBatchNorm(nn.Module):
+    """`.bn` is a plain nn.BatchNorm1d so state-dict keys are `*.bn.{weight,bias,running_*}`."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
+                                 track_running_stats=track_running_stats)
+
+    def forward(self, input, relu=False, residual=None):
+        """`relu` / `residual` are extensions the build's own models use to fuse the whole
+        BN -> (+residual) -> ReLU chain into one kernel; reference code calls forward(input)."""
+        bn = self.bn
+        backend = get_backend()
+        x = input.F
+        res = residual.F if isinstance(residual, SparseTensor) else residual
+        fused = hasattr(backend, "bn_forward") and bn.affine and (bn.training or not bn.track_running_stats)
+        if fused:
+            if bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+            rm = bn.running_mean if bn.track_running_stats else None
+            rv = bn.running_var if bn.track_running_stats else None
+            y = FusedBatchNormFunction.apply(x, bn.weight, bn.bias, res, rm, rv, bn.eps, bn.momentum, relu, backend)
+        else:
+            y = bn(x.float()).to(x.dtype) if x.dtype != torch.float32 else bn(x)
+            if res is not None:
+                y = y + res
+            if relu:
+                y = torch.relu(y)
+        return SparseTensor(y, coordinate_map_key=input.coordinate_map_key, coordinate_manager=input.coordinate_manager)
+
+    def __repr__(self):
+        b = self.bn
+        return "MinkowskiBatchNorm(%d, eps=%g, momentum=%g, affine=%s, track_running_stats=%s)" % (
+            b.num_features, b.eps, b.momentum, b.affine, b.track_running_stats)
+
+
+class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
+    """Cross-rank batch statistics (main.py:122-123).  Statistics of all ranks are exchanged with ONE
+    packed all-reduce per layer ([sum, sumsq, count]) instead of torch SyncBatchNorm's gather."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, process_group=None):
+        super().__init__(num_features, eps, momentum, affine, track_running_stats)
+        self.process_group = process_group
+
+    def forward(self, input, relu=False, residual=None):
+        import torch.distributed as dist
+        if not (self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1):
+            return super().forward(input, relu=relu, residual=residual)
+        from ..ddp import sync_batch_norm
+        y = sync_batch_norm(input.F, self.bn, self.process_group)
+        if residual is not None:
+            y = y + (residual.F if isinstance(residual, SparseTensor) else residual)
+        if relu:
+            y = torch.relu(y)
+        return SparseTensor(y, coordinate_map_key=input.coordinate_map_key, coordinate_manager=input.coordinate_manager)
+
+    @classmethod
+    def convert_sync_batchnorm(cls, module, process_group=None):
+        out = module
+        if isinstance(module, MinkowskiBatchNorm) and not isinstance(module, MinkowskiSyncBatchNorm):
+            b = module.bn
+            out = cls(b.num_features, b.eps, b.momentum, b.affine, b.track_running_stats, process_group)
+            if b.affine:
+                with torch.no_grad():
+                    out.bn.weight = b.weight
+                    out.bn.bias = b.bias
+            out.bn.running_mean = b.running_mean
+            out.bn.running_var = b.running_var
+            out.bn.num_batches_tracked = b.num_batches_tracked
+            out.train(module.training)
+        for name, child in module.named_children():
+            out.add_module(name, cls.convert_sync_batchnorm(child, process_group))
+        return out
+
+
+class MinkowskiInstanceNorm(nn.Module):
+    """Per-scene normalisation (only the out-of-scope 34Dv2/v3 variants use it, clip_models.py:416,431)."""
+
+    def __init__(self, num_features):
+        super().__init__()
+        self.num_features = num_features
+        self.eps = 1e-6
+        self.weight = nn.Parameter(torch.ones(1, num_features))
+        self.bias = nn.Parameter(torch.zeros(1, num_features))
+
+    def forward(self, input):
+        x, b = input.F, input.C[:, 0].long()
+        nb = int(b.max().item()) + 1 if b.numel() else 0
+        cnt = torch.zeros(nb, device=x.device, dtype=torch.float32).index_add_(0, b, torch.ones_like(b, dtype=torch.float32))
+        xf = x.float()
+        mean = torch.zeros(nb, x.shape[1], device=x.device).index_add_(0, b, xf) / cnt[:, None]
+        d = xf - mean[b]
+        var = torch.zeros(nb, x.shape[1], device=x.device).index_add_(0, b, d * d) / cnt[:, None]
+        y = d / torch.sqrt(var[b] + self.eps) * self.weight + self.bias
+        return input._like(y.to(x.dtype))
+
+
+# ------------------------------------------------------------------------------------------ pointwise
+class MinkowskiNonlinearityBase(MinkowskiModuleBase):
+    MODULE = None
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self.module = self.MODULE(*args, **kwargs)
+
+    def forward(self, input):
+        return SparseTensor(self.module(input.F), coordinate_map_key=input.coordinate_map_key,
+                            coordinate_manager=input.coordinate_manager)
+
+    def __repr__(self):
+        return self.__class__.__name__ + "()"
+
+
+class MinkowskiReLU(MinkowskiNonlinearityBase):
+    MODULE = nn.ReLU
+
+
+class MinkowskiSigmoid(MinkowskiNonlinearityBase):
+    MODULE = nn.Sigmoid
+
+
+class MinkowskiTanh(MinkowskiNonlinearityBase):
+    MODULE = nn.Tanh
+
+
+class MinkowskiLeakyReLU(MinkowskiNonlinearityBase):
+    MODULE = nn.LeakyReLU
+
+
+class MinkowskiELU(MinkowskiNonlinearityBase):
+    MODULE = nn.ELU
+
+
+class MinkowskiDropout(MinkowskiNonlinearityBase):
+    MODULE = nn.Dropout
+
+
+class MinkowskiLinear(nn.Module):
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.linear = nn.Linear(in_features, out_features, bias=bias)
+
+    def forward(self, input):
+        return input._like(self.linear(input.F))
+
+
+class _OutOfScope(nn.Module):
+    """Placeholder for ME modules that only out-of-scope model families construct:
+    constructible (so `import models` and unrelated ctors work) but raises if executed."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("%s is outside the Res16UNet hot path (SURVEY.md section 8)" % self.__class__.__name__)
+
+
+class MinkowskiSumPooling(_OutOfScope):
+    pass
+
+
+class MinkowskiAvgPooling(_OutOfScope):
+    pass
+
+
+class MinkowskiMaxPooling(_OutOfScope):
+    pass
+
+
+class MinkowskiAvgUnpooling(_OutOfScope):
+    pass
+
+
+class MinkowskiPoolingTranspose(_OutOfScope):
+    pass
+
+
+class MinkowskiGlobalPooling(_OutOfScope):
+    pass
+
+
+class MinkowskiGlobalSumPooling(_OutOfScope):
+    pass
+
+
+class MinkowskiGlobalAvgPooling(_OutOfScope):
+    pass
+
+
+class MinkowskiGlobalMaxPooling(_OutOfScope):
+    pass
+
+
+class MinkowskiBroadcast(_OutOfScope):
+    pass
+
+
+class MinkowskiBroadcastAddition(_OutOfScope):
+    pass
+
+
+class MinkowskiBroadcastMultiplication(_OutOfScope):
+    pass
+
+
+class MinkowskiBroadcastConcatenation(_OutOfScope):
+    pass

@@ -1,0 +1,87 @@
+"""Whole-network parity on the GPU: Res16UNet forward + backward on the HIP engine against the CPU
+oracle (BASELINE config[0]-style scene sizes that the oracle finishes in seconds) and against the
+committed reference-generated fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import MinkowskiEngine as ME
+from helpers import Cfg, deterministic_init
+from languagegroundedsemseg_amd.models import load_model
+from oracle.backend import OracleBackend
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def run_model(name, coords, feats, labels, device, dtype=torch.float32):
+    m = deterministic_init(load_model(name)(3, 20, Cfg()), 42).to(device).train()
+    f = torch.from_numpy(feats).to(device).to(dtype)
+    x = ME.SparseTensor(f, torch.from_numpy(coords).to(device))
+    logits, fmap = m(x)
+    loss = torch.nn.functional.cross_entropy(logits.F.float(), torch.from_numpy(labels).to(device), ignore_index=-1)
+    loss.backward()
+    grads = {k: p.grad.detach().float().cpu().numpy() for k, p in m.named_parameters()}
+    return logits.F.detach().float().cpu().numpy(), float(loss), grads, m
+
+
+@pytest.mark.parametrize("name", ["Res16UNet14A", "Res16UNet34C"])
+def test_logits_match_reference_fixture(name):
+    """HIP engine vs the logits the REFERENCE's model files produced on the oracle backend."""
+    fx = np.load(os.path.join(G, "%s_forward.npz" % name.lower()))
+    m = deterministic_init(load_model(name)(3, 20, Cfg()), 42).to(DEV).train()
+    x = ME.SparseTensor(torch.from_numpy(fx["feats"]).to(DEV), torch.from_numpy(fx["coords"]).to(DEV))
+    logits, fmap = m(x)
+    err = np.abs(logits.F.detach().cpu().numpy() - fx["logits"]).max()
+    assert err < 1e-3, err                          # north_star: logits within 1e-3 fp32
+    assert np.abs(m.bn0.bn.running_mean.cpu().numpy() - fx["running_mean_bn0"]).max() < 1e-5
+
+
+def test_forward_backward_fp32_matches_oracle():
+    fx = np.load(os.path.join(G, "res16unet14a_forward.npz"))
+    coords, feats = fx["coords"], fx["feats"]
+    labels = np.random.default_rng(0).integers(-1, 20, coords.shape[0]).astype(np.int64)
+    h_logits, h_loss, h_g, _ = run_model("Res16UNet14A", coords, feats, labels, DEV)
+    prev = ME.set_backend(OracleBackend("c"))
+    try:
+        o_logits, o_loss, o_g, _ = run_model("Res16UNet14A", coords, feats, labels, "cpu")
+    finally:
+        ME.set_backend(prev)
+    assert np.abs(h_logits - o_logits).max() < 1e-3
+    assert abs(h_loss - o_loss) < 1e-4
+    worst = 0.0
+    for k in o_g:
+        e = np.abs(h_g[k] - o_g[k]).max() / max(1e-6, np.abs(o_g[k]).max())
+        worst = max(worst, e)
+        assert e < 2e-3, (k, e)
+    print("worst relative grad error", worst)
+
+
+def test_bf16_storage_deviation_from_fp32_oracle_is_reported():
+    fx = np.load(os.path.join(G, "res16unet14a_forward.npz"))
+    coords, feats = fx["coords"], fx["feats"]
+    labels = np.random.default_rng(0).integers(-1, 20, coords.shape[0]).astype(np.int64)
+    h_logits, h_loss, h_g, _ = run_model("Res16UNet14A", coords, feats, labels, DEV, dtype=torch.bfloat16)
+    err = np.abs(h_logits - fx["logits"]).max() / np.abs(fx["logits"]).max()
+    print("bf16 storage: max relative logit deviation from the fp32 reference fixture = %.4f" % err)
+    assert err < 0.1
+    assert np.isfinite(h_loss) and all(np.isfinite(v).all() for v in h_g.values())
+
+
+def test_reference_style_unfused_calls_equal_fused():
+    """reference code calls bn(x); relu(x); out += residual separately -- same numbers as the fused call"""
+    torch.manual_seed(0)
+    fx = np.load(os.path.join(G, "res16unet14a_forward.npz"))
+    x = ME.SparseTensor(torch.randn(fx["coords"].shape[0], 32, device=DEV), torch.from_numpy(fx["coords"]).to(DEV))
+    r = ME.SparseTensor(torch.randn(fx["coords"].shape[0], 32, device=DEV), coordinate_map_key=x.coordinate_map_key,
+                        coordinate_manager=x.coordinate_manager)
+    bn = ME.MinkowskiBatchNorm(32).to(DEV)
+    relu = ME.MinkowskiReLU(inplace=True)
+    a = bn(x, relu=True, residual=r).F
+    out = bn(x)
+    out += r
+    b = relu(out).F
+    assert torch.allclose(a, b, atol=1e-6)

@@ -1,0 +1,77 @@
+"""Per-op timings on the GPU (HIP events on torch's current stream) for the hot layer shapes.
+usage: python tools/microbench.py [scenes]"""
+import sys
+import time
+
+import numpy as np
+import torch
+
+import MinkowskiEngine as ME
+from languagegroundedsemseg_amd.synthetic import make_batch
+
+DEV = "cuda:0"
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    coords, feats, labels = make_batch(list(range(B)), n_target=150000, shift_seed=0)
+    c = torch.from_numpy(coords).to(DEV)
+    n = coords.shape[0]
+    print("voxels", n)
+    t0 = time.time()
+    x = ME.SparseTensor(torch.from_numpy(feats).to(DEV), c)
+    torch.cuda.synchronize()
+    print("insert (first call, incl. lib load) %.1f ms" % ((time.time() - t0) * 1e3))
+
+    def build_maps():
+        xx = ME.SparseTensor(torch.zeros(n, 3, device=DEV), c)
+        m = xx.coordinate_manager
+        k = xx.coordinate_map_key
+        for lvl in range(5):
+            m.kernel_map_handle(k, k, 3)
+            if lvl < 4:
+                k2 = m.stride(k, 2)
+                m.kernel_map_handle(k, k2, 2)
+                k = k2
+    print("all maps (5x 3^3 + 4x 2^3 + 4 strides + insert): %.2f ms" % timeit(build_maps, 3, 1))
+
+    mgr, k0 = x.coordinate_manager, x.coordinate_map_key
+    km = mgr.kernel_map_handle(k0, k0, 3)
+    kk, ii, oo = km.export()
+    M = kk.shape[0]
+    print("3^3 pairs at L0: %d (%.2f per voxel)" % (M, M / n))
+    for dtype in (torch.bfloat16, torch.float32):
+        e = 2 if dtype == torch.bfloat16 else 4
+        for cin, cout in ((96, 96), (128, 96), (32, 32)):
+            f = torch.randn(n, cin, device=DEV).to(dtype)
+            g = torch.randn(n, cout, device=DEV).to(dtype)
+            w = torch.randn(27, cin, cout, device=DEV) * 0.05
+            tf = timeit(lambda: km.conv_forward(f, w, None, False))
+            td = timeit(lambda: km.conv_dgrad(g, w, False))
+            tw = timeit(lambda: km.conv_wgrad(f, g, False))
+            flop = 2.0 * M * cin * cout
+            bf = M * cin * e + n * cout * e + 8 * M + 27 * cin * cout * e
+            print("%-9s %3d->%3d  fwd %.3f ms (%.1f TF, %.2f TB/s alg)  dgrad %.3f ms  wgrad %.3f ms (%.1f TF)" % (
+                str(dtype).split(".")[1], cin, cout, tf, flop / tf / 1e9, bf / tf / 1e9, td, tw, flop / tw / 1e9))
+        f = torch.randn(n, 96, device=DEV).to(dtype)
+        bn = ME.MinkowskiBatchNorm(96).to(DEV)
+        sx = ME.SparseTensor(f.clone().requires_grad_(True), coordinate_map_key=k0, coordinate_manager=mgr)
+        tb = timeit(lambda: bn(sx, relu=True))
+        print("%-9s BN+ReLU fwd 96ch %.3f ms (%.2f TB/s of 3*N*C*e)" % (str(dtype).split(".")[1], tb, 3 * n * 96 * e / tb / 1e9))
+
+
+if __name__ == "__main__":
+    main()
