@@ -111,6 +111,14 @@ __global__ void k_pad_rows(const T *__restrict__ src, int64_t n, int c, int cpad
   dst[i] = ch < c ? src[r * c + ch] : (T)0;
 }
 
+// inverse of k_pad_rows: [n, cpad] -> [n, c]
+template <typename T>
+__global__ void k_unpad_rows(const T *__restrict__ src, int64_t n, int c, int cpad, T *__restrict__ dst) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * c) return;
+  dst[i] = src[(i / c) * cpad + (i % c)];
+}
+
 // ------------------------------------------------------------------------------------ forward / dgrad
 // Tile: WM x WN waves; each wave owns RB*32 positions x NCB*32 output channels.
 template <typename T, int RB, int NCB, int WM, int WN>
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
         F[rb][t] = (ok && ch + EPL <= cin_real) ? *reinterpret_cast<const uint4 *>(src + t * EPL) : make_uint4(0, 0, 0, 0);
       }
     }
-    const int kw = v.KS > 1 ? (v.mirror ? v.K - 1 - islot : islot) : kw_single;
+    const int kw = v.KS > 1 ? islot : kw_single;  // 3^3 dgrad mirroring (K-1-k) is folded into the weight packing
     const uint4 *wsrc = wp + (((int64_t)kw * nc + ichunk) * nb_total + nb_wg) * (LD * 64);
     const int wvalid = min(WB, nb_total - nb_wg) * LD * 64;
 #pragma unroll
@@ -460,13 +468,31 @@ int launch_gather(const View &v, const T *in, int cin_real, int nc, const uint4 
 
 template <typename T>
 int conv_gather_op(const View &v, const void *in_v, int g_real, const float *weight, int K, int cin_w, int cout_w,
-                   int transposed_w, int o_real, const float *bias, void *out_v, void *workspace, hipStream_t s) {
+                   int transposed_w, int o_real, const float *bias, void *out_v, void *workspace, hipStream_t s,
+                   int w_o_real = -1) {
+  if (w_o_real < 0) w_o_real = o_real;
   constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
-  LGS_REQUIRE(o_real % 4 == 0, "sparse conv: output channel count must be a multiple of 4");
   const int g_pad = pad32(g_real), nc = g_pad / 32, nb_total = pad32(o_real) / 32;
   char *ws = reinterpret_cast<char *>(workspace);
   uint4 *wp = reinterpret_cast<uint4 *>(ws);
   int64_t wbytes = align256((int64_t)K * nc * nb_total * LD * 64 * 16);
+  if (o_real % 4 != 0) {
+    // rows are written in 4-channel groups: route odd widths (e.g. the 3-channel input gradient of a
+    // test) through a 4-aligned scratch image placed after the packed weights and the padded input
+    LGS_REQUIRE(bias == nullptr, "sparse conv: bias needs an output channel count that is a multiple of 4");
+    const int o4 = (o_real + 3) / 4 * 4;
+    int64_t off = wbytes + ((g_real % EPL != 0) ? align256(v.n_in * (int64_t)g_pad * (int64_t)sizeof(T)) : 0);
+    T *tmp = reinterpret_cast<T *>(ws + off);
+    if (v.n_out > 0) LGS_HIP(hipMemsetAsync(tmp, 0, (size_t)v.n_out * o4 * sizeof(T), s));
+    int rc = conv_gather_op<T>(v, in_v, g_real, weight, K, cin_w, cout_w, transposed_w, o4, nullptr, tmp, workspace, s, o_real);
+    if (rc) return rc;
+    int64_t tot = v.n_out * (int64_t)o_real;
+    if (tot > 0)
+      hipLaunchKernelGGL((k_unpad_rows<T>), (unsigned)((tot + 255) / 256), 256, 0, s, tmp, v.n_out, o_real, o4,
+                         reinterpret_cast<T *>(out_v));
+    LGS_HIP(hipGetLastError());
+    return 0;
+  }
   const T *in = reinterpret_cast<const T *>(in_v);
   int g_stride = g_real;
   if (g_real % EPL != 0) {  // e.g. the 3-channel colour input of conv0p1s1
@@ -478,7 +504,7 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
   }
   int64_t total = (int64_t)K * nc * nb_total * LD * 64;
   hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, weight, K, cin_w, cout_w, transposed_w,
-                     v.mirror, g_real, o_real, nc, nb_total, wp);
+                     v.mirror, g_real, w_o_real, nc, nb_total, wp);
   LGS_HIP(hipGetLastError());
   return launch_gather<T>(v, in, g_stride, nc, wp, nb_total, reinterpret_cast<T *>(out_v), o_real, bias, s);
 }
@@ -582,10 +608,9 @@ int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtyp
   }
   int g = op == 0 ? cin : cout, o = op == 0 ? cout : cin;
   int64_t bytes = align256((int64_t)km->K * pad32(g) * pad32(o) * e);
-  if (g % epl(dtype) != 0) {
-    int64_t nmax = km->fwd.n_in > km->bwd.n_in ? km->fwd.n_in : km->bwd.n_in;
-    bytes += align256(nmax * pad32(g) * e);
-  }
+  int64_t nmax = km->fwd.n_in > km->bwd.n_in ? km->fwd.n_in : km->bwd.n_in;
+  if (g % epl(dtype) != 0) bytes += align256(nmax * pad32(g) * e);
+  if (o % 4 != 0) bytes += align256(nmax * (int64_t)((o + 3) / 4 * 4) * e);
   return bytes + 256;
 }
 
