@@ -1,0 +1,301 @@
+#!/usr/bin/env python
+"""bench.py -- voxels/sec of the Res16UNet34C training step (forward + loss + backward + gradient
+all-reduce + SGD step) on synthetic ScanNet200-shaped scenes, one process per GPU.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps 10 --warmup 3
+
+A "step" is one pass of the hot path over one batch of `--scenes` synthetic scenes per GPU (~150k voxels
+each @2cm, BASELINE.json configs[1]); inputs are resident in HBM when the timed region starts; the step
+includes the trainer's per-step coordinate shift, SparseTensor construction (coordinate hashing + all kernel
+maps), forward, cross-entropy over 200 classes, backward, RCCL gradient all-reduce (N>1) and the SGD update.
+Scenes shard over ranks with no data-path collective ("weak" scaling: per-GPU work fixed).
+
+Rank 0 prints ONE JSON line; besides the driver's contract it carries
+  roofline     -- the dominant kernel family (k_conv_gather: sparse-conv forward/dgrad implicit GEMM),
+                  algorithmic bytes of every launch of one step (SURVEY 8d byte model) / their HIP-event
+                  durations, vs the 8 TB/s HBM peak; plus the whole-step B_alg fraction
+  cpu_baseline -- the oracle's BLAS gather-GEMM-scatter restatement of the same model on the host cores,
+                  on a bounded sample (it is a restatement of MinkowskiEngine's CPU algorithm, not ME itself)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import MinkowskiEngine as ME  # noqa: E402
+from languagegroundedsemseg_amd import models  # noqa: E402
+from languagegroundedsemseg_amd.ddp import BucketedDDP  # noqa: E402
+from languagegroundedsemseg_amd.synthetic import make_batch  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md; 6.29 TB/s measured float4 copy)
+
+
+class Cfg:
+    bn_momentum = 0.02
+    conv1_kernel_size = 3
+    dilations = [1, 1, 1, 1]
+
+
+# ----------------------------------------------------------------------------------------------- byte model
+class ConvLog:
+    """Wraps HipKernelMap conv entry points to log (kind, M, n_out, cin, cout, K, t_ms) per launch."""
+
+    def __init__(self):
+        self.rows = []
+        self.enabled = False
+        self._patched = False
+
+    def patch(self):
+        if self._patched:
+            return
+        from languagegroundedsemseg_amd.me import backend_hip as bh
+        log = self
+        pairs_cache = {}
+
+        def n_pairs(km):
+            key = id(km)
+            if key not in pairs_cache:
+                pairs_cache[key] = int(km.export()[0].shape[0])
+            return pairs_cache[key]
+
+        def wrap(name, kind):
+            orig = getattr(bh.HipKernelMap, name)
+
+            def f(self, *a, **k):
+                if not log.enabled:
+                    return orig(self, *a, **k)
+                M = n_pairs(self)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = orig(self, *a, **k)
+                e.record()
+                if kind == "wgrad":
+                    cin, cout, n_out = a[0].shape[1], a[1].shape[1], a[1].shape[0]
+                elif kind == "fwd":
+                    w = a[1]
+                    cin, cout, n_out = a[0].shape[1], w.shape[-1], out.shape[0]
+                else:  # dgrad: "output" side is the op's input
+                    w = a[1]
+                    cin, cout, n_out = a[0].shape[1], w.shape[-2], out.shape[0]
+                log.rows.append(dict(kind=kind, M=M, n_out=n_out, cin=cin, cout=cout, K=self.K, ev=(s, e),
+                                     e=a[0].element_size()))
+                return out
+            setattr(bh.HipKernelMap, name, f)
+        wrap("conv_forward", "fwd")
+        wrap("conv_dgrad", "dgrad")
+        wrap("conv_wgrad", "wgrad")
+        self._patched = True
+
+    def summarize(self):
+        torch.cuda.synchronize()
+        fam = dict(bytes=0.0, ms=0.0, n=0)      # k_conv_gather family = fwd + dgrad launches
+        wg = dict(bytes=0.0, ms=0.0, n=0)
+        for r in self.rows:
+            t = r["ev"][0].elapsed_time(r["ev"][1])
+            e, M, K = r["e"], r["M"], r["K"]
+            idx = 0 if K == 1 else 8 * M
+            if r["kind"] == "wgrad":
+                b = M * (r["cin"] + r["cout"]) * e + idx + K * r["cin"] * r["cout"] * 4
+                wg["bytes"] += b; wg["ms"] += t; wg["n"] += 1
+            else:
+                b = M * r["cin"] * e + r["n_out"] * r["cout"] * e + idx + K * r["cin"] * r["cout"] * e
+                fam["bytes"] += b; fam["ms"] += t; fam["n"] += 1
+        return fam, wg
+
+
+# ----------------------------------------------------------------------------------------------- the step
+def build(device, dtype, n_classes=200, model_name="Res16UNet34C"):
+    torch.manual_seed(42)  # config.py:276
+    model = models.load_model(model_name)(3, n_classes, Cfg()).to(device).train()
+    return model
+
+
+def train_step(model, ddp, opt, coords, feats, labels, dtype, step_idx, shift=True):
+    c = coords
+    if shift:  # pl_BaselineTrainer.py:294: random integer shift, same for the whole batch
+        g = torch.Generator().manual_seed(1000 + step_idx)
+        sh = (torch.rand(3, generator=g) * 100).to(torch.int32)
+        c = coords.clone()
+        c[:, 1:] += sh.to(coords.device)
+    ddp.zero_grad()
+    sinput = ME.SparseTensor(feats.to(dtype), c)                       # coordinate hash + maps live for this step only
+    logits, _ = model(sinput)
+    loss = torch.nn.functional.cross_entropy(logits.F.float(), labels, ignore_index=-1)
+    loss.backward()
+    ddp.finalize()
+    opt.step()
+    return loss
+
+
+def cpu_baseline(seconds_budget=25.0, model_name="Res16UNet34C"):
+    """Oracle ("port"): MinkowskiEngine-CPU-style gather -> BLAS GEMM -> scatter restated with torch CPU ops,
+    same model, one synthetic 5cm scene (~26k voxels), all host cores, fwd + loss + bwd."""
+    from oracle.backend import OracleBackend
+    prev = ME.set_backend(OracleBackend("torch"))
+    try:
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        coords, feats, labels = make_batch([0], voxel=0.05, n_target=25000)
+        torch.manual_seed(42)
+        model = models.load_model(model_name)(3, 200, Cfg()).train()
+        c, f, l = torch.from_numpy(coords), torch.from_numpy(feats), torch.from_numpy(labels)
+
+        def one():
+            for p in model.parameters():
+                p.grad = None
+            x = ME.SparseTensor(f, c)
+            logits, _ = model(x)
+            loss = torch.nn.functional.cross_entropy(logits.F, l, ignore_index=-1)
+            loss.backward()
+        one()  # warm-up (builds nothing persistent: maps are per step, as in the reference)
+        times, t_all = [], time.perf_counter()
+        while len(times) < 5 and (time.perf_counter() - t_all) < seconds_budget:
+            t0 = time.perf_counter()
+            one()
+            times.append(time.perf_counter() - t0)
+        best = min(times)
+        return {"value": coords.shape[0] / best, "unit": "voxels/s", "cores": cores, "kind": "port",
+                "sample": "%s fwd+loss+bwd, 1 synthetic scene @5cm (%d voxels), fp32, best of %d; oracle BLAS "
+                          "gather-GEMM-scatter restatement of ME's CPU algorithm (not ME itself)" % (
+                              model_name, coords.shape[0], len(times))}
+    finally:
+        ME.set_backend(prev)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scenes", type=int, default=8, help="synthetic scenes per GPU per step")
+    ap.add_argument("--voxels", type=int, default=150000, help="target voxels per scene (@2cm)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--model", default="Res16UNet34C")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--sync-bn", type=int, default=1, help="convert to MinkowskiSyncBatchNorm when gpus > 1 (main.py:122)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    # ---- data: scenes shard over ranks (rank r owns seeds r*S .. r*S+S-1); resident in HBM before timing
+    seeds = [rank * args.scenes + i for i in range(args.scenes)]
+    coords_np, feats_np, labels_np = make_batch(seeds, voxel=0.02, n_target=args.voxels)
+    coords = torch.from_numpy(coords_np).to(device)
+    feats = torch.from_numpy(feats_np).to(device)
+    labels = torch.from_numpy(labels_np).to(device)
+    n_vox = int(coords.shape[0])
+
+    model = build(device, dtype, model_name=args.model)
+    if world > 1 and args.sync_bn:
+        model = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)
+    ddp = BucketedDDP(model, bucket_mb=32.0)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9, dampening=0.1, weight_decay=1e-4)  # lib/solvers.py
+
+    for i in range(args.warmup):
+        train_step(model, ddp, opt, coords, feats, labels, dtype, i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = train_step(model, ddp, opt, coords, feats, labels, dtype, args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    nv = torch.tensor([float(n_vox)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nv, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    total_vox = float(nv.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = total_vox * args.steps / dt
+    final_loss = float(loss.item())
+
+    out = {
+        "metric": "voxels/sec fwd+bwd Res16UNet34C @2cm ScanNet200", "value": value, "unit": "voxels/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "%s 2cm ScanNet200-shaped synthetic scenes, cross-entropy fine-tune step "
+                               "(configs[1]): SparseTensor build + fwd + CE(200) + bwd + grad all-reduce + SGD" % args.model,
+                   "scenes_per_gpu": args.scenes, "voxels_per_gpu": n_vox, "global_voxels": int(total_vox),
+                   "parallelism": "dp%d" % world, "sync_bn": bool(world > 1 and args.sync_bn),
+                   "storage": "bf16 features / fp32 master weights, fp32 accumulate + BN statistics" if args.dtype == "bf16"
+                   else "fp32"},
+        "final_loss": final_loss,
+    }
+
+    if rank == 0 and not args.no_roofline:
+        log = ConvLog()
+        log.patch()
+        log.enabled = True
+        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # NB: in a multi-rank run the other ranks must take part in the collectives of this extra step
+    else:
+        log = None
+    if not args.no_roofline:
+        if log is not None:
+            s_ev.record()
+        train_step(model, ddp, opt, coords, feats, labels, dtype, args.warmup + args.steps)
+        if log is not None:
+            e_ev.record()
+            fam, wg = log.summarize()
+            log.enabled = False
+            step_ms = s_ev.elapsed_time(e_ev)
+            e = 2 if args.dtype == "bf16" else 4
+            # BN byte model: 3 N C e fwd + 5 N C e bwd per norm layer
+            bn_bytes = 0.0
+            # every BN follows exactly one conv forward launch with the same (n_out, cout), except `final`
+            fwd_rows = [r for r in log.rows if r["kind"] == "fwd"]
+            for r in fwd_rows[:-1]:
+                bn_bytes += 8.0 * r["n_out"] * r["cout"] * e
+            b_alg_step = fam["bytes"] + wg["bytes"] + bn_bytes
+            achieved = fam["bytes"] / (fam["ms"] * 1e-3) if fam["ms"] > 0 else 0.0
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "k_conv_gather (sparse-conv forward + dgrad implicit GEMM, all instances)",
+                "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                "traffic": None,
+                "launches_per_step": fam["n"], "avg_launch_ms": fam["ms"] / max(fam["n"], 1),
+                "alg_bytes_per_launch": fam["bytes"] / max(fam["n"], 1),
+                "wgrad": {"kernel": "k_wgrad", "achieved": (wg["bytes"] / (wg["ms"] * 1e-3) / 1e9) if wg["ms"] > 0 else 0.0,
+                          "launches_per_step": wg["n"], "avg_launch_ms": wg["ms"] / max(wg["n"], 1)},
+                "step": {"b_alg_bytes": b_alg_step, "b_alg_per_voxel": b_alg_step / n_vox,
+                         "frac_of_hbm_peak": b_alg_step / (ms_per_step * 1e-3) / HBM_PEAK,
+                         "conv_gather_ms": fam["ms"], "wgrad_ms": wg["ms"], "instrumented_step_ms": step_ms},
+            }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(model_name=args.model)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+"""Data-parallel helpers: one process per GPU, RCCL over xGMI through torch.distributed.
+
+Replaces (functionally) what the reference gets from PyTorch-Lightning's DDPPlugin + ME SyncBatchNorm:
+  /root/reference/main.py:121-123   MinkowskiSyncBatchNorm.convert_sync_batchnorm when num_gpu > 1
+  /root/reference/main.py:192-195   DDPPlugin(find_unused_parameters=True) -> NCCL gradient all-reduce
+Scenes are independent: every rank owns its own batch, coordinate manager and kernel maps;
+the only exchange per step is the gradient all-reduce (+ SyncBN statistics).
+
+Design for xGMI (point-to-point links, ring collectives are per-link bound): gradients live in a few
+large flat fp32 buckets (param.grad are views into them, so there is no copy-in/copy-out), each bucket is
+all-reduced asynchronously on RCCL's stream the moment its last gradient has been accumulated, i.e.
+overlapped with the rest of backward; finalize() waits once before the optimiser step.
+"""
+import torch
+import torch.distributed as dist
+
+
+class BucketedDDP:
+    def __init__(self, module, bucket_mb=32.0, process_group=None):
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        params = [p for p in module.parameters() if p.requires_grad]
+        # gradients become ready roughly in reverse registration order
+        params = list(reversed(params))
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        self.buckets = []  # dict(flat, params, pending, handle)
+        cur, cur_n = [], 0
+        for p in params:
+            if cur and cur_n + p.numel() > cap:
+                self._make_bucket(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self._make_bucket(cur)
+        self._handles = []
+        if self.world > 1:
+            for p in params:
+                dist.broadcast(p.data, src=0, group=self.group)
+            for b in module.buffers():
+                if b.dtype.is_floating_point:
+                    dist.broadcast(b.data, src=0, group=self.group)
+
+    def _make_bucket(self, params):
+        n = sum(p.numel() for p in params)
+        flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+        off = 0
+        bucket = {"flat": flat, "params": params, "pending": len(params), "n": len(params)}
+        for p in params:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+            if self.world > 1:
+                p.register_post_accumulate_grad_hook(self._hook(bucket))
+        self.buckets.append(bucket)
+
+    def _hook(self, bucket):
+        def fn(param):
+            bucket["pending"] -= 1
+            if bucket["pending"] == 0:
+                bucket["flat"].div_(self.world)
+                self._handles.append(dist.all_reduce(bucket["flat"], group=self.group, async_op=True))
+        return fn
+
+    def zero_grad(self):
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["pending"] = b["n"]
+
+    def finalize(self):
+        """call after backward(): waits for the in-flight bucket all-reduces (and flushes buckets whose
+        parameters received no gradient this step -- the reference runs find_unused_parameters=True)."""
+        if self.world > 1:
+            for b in self.buckets:
+                if 0 < b["pending"]:
+                    if b["pending"] <= b["n"]:
+                        b["flat"].div_(self.world)
+                        self._handles.append(dist.all_reduce(b["flat"], group=self.group, async_op=True))
+                    b["pending"] = 0
+            for h in self._handles:
+                h.wait()
+        self._handles = []
+
+    def __call__(self, *a, **k):
+        return self.module(*a, **k)
+
+
+class _SyncBNFunction(torch.autograd.Function):
+    """Batch statistics over the rows of ALL ranks with one packed all-reduce per direction:
+    forward [sum | sumsq | count] (2C+1 floats), backward [sum dy | sum dy*xhat] (2C floats)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, group):
+        xf = x.float()
+        c = xf.shape[1]
+        packed = torch.empty(2 * c + 1, dtype=torch.float32, device=x.device)
+        packed[:c] = xf.sum(0)
+        packed[c:2 * c] = (xf * xf).sum(0)
+        packed[2 * c] = float(xf.shape[0])
+        dist.all_reduce(packed, group=group)
+        n = packed[2 * c]
+        mean = packed[:c] / n
+        var = (packed[c:2 * c] / n - mean * mean).clamp_min(0)
+        invstd = torch.rsqrt(var + eps)
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean * momentum)
+                running_var.mul_(1 - momentum).add_(var * (n / (n - 1).clamp_min(1)) * momentum)
+        xhat = (xf - mean) * invstd
+        ctx.save_for_backward(xhat, weight, invstd, n)
+        ctx.group = group
+        return (xhat * weight.float() + bias.float()).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, weight, invstd, n = ctx.saved_tensors
+        g = dy.float()
+        c = g.shape[1]
+        packed = torch.empty(2 * c, dtype=torch.float32, device=g.device)
+        packed[:c] = g.sum(0)
+        packed[c:] = (g * xhat).sum(0)
+        dbeta, dgamma = packed[:c].clone(), packed[c:].clone()   # parameter grads stay local (DDP averages them)
+        dist.all_reduce(packed, group=ctx.group)
+        dx = (g - packed[:c] / n - xhat * (packed[c:] / n)) * (weight.float() * invstd)
+        return dx.to(dy.dtype), dgamma.to(weight.dtype), dbeta.to(weight.dtype), None, None, None, None, None
+
+
+def sync_batch_norm(x, bn, group=None):
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return _SyncBNFunction.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, group)
