@@ -144,7 +144,7 @@ def cpu_baseline(seconds_budget=25.0, model_name="Res16UNet34C"):
     from oracle.backend import OracleBackend
     prev = ME.set_backend(OracleBackend("torch"))
     try:
-        cores = os.cpu_count() or 1
+        cores = min(host_cores(), 16)  # more threads only add OpenMP contention to the small per-offset GEMMs
         torch.set_num_threads(cores)
         coords, feats, labels = make_batch([0], voxel=0.05, n_target=25000)
         torch.manual_seed(42)
@@ -171,6 +171,21 @@ def cpu_baseline(seconds_budget=25.0, model_name="Res16UNet34C"):
                               model_name, coords.shape[0], len(times))}
     finally:
         ME.set_backend(prev)
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %8.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def host_cores():
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return os.cpu_count() or 1
 
 
 def main():
@@ -206,6 +221,7 @@ def main():
     feats = torch.from_numpy(feats_np).to(device)
     labels = torch.from_numpy(labels_np).to(device)
     n_vox = int(coords.shape[0])
+    log("data resident: %d voxels in %d scenes" % (n_vox, args.scenes))
 
     model = build(device, dtype, model_name=args.model)
     if world > 1 and args.sync_bn:
@@ -215,6 +231,8 @@ def main():
 
     for i in range(args.warmup):
         train_step(model, ddp, opt, coords, feats, labels, dtype, i)
+        torch.cuda.synchronize()
+        log("warmup step %d done" % i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -236,6 +254,7 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = total_vox * args.steps / dt
     final_loss = float(loss.item())
+    log("timed region done: %.2f ms/step, %.3g voxels/s" % (ms_per_step, value))
 
     out = {
         "metric": "voxels/sec fwd+bwd Res16UNet34C @2cm ScanNet200", "value": value, "unit": "voxels/s",
@@ -251,27 +270,27 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
-        log = ConvLog()
-        log.patch()
-        log.enabled = True
+        clog = ConvLog()
+        clog.patch()
+        clog.enabled = True
         s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         # NB: in a multi-rank run the other ranks must take part in the collectives of this extra step
     else:
-        log = None
+        clog = None
     if not args.no_roofline:
-        if log is not None:
+        if clog is not None:
             s_ev.record()
         train_step(model, ddp, opt, coords, feats, labels, dtype, args.warmup + args.steps)
-        if log is not None:
+        if clog is not None:
             e_ev.record()
-            fam, wg = log.summarize()
-            log.enabled = False
+            fam, wg = clog.summarize()
+            clog.enabled = False
             step_ms = s_ev.elapsed_time(e_ev)
             e = 2 if args.dtype == "bf16" else 4
             # BN byte model: 3 N C e fwd + 5 N C e bwd per norm layer
             bn_bytes = 0.0
             # every BN follows exactly one conv forward launch with the same (n_out, cout), except `final`
-            fwd_rows = [r for r in log.rows if r["kind"] == "fwd"]
+            fwd_rows = [r for r in clog.rows if r["kind"] == "fwd"]
             for r in fwd_rows[:-1]:
                 bn_bytes += 8.0 * r["n_out"] * r["cout"] * e
             b_alg_step = fam["bytes"] + wg["bytes"] + bn_bytes
@@ -288,8 +307,10 @@ def main():
                          "frac_of_hbm_peak": b_alg_step / (ms_per_step * 1e-3) / HBM_PEAK,
                          "conv_gather_ms": fam["ms"], "wgrad_ms": wg["ms"], "instrumented_step_ms": step_ms},
             }
+    log("roofline pass done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model_name=args.model)
+        log("cpu baseline done")
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

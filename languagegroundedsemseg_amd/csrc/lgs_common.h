@@ -8,6 +8,8 @@
 
 #include "../../include/lgs_engine.h"
 
+struct lgs_kmap;
+
 namespace lgs {
 
 void set_error(const std::string &msg);
@@ -50,6 +52,27 @@ struct View {
   int K = 1;          // weight matrices of the op (27 / 8 / 1)
   int mirror = 0;     // weight index = K-1-s (the 3^3 map read in the dgrad direction)
 };
+
+inline int pad32(int c) { return (c + 31) / 32 * 32; }
+inline int esize(int dtype) { return dtype == LGS_BF16 ? 2 : 4; }
+inline int epl(int dtype) { return dtype == LGS_BF16 ? 8 : 4; }
+inline int64_t align256(int64_t b) { return (b + 255) / 256 * 256; }
+
+#if defined(__HIPCC__)
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+typedef uint16_t bf16_t;  // storage type tag for bf16 tensors
+__device__ inline float bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+__device__ inline uint16_t f32_to_bf16(float f) {  // round to nearest even
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ inline float ld_elem(const float *p) { return *p; }
+__device__ inline float ld_elem(const bf16_t *p) { return bf16_to_f32(*p); }
+#endif
+
+int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype);
 
 }  // namespace lgs
 

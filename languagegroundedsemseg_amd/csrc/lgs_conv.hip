@@ -22,9 +22,6 @@
 
 namespace lgs {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-typedef uint16_t bf16_t;  // storage type tag for bf16 tensors
 
 template <typename T> struct Tr;
 template <> struct Tr<float> {
@@ -36,14 +33,6 @@ template <> struct Tr<bf16_t> {
   static constexpr int LD = 2;
 };
 
-__device__ inline float bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
-__device__ inline uint16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-__device__ inline float ld_elem(const float *p) { return *p; }
-__device__ inline float ld_elem(const bf16_t *p) { return bf16_to_f32(*p); }
 
 // one 16-byte operand pair: bf16 = one 32x32x16 MFMA, fp32 = four 32x32x2 MFMAs
 template <typename T> __device__ inline void mma16(f32x16 &acc, const uint4 &w, const uint4 &f);
@@ -291,153 +280,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
 // rows that no position of the view writes must still be defined: the forward output of a strided
 // map always covers every row, but a grouped view's padding never does -- nothing to do there.
 
-// ------------------------------------------------------------------------------------ wgrad (v1)
-// gw[k][ci][co] = sum over pairs (i,o) of offset k:  in[i][ci] * gout[o][co]
-// fp32 MFMA 32x32x2 (exact fp32 accumulate) for both storage types; pairs of a position chunk are
-// ballot-compacted into LDS in fixed wave order (deterministic), each wave owns one 32-channel ci block
-// and NCB co blocks, super-chunk partials are reduced by k_wgrad_reduce.
-constexpr int kWgChunk = 512;  // positions compacted per iteration
-
-template <typename T, int NCB>
-__global__ __launch_bounds__(256) void k_wgrad(View v, const T *__restrict__ in, int cin_real, const T *__restrict__ gout,
-                                               int cout_real, int cin_pad, int cout_pad, int64_t span,
-                                               float *__restrict__ partial) {
-  __shared__ int32_t l_in[kWgChunk], l_out[kWgChunk];
-  __shared__ int32_t l_cnt[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int vx = lane & 31, h = lane >> 5;
-  const int k = blockIdx.y;
-  const int n_cot = cout_pad / (32 * NCB);
-  const int cot = blockIdx.z % n_cot, cig = blockIdx.z / n_cot;
-  const int cib = cig * 4 + wave;
-  const bool wave_active = cib * 32 < cin_pad;
-  const int slot = v.KS > 1 ? k : 0;
-
-  f32x16 acc[NCB];
-#pragma unroll
-  for (int nb = 0; nb < NCB; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-
-  const int64_t p_begin = (int64_t)blockIdx.x * span;
-  const int64_t p_end = min(p_begin + span, v.n_pad);
-  for (int64_t base = p_begin; base < p_end; base += kWgChunk) {
-    // ---- compact valid pairs of this chunk (two positions per thread, fixed wave order)
-    int32_t my_in[2], my_out[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      int64_t p = base + wave * 128 + u * 64 + lane;
-      int32_t i = -1, o = -1;
-      if (p < p_end) {
-        bool grp_ok = true;
-        if (v.KS > 1) grp_ok = (v.mask64[p >> 6] >> slot) & 1u;
-        else if (v.tile_k) grp_ok = v.tile_k[p >> 6] == k;
-        if (grp_ok) {
-          o = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
-          i = v.nbr ? v.nbr[(int64_t)slot * v.n_pad + p] : (p < v.n_in ? (int32_t)p : -1);
-        }
-      }
-      my_in[u] = (i >= 0 && o >= 0) ? i : -1;
-      my_out[u] = o;
-    }
-    unsigned long long bal0 = __ballot(my_in[0] >= 0), bal1 = __ballot(my_in[1] >= 0);
-    int c0 = (int)__builtin_popcountll(bal0), c1 = (int)__builtin_popcountll(bal1);
-    if (lane == 0) l_cnt[wave] = c0 + c1;
-    __syncthreads();
-    int wbase = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      int c = l_cnt[w];
-      if (w < wave) wbase += c;
-      total += c;
-    }
-    if (my_in[0] >= 0) {
-      int at = wbase + (int)__builtin_popcountll(bal0 & ((1ull << lane) - 1ull));
-      l_in[at] = my_in[0]; l_out[at] = my_out[0];
-    }
-    if (my_in[1] >= 0) {
-      int at = wbase + c0 + (int)__builtin_popcountll(bal1 & ((1ull << lane) - 1ull));
-      l_in[at] = my_in[1]; l_out[at] = my_out[1];
-    }
-    __syncthreads();
-    // ---- MFMA over the compacted pairs, two pairs (k = h) per 32x32x2 instruction
-    if (wave_active) {
-      const int ci = cib * 32 + vx;
-      for (int j = 0; j < total; j += 8) {
-        float a[4], b[4][NCB];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          int pr = j + 2 * u + h;
-          bool ok = pr < total;
-          int32_t irow = ok ? l_in[pr] : 0, orow = ok ? l_out[pr] : 0;
-          a[u] = (ok && ci < cin_real) ? ld_elem(in + (int64_t)irow * cin_real + ci) : 0.f;
-#pragma unroll
-          for (int nb = 0; nb < NCB; ++nb) {
-            int co = (cot * NCB + nb) * 32 + vx;
-            b[u][nb] = (ok && co < cout_real) ? ld_elem(gout + (int64_t)orow * cout_real + co) : 0.f;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int nb = 0; nb < NCB; ++nb)
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][nb], acc[nb], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-  }
-  if (!wave_active) return;
-  // D[i = ci][j = co]: lane holds column j = vx, rows (r&3) + 8*(r>>2) + 4*h
-  float *dst = partial + (((int64_t)blockIdx.x * v.K + k) * cin_pad) * cout_pad;
-#pragma unroll
-  for (int nb = 0; nb < NCB; ++nb) {
-    int co = (cot * NCB + nb) * 32 + vx;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int ci = cib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      dst[(int64_t)ci * cout_pad + co] = acc[nb][r];
-    }
-  }
-}
-
-__global__ void k_wgrad_reduce(const float *__restrict__ partial, int S, int K, int cin_pad, int cout_pad, int cin,
-                               int cout, float *__restrict__ gw) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t total = (int64_t)K * cin * cout;
-  if (idx >= total) return;
-  int co = (int)(idx % cout);
-  int ci = (int)((idx / cout) % cin);
-  int k = (int)(idx / ((int64_t)cout * cin));
-  float s = 0.f;
-  for (int x = 0; x < S; ++x) s += partial[(((int64_t)x * K + k) * cin_pad + ci) * cout_pad + co];
-  gw[idx] = s;
-}
-
 // ------------------------------------------------------------------------------------ host side
-inline int pad32(int c) { return (c + 31) / 32 * 32; }
-inline int esize(int dtype) { return dtype == LGS_BF16 ? 2 : 4; }
-inline int epl(int dtype) { return dtype == LGS_BF16 ? 8 : 4; }
-inline int64_t align256(int64_t b) { return (b + 255) / 256 * 256; }
-
-struct WgradPlan { int S; int64_t span; int cin_pad, cout_pad, ncb; };
-inline WgradPlan wgrad_plan(const View &v, int cin, int cout) {
-  WgradPlan p;
-  p.cin_pad = pad32(cin);
-  p.cout_pad = pad32(cout);
-  int nb = p.cout_pad / 32;
-  p.ncb = (nb % 4 == 0) ? 4 : (nb % 3 == 0) ? 3 : (nb % 2 == 0) ? 2 : 1;
-  int64_t chunks = (v.n_pad + kWgChunk - 1) / kWgChunk;
-  int64_t S = chunks / 4;
-  if (S < 1) S = 1;
-  if (S > 64) S = 64;
-  int64_t per = (int64_t)v.K * p.cin_pad * p.cout_pad * 4;
-  while (S > 1 && S * per > (1ll << 30)) S /= 2;
-  int64_t cps = (chunks + S - 1) / S;
-  p.span = cps * kWgChunk;
-  p.S = (int)((v.n_pad + p.span - 1) / p.span);
-  if (p.S < 1) p.S = 1;
-  return p;
-}
 
 template <typename T>
 int launch_gather(const View &v, const T *in, int cin_real, int nc, const uint4 *wp, int nb_total, T *out, int cout_real,
@@ -509,34 +352,6 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
   return launch_gather<T>(v, in, g_stride, nc, wp, nb_total, reinterpret_cast<T *>(out_v), o_real, bias, s);
 }
 
-template <typename T>
-int conv_wgrad_op(const View &v, const void *in_v, int cin, const void *gout_v, int cout, float *gw, void *workspace,
-                  hipStream_t s) {
-  WgradPlan p = wgrad_plan(v, cin, cout);
-  float *partial = reinterpret_cast<float *>(workspace);
-  if (v.n_pad == 0) {
-    LGS_HIP(hipMemsetAsync(gw, 0, sizeof(float) * (size_t)v.K * cin * cout, s));
-    return 0;
-  }
-  const T *in = reinterpret_cast<const T *>(in_v);
-  const T *go = reinterpret_cast<const T *>(gout_v);
-  int n_cot = p.cout_pad / (32 * p.ncb);
-  int n_cig = (p.cin_pad / 32 + 3) / 4;
-  dim3 grid((unsigned)p.S, (unsigned)v.K, (unsigned)(n_cot * n_cig));
-  switch (p.ncb) {
-    case 4: hipLaunchKernelGGL((k_wgrad<T, 4>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
-    case 3: hipLaunchKernelGGL((k_wgrad<T, 3>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
-    case 2: hipLaunchKernelGGL((k_wgrad<T, 2>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
-    default: hipLaunchKernelGGL((k_wgrad<T, 1>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
-  }
-  int64_t total = (int64_t)v.K * cin * cout;
-  hipLaunchKernelGGL(k_wgrad_reduce, (unsigned)((total + 255) / 256), 256, 0, s, partial, p.S, v.K, p.cin_pad, p.cout_pad, cin,
-                     cout, gw);
-  LGS_HIP(hipGetLastError());
-  return 0;
-}
-
-
 // ------------------------------------------------------------------------------------ CLIP contraction
 // S = normalize(F) . normalize(T)^T is the 1x1 "convolution" of the voxel features with the
 // normalised text anchors as the weight matrix, scaled per row by 1/|f|: it reuses the MFMA gather
@@ -600,12 +415,7 @@ extern "C" {
 int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype, int op) {
   if (!km) return -1;
   const int e = esize(dtype);
-  if (op == 2) {
-    // the larger of the two views bounds the plan
-    WgradPlan a = wgrad_plan(km->fwd, cin, cout), b = wgrad_plan(km->bwd, cin, cout);
-    int64_t per = (int64_t)km->K * pad32(cin) * pad32(cout) * 4;
-    return align256((int64_t)(a.S > b.S ? a.S : b.S) * per) + 256;
-  }
+  if (op == 2) return lgs::wgrad_workspace_bytes(km, cin, cout, dtype);
   int g = op == 0 ? cin : cout, o = op == 0 ? cout : cin;
   int64_t bytes = align256((int64_t)km->K * pad32(g) * pad32(o) * e);
   int64_t nmax = km->fwd.n_in > km->bwd.n_in ? km->fwd.n_in : km->bwd.n_in;
@@ -636,18 +446,6 @@ int lgs_conv_dgrad(lgs_kmap *km, int transposed, const void *grad_out, int cout,
   if (dtype == LGS_F32) return conv_gather_op<float>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s);
   if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s);
   LGS_REQUIRE(false, "lgs_conv_dgrad: unknown dtype");
-}
-
-int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const void *grad_out, int cout,
-                   float *grad_weight, int dtype, void *workspace, void *stream) {
-  LGS_REQUIRE(km && grad_weight && workspace, "lgs_conv_wgrad: null argument");
-  LGS_REQUIRE(!(transposed && km->ks == 3), "transposed 3x3x3 convolution is not part of the model family");
-  const View &v = transposed ? km->bwd : km->fwd;  // same view as the forward
-  View vv = v; vv.mirror = 0;
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == LGS_F32) return conv_wgrad_op<float>(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
-  if (dtype == LGS_BF16) return conv_wgrad_op<bf16_t>(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
-  LGS_REQUIRE(false, "lgs_conv_wgrad: unknown dtype");
 }
 
 }  // extern "C"

@@ -1,0 +1,444 @@
+// lgs_wgrad.hip -- weight gradient of the sparse convolution on gfx950.
+//
+// Replaces the wgrad half of MinkowskiConvolution[Transpose]'s autograd backward
+//   /root/reference/models/modules/common.py:195-203,228-236 ; call sites res16unet.py:196-270
+//
+//   gw[k][ci][co] = sum over pairs (i, o) of kernel offset k:  in[i][ci] * gout[o][co]
+//
+// It is a GEMM whose reduction axis is the (ragged, gathered) pair list, so neither operand is in MFMA
+// fragment order in memory: the fragment wants 8 consecutive PAIRS of one channel per lane while HBM holds
+// rows of channels.  bf16 path (k_wgrad_bf16): each wavefront works alone -- it ballot-compacts the valid
+// pairs of its position range into LDS, then per group of 16 pairs gathers the 16 input rows and 16
+// grad rows with 16-byte loads (whole 64..256-byte row pieces), parks them row-major in a wave-private
+// LDS tile and reads them back TRANSPOSED with ds_read_b64_tr_b16 (gfx950), which yields exactly the
+// 32x32x16 bf16 MFMA operand layout; the row stride is chosen = 64 (mod 256) bytes so the transposing
+// reads are bank-conflict free.  No workgroup barriers.  Partials per wave slot are written once and folded
+// by k_wgrad_reduce in a fixed order (deterministic, no float atomics).
+// fp32 path (k_wgrad_f32): v_mfma_f32_32x32x2_f32 takes ONE element per lane, so rows are read straight
+// from HBM in operand order (32 consecutive channels of 2 pairs per instruction) -- exact fp32.
+#include "lgs_common.h"
+
+namespace lgs {
+
+// ------------------------------------------------------------------------------------ fp32 (exact) path
+constexpr int kWgChunk = 512;  // positions compacted per iteration
+
+template <typename T, int NCB>
+__global__ __launch_bounds__(256) void k_wgrad_f32(View v, const T *__restrict__ in, int cin_real, const T *__restrict__ gout,
+                                                   int cout_real, int cin_pad, int cout_pad, int64_t span,
+                                                   float *__restrict__ partial) {
+  __shared__ int32_t l_in[kWgChunk], l_out[kWgChunk];
+  __shared__ int32_t l_cnt[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vx = lane & 31, h = lane >> 5;
+  const int k = blockIdx.y;
+  const int n_cot = cout_pad / (32 * NCB);
+  const int cot = blockIdx.z % n_cot, cig = blockIdx.z / n_cot;
+  const int cib = cig * 4 + wave;
+  const bool wave_active = cib * 32 < cin_pad;
+  const int slot = v.KS > 1 ? k : 0;
+
+  f32x16 acc[NCB];
+#pragma unroll
+  for (int nb = 0; nb < NCB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+  const int64_t p_begin = (int64_t)blockIdx.x * span;
+  const int64_t p_end = min(p_begin + span, v.n_pad);
+  for (int64_t base = p_begin; base < p_end; base += kWgChunk) {
+    // ---- compact valid pairs of this chunk (two positions per thread, fixed wave order)
+    int32_t my_in[2], my_out[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int64_t p = base + wave * 128 + u * 64 + lane;
+      int32_t i = -1, o = -1;
+      if (p < p_end) {
+        bool grp_ok = true;
+        if (v.KS > 1) grp_ok = (v.mask64[p >> 6] >> slot) & 1u;
+        else if (v.tile_k) grp_ok = v.tile_k[p >> 6] == k;
+        if (grp_ok) {
+          o = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
+          i = v.nbr ? v.nbr[(int64_t)slot * v.n_pad + p] : (p < v.n_in ? (int32_t)p : -1);
+        }
+      }
+      my_in[u] = (i >= 0 && o >= 0) ? i : -1;
+      my_out[u] = o;
+    }
+    unsigned long long bal0 = __ballot(my_in[0] >= 0), bal1 = __ballot(my_in[1] >= 0);
+    int c0 = (int)__builtin_popcountll(bal0), c1 = (int)__builtin_popcountll(bal1);
+    if (lane == 0) l_cnt[wave] = c0 + c1;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      int c = l_cnt[w];
+      if (w < wave) wbase += c;
+      total += c;
+    }
+    if (my_in[0] >= 0) {
+      int at = wbase + (int)__builtin_popcountll(bal0 & ((1ull << lane) - 1ull));
+      l_in[at] = my_in[0]; l_out[at] = my_out[0];
+    }
+    if (my_in[1] >= 0) {
+      int at = wbase + c0 + (int)__builtin_popcountll(bal1 & ((1ull << lane) - 1ull));
+      l_in[at] = my_in[1]; l_out[at] = my_out[1];
+    }
+    __syncthreads();
+    // ---- MFMA over the compacted pairs, two pairs (k = h) per 32x32x2 instruction
+    if (wave_active) {
+      const int ci = cib * 32 + vx;
+      for (int j = 0; j < total; j += 8) {
+        float a[4], b[4][NCB];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          int pr = j + 2 * u + h;
+          bool ok = pr < total;
+          int32_t irow = ok ? l_in[pr] : 0, orow = ok ? l_out[pr] : 0;
+          a[u] = (ok && ci < cin_real) ? ld_elem(in + (int64_t)irow * cin_real + ci) : 0.f;
+#pragma unroll
+          for (int nb = 0; nb < NCB; ++nb) {
+            int co = (cot * NCB + nb) * 32 + vx;
+            b[u][nb] = (ok && co < cout_real) ? ld_elem(gout + (int64_t)orow * cout_real + co) : 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int nb = 0; nb < NCB; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][nb], acc[nb], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (!wave_active) return;
+  // D[i = ci][j = co]: lane holds column j = vx, rows (r&3) + 8*(r>>2) + 4*h
+  float *dst = partial + (((int64_t)blockIdx.x * v.K + k) * cin_pad) * cout_pad;
+#pragma unroll
+  for (int nb = 0; nb < NCB; ++nb) {
+    int co = (cot * NCB + nb) * 32 + vx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int ci = cib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      dst[(int64_t)ci * cout_pad + co] = acc[nb][r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ bf16 MFMA path
+constexpr int kQ = 512;  // positions compacted per wave chunk
+
+// row stride (bytes) of a [16 pairs][C channels] bf16 tile, = 64 (mod 256) -> conflict-free tr reads
+__host__ __device__ constexpr int tile_stride(int c) {
+  int s = c * 2;
+  while ((s / 64) % 4 != 1 && (s / 64) % 4 != 3) s += 64;
+  return s;
+}
+
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+template <int NCI, int NCO>
+__global__ __launch_bounds__(256) void k_wgrad_bf16(View v, const bf16_t *__restrict__ in, int cin_real,
+                                                    const bf16_t *__restrict__ gout, int cout_real, int cin_pad,
+                                                    int cout_pad, int64_t span, int n_ci_tasks,
+                                                    float *__restrict__ partial) {
+  constexpr int CA = 32 * NCI, CG = 32 * NCO;
+  constexpr int SA = tile_stride(CA), SG = tile_stride(CG);
+  constexpr int LA = (16 * CA / 8 + 63) / 64, LG = (16 * CG / 8 + 63) / 64;  // 16-byte loads per lane per group
+  constexpr int WAVE_BYTES = 2 * kQ * 4 + 16 * SA + 16 * SG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char *wbase = smem + wave * WAVE_BYTES;
+  int32_t *q_in = reinterpret_cast<int32_t *>(wbase);
+  int32_t *q_out = q_in + kQ;
+  char *stA = wbase + 2 * kQ * 4;
+  char *stG = stA + 16 * SA;
+
+  const int k = blockIdx.y;
+  const int cit = blockIdx.z % n_ci_tasks, cot = blockIdx.z / n_ci_tasks;
+  const int ci0 = cit * CA, co0 = cot * CG;
+  const int slot = v.KS > 1 ? k : 0;
+  const int64_t wslot = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t p_begin = wslot * span;
+  const int64_t p_end = min(p_begin + span, v.n_pad);
+
+  f32x16 acc[NCI][NCO];
+#pragma unroll
+  for (int a = 0; a < NCI; ++a)
+#pragma unroll
+    for (int b = 0; b < NCO; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // lane roles
+  // loads: chunk id = q*64 + lane -> (row, 16-byte column chunk)
+  // tr read: 16-lane group g = lane>>4: cb = g&1 (16-channel half), h = g>>1 (pairs 8h..8h+7); lane i = lane&15
+  //          supplies the 8-byte address (row 8h + 4*rd + i/4, channel 32*blk + 16*cb + 4*(i%4))
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int tr_row = 8 * (g16 >> 1) + (i16 >> 2);
+  const int tr_col = 16 * (g16 & 1) + 4 * (i16 & 3);
+
+  for (int64_t base = p_begin; base < p_end; base += kQ) {
+    // ---- ballot-compact the valid pairs of up to kQ positions (wave-private, in order)
+    int n = 0;
+    const int64_t cend = min(base + kQ, p_end);
+    for (int64_t b = base; b < cend; b += 64) {
+      bool grp_ok = true;
+      if (v.KS > 1) grp_ok = (v.mask64[b >> 6] >> slot) & 1u;
+      else if (v.tile_k) grp_ok = v.tile_k[b >> 6] == k;
+      if (!grp_ok) continue;  // wave-uniform
+      const int64_t p = b + lane;
+      int32_t o = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
+      int32_t i = v.nbr ? v.nbr[(int64_t)slot * v.n_pad + p] : (p < v.n_in ? (int32_t)p : -1);
+      const bool ok = (i >= 0) && (o >= 0);
+      const unsigned long long bal = __ballot(ok);
+      if (ok) {
+        const int at = n + (int)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+        q_in[at] = i; q_out[at] = o;
+      }
+      n += (int)__builtin_popcountll(bal);
+    }
+    const int ngroups = (n + 15) >> 4;
+    if (lane < 16 && n + lane < ngroups * 16) { q_in[n + lane] = -1; q_out[n + lane] = -1; }
+    __builtin_amdgcn_wave_barrier();
+
+    uint4 ra[LA], rg[LG];
+    auto issue = [&](int g) {
+#pragma unroll
+      for (int q = 0; q < LA; ++q) {
+        const int id = q * 64 + lane;
+        const int row = id / (CA / 8), ch = (id % (CA / 8)) * 8;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (row < 16) {
+          const int32_t r = q_in[g * 16 + row];
+          if (r >= 0 && ci0 + ch + 8 <= cin_real) val = *reinterpret_cast<const uint4 *>(in + (int64_t)r * cin_real + ci0 + ch);
+        }
+        ra[q] = val;
+      }
+#pragma unroll
+      for (int q = 0; q < LG; ++q) {
+        const int id = q * 64 + lane;
+        const int row = id / (CG / 8), ch = (id % (CG / 8)) * 8;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (row < 16) {
+          const int32_t r = q_out[g * 16 + row];
+          if (r >= 0 && co0 + ch + 8 <= cout_real) val = *reinterpret_cast<const uint4 *>(gout + (int64_t)r * cout_real + co0 + ch);
+        }
+        rg[q] = val;
+      }
+    };
+    if (ngroups > 0) issue(0);
+    for (int g = 0; g < ngroups; ++g) {
+      // park the 16 x CA and 16 x CG row pieces row-major in the wave's LDS tile
+#pragma unroll
+      for (int q = 0; q < LA; ++q) {
+        const int id = q * 64 + lane;
+        const int row = id / (CA / 8), ch = (id % (CA / 8)) * 8;
+        if (row < 16) *reinterpret_cast<uint4 *>(stA + row * SA + ch * 2) = ra[q];
+      }
+#pragma unroll
+      for (int q = 0; q < LG; ++q) {
+        const int id = q * 64 + lane;
+        const int row = id / (CG / 8), ch = (id % (CG / 8)) * 8;
+        if (row < 16) *reinterpret_cast<uint4 *>(stG + row * SG + ch * 2) = rg[q];
+      }
+      if (g + 1 < ngroups) issue(g + 1);  // next group's rows fly under the transposing reads + MFMAs
+      __builtin_amdgcn_wave_barrier();
+      // transposing reads -> MFMA operands (lane: channel = lane&31 of the block, pairs 8h..8h+7)
+      bf16x8 fa[NCI], fg[NCO];
+#pragma unroll
+      for (int a = 0; a < NCI; ++a) {
+        const char *p0 = stA + tr_row * SA + (32 * a + tr_col) * 2;
+        short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(p0));
+        short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(p0 + 4 * SA));
+        uint4 pk;
+        pk.x = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+        pk.y = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+        pk.z = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+        pk.w = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+        fa[a] = __builtin_bit_cast(bf16x8, pk);
+      }
+#pragma unroll
+      for (int b = 0; b < NCO; ++b) {
+        const char *p0 = stG + tr_row * SG + (32 * b + tr_col) * 2;
+        short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(p0));
+        short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(p0 + 4 * SG));
+        uint4 pk;
+        pk.x = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+        pk.y = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+        pk.z = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+        pk.w = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+        fg[b] = __builtin_bit_cast(bf16x8, pk);
+      }
+#pragma unroll
+      for (int a = 0; a < NCI; ++a)
+#pragma unroll
+        for (int b = 0; b < NCO; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fg[b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // ---- partial[wslot][k][ci][co]: D[i = ci][j = co], lane holds column j = lane&31, rows (r&3)+8(r>>2)+4h
+  const int vx = lane & 31, h = lane >> 5;
+  float *dst = partial + ((wslot * v.K + k) * cin_pad) * (int64_t)cout_pad;
+#pragma unroll
+  for (int a = 0; a < NCI; ++a)
+#pragma unroll
+    for (int b = 0; b < NCO; ++b) {
+      const int co = co0 + 32 * b + vx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (ci < cin_pad && co < cout_pad) dst[(int64_t)ci * cout_pad + co] = acc[a][b][r];
+      }
+    }
+}
+
+__global__ void k_wgrad_reduce(const float *__restrict__ partial, int S, int K, int cin_pad, int cout_pad, int cin,
+                               int cout, float *__restrict__ gw) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)K * cin * cout;
+  if (idx >= total) return;
+  int co = (int)(idx % cout);
+  int ci = (int)((idx / cout) % cin);
+  int k = (int)(idx / ((int64_t)cout * cin));
+  float s = 0.f;
+  for (int x = 0; x < S; ++x) s += partial[(((int64_t)x * K + k) * cin_pad + ci) * cout_pad + co];
+  gw[idx] = s;
+}
+
+// ------------------------------------------------------------------------------------ host side
+struct WgradPlan {
+  int S;          // partial slots
+  int64_t span;   // positions per slot
+  int cin_pad, cout_pad;
+  int ncb;        // fp32 path: co blocks per wave
+  int nci, nco;   // bf16 path: wave tile in 32-channel blocks
+  int n_ci_tasks, n_co_tasks;
+};
+
+inline WgradPlan wgrad_plan(const View &v, int cin, int cout, int dtype) {
+  WgradPlan p{};
+  p.cin_pad = pad32(cin);
+  p.cout_pad = pad32(cout);
+  const int nbi = p.cin_pad / 32, nbo = p.cout_pad / 32;
+  int64_t per = (int64_t)v.K * p.cin_pad * p.cout_pad * 4;
+  if (dtype == LGS_BF16) {
+    // wave tile <= 4 x 3 blocks (192 accumulator registers)
+    p.nci = nbi >= 4 ? 4 : nbi;
+    p.nco = nbo >= 3 ? 3 : nbo;
+    if (nbo % 3 != 0 && nbo % 2 == 0 && nbo >= 2) p.nco = 2;
+    if (nbo % 4 == 0 && p.nci <= 3) p.nco = 4;
+    p.n_ci_tasks = (nbi + p.nci - 1) / p.nci;
+    p.n_co_tasks = (nbo + p.nco - 1) / p.nco;
+    int64_t tasks = (int64_t)v.K * p.n_ci_tasks * p.n_co_tasks;
+    int64_t want = (2048 + tasks - 1) / tasks;           // wave slots so that ~2048 waves are in flight
+    int64_t maxs = (v.n_pad + 1023) / 1024;              // at least 1024 positions per slot
+    int64_t S = want < maxs ? want : maxs;
+    if (S < 1) S = 1;
+    S = (S + 3) / 4 * 4;                                  // 4 waves per workgroup
+    while (S > 4 && S * per > (1ll << 30)) S -= 4;
+    p.span = ((v.n_pad + S - 1) / S + 63) / 64 * 64;
+    p.S = (int)S;
+  } else {
+    p.ncb = (nbo % 4 == 0) ? 4 : (nbo % 3 == 0) ? 3 : (nbo % 2 == 0) ? 2 : 1;
+    int64_t chunks = (v.n_pad + kWgChunk - 1) / kWgChunk;
+    int64_t S = chunks / 4;
+    if (S < 1) S = 1;
+    if (S > 64) S = 64;
+    while (S > 1 && S * per > (1ll << 30)) S /= 2;
+    int64_t cps = (chunks + S - 1) / S;
+    p.span = cps * kWgChunk;
+    p.S = (int)((v.n_pad + p.span - 1) / p.span);
+    if (p.S < 1) p.S = 1;
+  }
+  return p;
+}
+
+int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype) {
+  WgradPlan a = wgrad_plan(km->fwd, cin, cout, dtype), b = wgrad_plan(km->bwd, cin, cout, dtype);
+  int64_t per = (int64_t)km->K * pad32(cin) * pad32(cout) * 4;
+  return align256((int64_t)(a.S > b.S ? a.S : b.S) * per) + 256;
+}
+
+template <int NCI, int NCO>
+int launch_wgrad_bf16(const View &v, const WgradPlan &p, const bf16_t *in, int cin, const bf16_t *go, int cout,
+                      float *partial, hipStream_t s) {
+  constexpr int CA = 32 * NCI, CG = 32 * NCO;
+  constexpr int WAVE_BYTES = 2 * kQ * 4 + 16 * tile_stride(CA) + 16 * tile_stride(CG);
+  dim3 grid((unsigned)(p.S / 4), (unsigned)v.K, (unsigned)(p.n_ci_tasks * p.n_co_tasks));
+  hipLaunchKernelGGL((k_wgrad_bf16<NCI, NCO>), grid, 256, 4 * WAVE_BYTES, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span,
+                     p.n_ci_tasks, partial);
+  return 0;
+}
+
+int conv_wgrad_bf16(const View &v, const void *in_v, int cin, const void *gout_v, int cout, float *gw, void *workspace,
+                    hipStream_t s) {
+  LGS_REQUIRE(cin % 8 == 0 && cout % 8 == 0, "bf16 wgrad: channel counts must be multiples of 8 (16-byte rows)");
+  WgradPlan p = wgrad_plan(v, cin, cout, LGS_BF16);
+  float *partial = reinterpret_cast<float *>(workspace);
+  const bf16_t *in = reinterpret_cast<const bf16_t *>(in_v), *go = reinterpret_cast<const bf16_t *>(gout_v);
+  // every (slot, k, ci, co) element of `partial` is written exactly once by the wave that owns it
+#define LGS_WG(A, B) if (p.nci == A && p.nco == B) { launch_wgrad_bf16<A, B>(v, p, in, cin, go, cout, partial, s); } else
+  LGS_WG(1, 1) LGS_WG(1, 2) LGS_WG(1, 3) LGS_WG(1, 4)
+  LGS_WG(2, 1) LGS_WG(2, 2) LGS_WG(2, 3) LGS_WG(2, 4)
+  LGS_WG(3, 1) LGS_WG(3, 2) LGS_WG(3, 3) LGS_WG(3, 4)
+  LGS_WG(4, 1) LGS_WG(4, 2) LGS_WG(4, 3)
+  { LGS_REQUIRE(false, "bf16 wgrad: no kernel instance for this tile"); }
+#undef LGS_WG
+  int64_t total = (int64_t)v.K * cin * cout;
+  hipLaunchKernelGGL(k_wgrad_reduce, (unsigned)((total + 255) / 256), 256, 0, s, partial, p.S, v.K, p.cin_pad, p.cout_pad, cin,
+                     cout, gw);
+  LGS_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int conv_wgrad_f32path(const View &v, const void *in_v, int cin, const void *gout_v, int cout, float *gw, void *workspace,
+                       hipStream_t s) {
+  WgradPlan p = wgrad_plan(v, cin, cout, LGS_F32);
+  float *partial = reinterpret_cast<float *>(workspace);
+  const T *in = reinterpret_cast<const T *>(in_v);
+  const T *go = reinterpret_cast<const T *>(gout_v);
+  int n_cot = p.cout_pad / (32 * p.ncb);
+  int n_cig = (p.cin_pad / 32 + 3) / 4;
+  dim3 grid((unsigned)p.S, (unsigned)v.K, (unsigned)(n_cot * n_cig));
+  switch (p.ncb) {
+    case 4: hipLaunchKernelGGL((k_wgrad_f32<T, 4>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
+    case 3: hipLaunchKernelGGL((k_wgrad_f32<T, 3>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
+    case 2: hipLaunchKernelGGL((k_wgrad_f32<T, 2>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
+    default: hipLaunchKernelGGL((k_wgrad_f32<T, 1>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
+  }
+  int64_t total = (int64_t)v.K * cin * cout;
+  hipLaunchKernelGGL(k_wgrad_reduce, (unsigned)((total + 255) / 256), 256, 0, s, partial, p.S, v.K, p.cin_pad, p.cout_pad, cin,
+                     cout, gw);
+  LGS_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace lgs
+
+using namespace lgs;
+
+extern "C" {
+
+int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const void *grad_out, int cout,
+                   float *grad_weight, int dtype, void *workspace, void *stream) {
+  LGS_REQUIRE(km && grad_weight && workspace, "lgs_conv_wgrad: null argument");
+  LGS_REQUIRE(!(transposed && km->ks == 3), "transposed 3x3x3 convolution is not part of the model family");
+  const View &v = transposed ? km->bwd : km->fwd;  // same view as the forward
+  View vv = v; vv.mirror = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (vv.n_pad == 0) {
+    LGS_HIP(hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)km->K * cin * cout, s));
+    return 0;
+  }
+  if (dtype == LGS_F32) return conv_wgrad_f32path<float>(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
+  if (dtype == LGS_BF16) {
+    if (cin % 8 == 0 && cout % 8 == 0) return conv_wgrad_bf16(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
+    return conv_wgrad_f32path<bf16_t>(vv, in, cin, grad_out, cout, grad_weight, workspace, s);  // e.g. the 3-channel input layer
+  }
+  LGS_REQUIRE(false, "lgs_conv_wgrad: unknown dtype");
+}
+
+}  // extern "C"

@@ -247,3 +247,34 @@ def test_clip_similarity_mfma_matches_fp64(c):
     assert rel_err(inv.cpu().numpy(), rinv.numpy()) < 1e-5
     simb, _ = ME.get_backend().clip_similarity(f.to(DEV).bfloat16(), t.to(DEV))
     assert np.abs(simb.cpu().numpy() - ref.numpy()).max() < 6e-3
+
+
+BF16_CASES = [(32, 32, 3, 1), (96, 96, 3, 1), (128, 96, 3, 1), (256, 128, 3, 1), (192, 128, 3, 1), (96, 200, 1, 1),
+              (64, 64, 2, 2), (384, 256, 3, 1), (8, 16, 3, 1)]
+
+
+@pytest.mark.parametrize("cin,cout,ks,st", BF16_CASES)
+def test_bf16_mfma_paths_all_tile_shapes(cin, cout, ks, st):
+    """every (wave tile, channel split) instance of the bf16 forward / dgrad / wgrad kernels vs the fp32 oracle"""
+    coords = small_scene(21, n=3000, extent=28)
+    feats = np.random.default_rng(9).standard_normal((coords.shape[0], cin)).astype(np.float32)
+    feats = torch.from_numpy(feats).bfloat16().float().numpy()
+    (h_out, h_g), (o_out, o_g) = run_both(
+        lambda: [ME.MinkowskiConvolution(cin, cout, kernel_size=ks, stride=st, bias=(ks == 1), dimension=3)], coords, feats,
+        dtype=torch.bfloat16)
+    assert rel_err(h_out, o_out) < 2e-2
+    for n, a, b in zip(["dgrad", "wgrad", "bgrad"], h_g, o_g):
+        assert rel_err(a, b) < 2e-2, n
+
+
+def test_bf16_transposed_conv_wgrad():
+    coords = small_scene(22, n=3000, extent=32)
+    feats = torch.from_numpy(np.random.default_rng(3).standard_normal((coords.shape[0], 32)).astype(np.float32)).bfloat16().float().numpy()
+
+    def build():
+        return [ME.MinkowskiConvolution(32, 64, kernel_size=2, stride=2, dimension=3),
+                ME.MinkowskiConvolutionTranspose(64, 96, kernel_size=2, stride=2, dimension=3)]
+    (h_out, h_g), (o_out, o_g) = run_both(build, coords, feats, dtype=torch.bfloat16)
+    assert rel_err(h_out, o_out) < 3e-2
+    for a, b in zip(h_g, o_g):
+        assert rel_err(a, b) < 3e-2
