@@ -36,6 +36,7 @@ if ROOT not in sys.path:
 import MinkowskiEngine as ME  # noqa: E402
 from languagegroundedsemseg_amd import models  # noqa: E402
 from languagegroundedsemseg_amd.ddp import BucketedDDP  # noqa: E402
+from languagegroundedsemseg_amd.losses import fused_cross_entropy  # noqa: E402
 from languagegroundedsemseg_amd.synthetic import make_batch  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md; 6.29 TB/s measured float4 copy)
@@ -131,7 +132,7 @@ def train_step(model, ddp, opt, coords, feats, labels, dtype, step_idx, shift=Tr
     ddp.zero_grad()
     sinput = ME.SparseTensor(feats.to(dtype), c)                       # coordinate hash + maps live for this step only
     logits, _ = model(sinput)
-    loss = torch.nn.functional.cross_entropy(logits.F.float(), labels, ignore_index=-1)
+    loss = fused_cross_entropy(logits.F, labels, ignore_index=-1)
     loss.backward()
     ddp.finalize()
     opt.step()

@@ -136,6 +136,15 @@ int lgs_clip_similarity(const void *feat, int64_t n, int c, const float *anchors
                         float *inv_norm_f, int dtype, void *workspace, void *stream);
 int64_t lgs_clip_workspace_bytes(int c, int n_anchor, int dtype);
 
+/* ---- fused softmax cross-entropy ----------------------------------------------------------------
+ * replaces nn.CrossEntropyLoss(ignore_index=-1) on the [N,200] logits of the fine-tune step
+ *   /root/reference/lib/train_test/pl_BaselineTrainer.py:94-99,350
+ * One pass: loss_rows[n] (float32, 0 for ignored rows) and dlogits[n,c] = (softmax - onehot) * (*scale)
+ * (same dtype as logits, zeros for ignored rows).  `scale` is a DEVICE float (e.g. 1 / #valid rows), so
+ * the mean reduction needs no host sync. */
+int lgs_ce_forward_backward(const void *logits, int64_t n, int c, const int64_t *labels, int64_t ignore_index,
+                            const float *scale, float *loss_rows, void *dlogits, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,118 @@
+// lgs_loss.hip -- fused softmax cross-entropy (forward + gradient in one pass) over [N, C] logits, gfx950.
+//
+// Replaces nn.CrossEntropyLoss(ignore_index=-1) on the [N,200] logits of the fine-tune step
+//   /root/reference/lib/train_test/pl_BaselineTrainer.py:94-99,350
+// HBM-bound: logits are read once (16-byte loads, half a wavefront per row), the per-row loss and the
+// gradient (softmax - onehot) * scale are written in the same pass; ignored rows produce 0 / zeros.
+#include "lgs_common.h"
+
+namespace lgs {
+
+template <typename T> struct LVec;
+template <> struct LVec<float> {
+  static constexpr int W = 4;
+  __device__ static void load(const float *p, float (&v)[4]) { float4 x = *reinterpret_cast<const float4 *>(p); v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
+  __device__ static void store(float *p, const float (&v)[4]) { *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct LVec<bf16_t> {
+  static constexpr int W = 8;
+  __device__ static void load(const bf16_t *p, float (&v)[8]) {
+    uint4 x = *reinterpret_cast<const uint4 *>(p);
+    uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_to_f32((uint16_t)(w[i] & 0xffff)); v[2 * i + 1] = bf16_to_f32((uint16_t)(w[i] >> 16)); }
+  }
+  __device__ static void store(bf16_t *p, const float (&v)[8]) {
+    uint4 x;
+    x.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    x.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    x.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+    x.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    *reinterpret_cast<uint4 *>(p) = x;
+  }
+};
+
+constexpr int kMaxChunks = 4;  // 16-byte chunks per lane per row: C <= 32 * 4 * W
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_ce_fwd_bwd(const T *__restrict__ logits, int64_t n, int c, const int64_t *__restrict__ labels,
+                                                    int64_t ignore_index, const float *__restrict__ scale_ptr,
+                                                    float *__restrict__ loss_rows, T *__restrict__ dlogits) {
+  constexpr int W = LVec<T>::W;
+  const int lane = threadIdx.x & 31;  // half-wave per row
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  if (row >= n) return;
+  const int nchunk = c / W;
+  const int64_t lab = labels[row];
+  const bool ignored = (lab == ignore_index) || lab < 0 || lab >= c;
+  float v[kMaxChunks][W];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int q = 0; q < kMaxChunks; ++q) {
+    const int ch = q * 32 + lane;
+    if (ch < nchunk) {
+      LVec<T>::load(logits + row * c + ch * W, v[q]);
+#pragma unroll
+      for (int i = 0; i < W; ++i) mx = fmaxf(mx, v[q][i]);
+    }
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 32));
+  float se = 0.f, xl = 0.f;
+#pragma unroll
+  for (int q = 0; q < kMaxChunks; ++q) {
+    const int ch = q * 32 + lane;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int i = 0; i < W; ++i) {
+        const float e = __expf(v[q][i] - mx);
+        se += e;
+        if ((int64_t)(ch * W + i) == lab) xl = v[q][i];
+        v[q][i] = e;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) { se += __shfl_xor(se, o, 32); xl += __shfl_xor(xl, o, 32); }
+  const float lse = mx + __logf(se);
+  if (lane == 0) loss_rows[row] = ignored ? 0.f : (lse - xl);
+  const float scale = ignored ? 0.f : *scale_ptr;
+  const float inv = scale / se;
+#pragma unroll
+  for (int q = 0; q < kMaxChunks; ++q) {
+    const int ch = q * 32 + lane;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int i = 0; i < W; ++i) {
+        float g = v[q][i] * inv;
+        if ((int64_t)(ch * W + i) == lab) g -= scale;
+        v[q][i] = g;
+      }
+      LVec<T>::store(dlogits + row * c + ch * W, v[q]);
+    }
+  }
+}
+
+}  // namespace lgs
+
+using namespace lgs;
+
+extern "C" int lgs_ce_forward_backward(const void *logits, int64_t n, int c, const int64_t *labels, int64_t ignore_index,
+                                       const float *scale, float *loss_rows, void *dlogits, int dtype, void *stream) {
+  LGS_REQUIRE(logits && labels && scale && loss_rows && dlogits, "lgs_ce_forward_backward: null argument");
+  const int W = dtype == LGS_BF16 ? 8 : 4;
+  LGS_REQUIRE(c % W == 0 && c / W <= 32 * kMaxChunks, "lgs_ce_forward_backward: class count unsupported");
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)((n * 32 + 255) / 256);
+  if (dtype == LGS_F32)
+    hipLaunchKernelGGL((k_ce_fwd_bwd<float>), blocks, 256, 0, s, (const float *)logits, n, c, labels, ignore_index, scale, loss_rows,
+                       (float *)dlogits);
+  else if (dtype == LGS_BF16)
+    hipLaunchKernelGGL((k_ce_fwd_bwd<bf16_t>), blocks, 256, 0, s, (const bf16_t *)logits, n, c, labels, ignore_index, scale, loss_rows,
+                       (bf16_t *)dlogits);
+  else
+    LGS_REQUIRE(false, "lgs_ce_forward_backward: unknown dtype");
+  LGS_HIP(hipGetLastError());
+  return 0;
+}

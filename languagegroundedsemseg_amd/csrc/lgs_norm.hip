@@ -8,8 +8,8 @@
 // Pure HBM-bound streaming work: features are [N, C] row-major with C in
 // {32..512}; a thread owns a fixed group of 4 (fp32) or 8 (bf16) adjacent channels = one 16-byte
 // access and walks rows, so every wave instruction is a fully coalesced 1 KiB access.  Statistics
-// are reduced per block in LDS, then across blocks through a [blocks, 2C] fp32 scratch that the last
-// block (agent-scope ticket) folds in a fixed order -> deterministic, no float atomics.
+// are reduced per block in LDS, then across blocks through a [blocks, 2C] fp32 scratch that a small fold
+// kernel sums in a fixed order (double accumulation) -> deterministic, no float atomics.
 #include "lgs_common.h"
 
 namespace lgs {
@@ -113,14 +113,29 @@ __global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, cons
   }
 }
 
-// fold the per-block partials (fixed order) and finish: forward -> mean / invstd / running stats,
-// backward -> dbeta = sum dy', dgamma = sum dy' xhat  (kept in `out` as [2][C])
-__global__ void k_fold_fwd(const float *__restrict__ scratch, int nblocks, int c, int64_t n, float eps, float momentum,
-                           float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ stats) {
-  int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nblocks; ++b) { s += scratch[(int64_t)b * 2 * c + ch]; ss += scratch[(int64_t)b * 2 * c + c + ch]; }
+// fold the per-block partials (fixed order, deterministic) and finish: forward -> mean / invstd / running stats,
+// backward -> dbeta = sum dy', dgamma = sum dy' xhat.  Block = 64 channels x 4 partial-slices; each thread sums
+// every 4th partial (coalesced across channels), slices are combined through LDS.
+__device__ inline void fold_sums(const float *__restrict__ scratch, int nblocks, int c, int ch, int part, double &s, double &ss,
+                                 double (*red)[2][64]) {
+  s = 0.0; ss = 0.0;
+  if (ch < c)
+    for (int b = part; b < nblocks; b += 4) { s += scratch[(int64_t)b * 2 * c + ch]; ss += scratch[(int64_t)b * 2 * c + c + ch]; }
+  red[part][0][threadIdx.x & 63] = s;
+  red[part][1][threadIdx.x & 63] = ss;
+  __syncthreads();
+  if (part == 0) {
+    for (int q = 1; q < 4; ++q) { s += red[q][0][threadIdx.x & 63]; ss += red[q][1][threadIdx.x & 63]; }
+  }
+}
+__global__ __launch_bounds__(256) void k_fold_fwd(const float *__restrict__ scratch, int nblocks, int c, int64_t n, float eps,
+                                                  float momentum, float *__restrict__ running_mean,
+                                                  float *__restrict__ running_var, float *__restrict__ stats) {
+  __shared__ double red[4][2][64];
+  const int ch = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  double s, ss;
+  fold_sums(scratch, nblocks, c, ch, part, s, ss, red);
+  if (part != 0 || ch >= c) return;
   double mean = n > 0 ? s / (double)n : 0.0;
   double var = n > 0 ? ss / (double)n - mean * mean : 0.0;
   if (var < 0.0) var = 0.0;
@@ -132,12 +147,13 @@ __global__ void k_fold_fwd(const float *__restrict__ scratch, int nblocks, int c
     running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
   }
 }
-__global__ void k_fold_bwd(const float *__restrict__ scratch, int nblocks, int c, float *__restrict__ dgamma,
-                           float *__restrict__ dbeta, float *__restrict__ sums) {
-  int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nblocks; ++b) { s += scratch[(int64_t)b * 2 * c + ch]; ss += scratch[(int64_t)b * 2 * c + c + ch]; }
+__global__ __launch_bounds__(256) void k_fold_bwd(const float *__restrict__ scratch, int nblocks, int c, float *__restrict__ dgamma,
+                                                  float *__restrict__ dbeta, float *__restrict__ sums) {
+  __shared__ double red[4][2][64];
+  const int ch = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  double s, ss;
+  fold_sums(scratch, nblocks, c, ch, part, s, ss, red);
+  if (part != 0 || ch >= c) return;
   dbeta[ch] = (float)s;
   dgamma[ch] = (float)ss;
   sums[ch] = (float)s;
@@ -201,8 +217,8 @@ __global__ __launch_bounds__(kNT) void k_bn_bwd_apply(const T *__restrict__ x, c
 }
 
 inline int reduce_blocks(int64_t n, int64_t *rows_per_block) {
-  int64_t nb = (n + 511) / 512;
-  if (nb > 1024) nb = 1024;
+  int64_t nb = (n + 1023) / 1024;
+  if (nb > 512) nb = 512;
   if (nb < 1) nb = 1;
   *rows_per_block = (n + nb - 1) / nb;
   if (*rows_per_block < 1) *rows_per_block = 1;
@@ -221,7 +237,7 @@ int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const flo
   const T *x = reinterpret_cast<const T *>(xv);
   hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, n, c, 0,
                      rpb, scratch);
-  hipLaunchKernelGGL(k_fold_fwd, (c + 63) / 64, 64, 0, s, scratch, nb, c, n, eps, momentum, rm, rv, stats);
+  hipLaunchKernelGGL(k_fold_fwd, (c + 63) / 64, 256, 0, s, scratch, nb, c, n, eps, momentum, rm, rv, stats);
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
@@ -245,7 +261,7 @@ int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, in
   float *sums = scratch + (size_t)2 * c * nb;
   const T *x = reinterpret_cast<const T *>(xv), *y = reinterpret_cast<const T *>(yv), *dy = reinterpret_cast<const T *>(dyv);
   hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, x, y, dy, stats, n, c, relu, rpb, scratch);
-  hipLaunchKernelGGL(k_fold_bwd, (c + 63) / 64, 64, 0, s, scratch, nb, c, dgamma, dbeta, sums);
+  hipLaunchKernelGGL(k_fold_bwd, (c + 63) / 64, 256, 0, s, scratch, nb, c, dgamma, dbeta, sums);
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);

@@ -358,7 +358,12 @@ inline WgradPlan wgrad_plan(const View &v, int cin, int cout, int dtype) {
 int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype) {
   WgradPlan a = wgrad_plan(km->fwd, cin, cout, dtype), b = wgrad_plan(km->bwd, cin, cout, dtype);
   int64_t per = (int64_t)km->K * pad32(cin) * pad32(cout) * 4;
-  return align256((int64_t)(a.S > b.S ? a.S : b.S) * per) + 256;
+  int64_t bytes = align256((int64_t)(a.S > b.S ? a.S : b.S) * per) + 256;
+  if (dtype == LGS_BF16 && cin % 8 != 0) {
+    int64_t nmax = km->fwd.n_in > km->bwd.n_in ? km->fwd.n_in : km->bwd.n_in;
+    bytes += align256(nmax * (int64_t)((cin + 7) / 8 * 8) * 2);
+  }
+  return bytes;
 }
 
 template <int NCI, int NCO>
@@ -372,12 +377,30 @@ int launch_wgrad_bf16(const View &v, const WgradPlan &p, const bf16_t *in, int c
   return 0;
 }
 
+__global__ void k_pad_rows_bf16(const bf16_t *__restrict__ src, int64_t n, int c, int cpad, bf16_t *__restrict__ dst) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * cpad) return;
+  int64_t r = i / cpad;
+  int ch = (int)(i % cpad);
+  dst[i] = ch < c ? src[r * c + ch] : (bf16_t)0;
+}
+
 int conv_wgrad_bf16(const View &v, const void *in_v, int cin, const void *gout_v, int cout, float *gw, void *workspace,
                     hipStream_t s) {
-  LGS_REQUIRE(cin % 8 == 0 && cout % 8 == 0, "bf16 wgrad: channel counts must be multiples of 8 (16-byte rows)");
+  LGS_REQUIRE(cout % 8 == 0, "bf16 wgrad: output channel count must be a multiple of 8 (16-byte rows)");
   WgradPlan p = wgrad_plan(v, cin, cout, LGS_BF16);
   float *partial = reinterpret_cast<float *>(workspace);
   const bf16_t *in = reinterpret_cast<const bf16_t *>(in_v), *go = reinterpret_cast<const bf16_t *>(gout_v);
+  const int cin_real = cin;
+  if (cin % 8 != 0) {  // e.g. the 3-channel colour input of conv0p1s1: zero-pad rows to 8 channels behind the partials
+    const int c8 = (cin + 7) / 8 * 8;
+    bf16_t *padded = reinterpret_cast<bf16_t *>(reinterpret_cast<char *>(workspace) +
+                                                align256((int64_t)p.S * v.K * p.cin_pad * p.cout_pad * 4));
+    int64_t tot = v.n_in * (int64_t)c8;
+    if (tot > 0) hipLaunchKernelGGL(k_pad_rows_bf16, (unsigned)((tot + 255) / 256), 256, 0, s, in, v.n_in, cin, c8, padded);
+    in = padded;
+    cin = c8;
+  }
   // every (slot, k, ci, co) element of `partial` is written exactly once by the wave that owns it
 #define LGS_WG(A, B) if (p.nci == A && p.nco == B) { launch_wgrad_bf16<A, B>(v, p, in, cin, go, cout, partial, s); } else
   LGS_WG(1, 1) LGS_WG(1, 2) LGS_WG(1, 3) LGS_WG(1, 4)
@@ -386,8 +409,8 @@ int conv_wgrad_bf16(const View &v, const void *in_v, int cin, const void *gout_v
   LGS_WG(4, 1) LGS_WG(4, 2) LGS_WG(4, 3)
   { LGS_REQUIRE(false, "bf16 wgrad: no kernel instance for this tile"); }
 #undef LGS_WG
-  int64_t total = (int64_t)v.K * cin * cout;
-  hipLaunchKernelGGL(k_wgrad_reduce, (unsigned)((total + 255) / 256), 256, 0, s, partial, p.S, v.K, p.cin_pad, p.cout_pad, cin,
+  int64_t total = (int64_t)v.K * cin_real * cout;
+  hipLaunchKernelGGL(k_wgrad_reduce, (unsigned)((total + 255) / 256), 256, 0, s, partial, p.S, v.K, p.cin_pad, p.cout_pad, cin_real,
                      cout, gw);
   LGS_HIP(hipGetLastError());
   return 0;
@@ -435,8 +458,8 @@ int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const 
   }
   if (dtype == LGS_F32) return conv_wgrad_f32path<float>(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
   if (dtype == LGS_BF16) {
-    if (cin % 8 == 0 && cout % 8 == 0) return conv_wgrad_bf16(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
-    return conv_wgrad_f32path<bf16_t>(vv, in, cin, grad_out, cout, grad_weight, workspace, s);  // e.g. the 3-channel input layer
+    if (cout % 8 == 0) return conv_wgrad_bf16(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
+    return conv_wgrad_f32path<bf16_t>(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
   }
   LGS_REQUIRE(false, "lgs_conv_wgrad: unknown dtype");
 }

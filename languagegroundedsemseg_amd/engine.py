@@ -22,6 +22,7 @@ EXPORTS = [
     "lgs_conv_workspace_bytes", "lgs_conv_forward", "lgs_conv_dgrad", "lgs_conv_wgrad",
     "lgs_bn_forward", "lgs_bn_backward",
     "lgs_clip_similarity", "lgs_clip_workspace_bytes",
+    "lgs_ce_forward_backward",
 ]
 
 
@@ -63,6 +64,7 @@ def lib():
         "lgs_bn_forward": [vp, i64, ci, vp, vp, cf, cf, vp, vp, vp, ci, vp, vp, ci, vp],
         "lgs_bn_backward": [vp, vp, vp, i64, ci, vp, vp, ci, vp, vp, vp, vp, ci, vp],
         "lgs_clip_similarity": [vp, i64, ci, vp, ci, vp, vp, ci, vp, vp],
+        "lgs_ce_forward_backward": [vp, i64, ci, vp, i64, vp, vp, vp, ci, vp],
     }
     for name, args in sig.items():
         f = getattr(L, name)

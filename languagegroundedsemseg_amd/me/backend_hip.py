@@ -235,3 +235,20 @@ class HipBackend:
             engine.check(L.lgs_clip_similarity(_ptr(feats), n, c, _ptr(anchors), na, _ptr(sim), _ptr(inv), dt, _ptr(ws),
                                                _stream()))
         return sim, inv[:n]
+
+    # ---- fused softmax cross-entropy: lgs_ce_forward_backward
+    def cross_entropy(self, logits, labels, ignore_index):
+        _require_dev(logits, "logits")
+        L = engine.lib()
+        logits = logits.contiguous()
+        labels = labels.contiguous().to(torch.int64)
+        n, c = logits.shape
+        dt = _dtype_code(logits)
+        with torch.cuda.device(logits.device):
+            valid = (labels != ignore_index).sum().to(torch.float32).clamp_min(1.0)
+            scale = valid.reciprocal()
+            loss_rows = torch.empty(max(n, 1), dtype=torch.float32, device=logits.device)
+            dlogits = torch.empty_like(logits)
+            engine.check(L.lgs_ce_forward_backward(_ptr(logits), n, c, _ptr(labels), int(ignore_index), _ptr(scale),
+                                                   _ptr(loss_rows), _ptr(dlogits), dt, _stream()))
+        return loss_rows[:n].sum() * scale, dlogits

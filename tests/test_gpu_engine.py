@@ -278,3 +278,36 @@ def test_bf16_transposed_conv_wgrad():
     assert rel_err(h_out, o_out) < 3e-2
     for a, b in zip(h_g, o_g):
         assert rel_err(a, b) < 3e-2
+
+
+# ------------------------------------------------------------------------------------------- losses
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+def test_fused_cross_entropy_matches_torch(dtype, tol):
+    from languagegroundedsemseg_amd.losses import fused_cross_entropy
+    torch.manual_seed(0)
+    x = (torch.randn(7001, 200) * 3).to(dtype).float()
+    lab = torch.randint(-1, 200, (7001,))
+    xh = x.to(DEV).to(dtype).requires_grad_(True)
+    loss = fused_cross_entropy(xh, lab.to(DEV), -1)
+    (loss * 2.0).backward()
+    xt = x.clone().requires_grad_(True)
+    lt = torch.nn.functional.cross_entropy(xt, lab, ignore_index=-1)
+    (lt * 2.0).backward()
+    assert abs(float(loss) - float(lt)) < 1e-4
+    assert rel_err(xh.grad.float().cpu().numpy(), xt.grad.numpy()) < tol
+
+
+def test_contrastive_loss_on_mfma_matches_reference_golden():
+    import os
+    from languagegroundedsemseg_amd.losses import ContrastiveLanguageLoss
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "contrastive_loss.npz"))
+    for tag in ("c512", "c96"):
+        g = lambda k: torch.from_numpy(fx["%s_%s" % (tag, k)]).to(DEV)
+        crit = ContrastiveLanguageLoss(num_labels=200, num_negative_samples=3)
+        F = g("F").clone().requires_grad_(True)
+        loss, pos, neg = crit(F, g("labels"), g("T"), neg_indices=g("neg"))
+        assert torch.allclose(pos, g("pos_loss"), atol=1e-5)
+        assert torch.allclose(neg, g("neg_loss"), atol=1e-5)
+        assert abs(float(loss) - float(g("total"))) < 1e-5
+        loss.backward()
+        assert torch.isfinite(F.grad).all()
