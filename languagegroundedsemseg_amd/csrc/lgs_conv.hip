@@ -128,7 +128,15 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int vx = lane & 31, h = lane >> 5;
-  const int64_t pos_wg = (int64_t)blockIdx.x * TM;
+  // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (speed only, never correctness), so give
+  // every XCD a CONTIGUOUS run of position tiles -- neighbouring tiles share most of their gathered rows and
+  // now hit the same private L2.  Bijective for any tile count.
+  int64_t tile;
+  {
+    const unsigned nt = gridDim.x, xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, q = nt >> 3, r = nt & 7u;
+    tile = (int64_t)(xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int64_t pos_wg = tile * TM;
   const int64_t pos_w = pos_wg + (int64_t)wm * RB * 32;
   const int nb_wg = blockIdx.y * WB;  // first cout block of the workgroup
   const int nb_w = nb_wg + wn * NCB;  // first cout block of this wave

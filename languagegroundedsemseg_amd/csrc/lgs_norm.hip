@@ -14,7 +14,6 @@
 
 namespace lgs {
 
-typedef uint16_t bf16_t;
 __device__ inline float bf2f(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
 __device__ inline uint16_t f2bf(float f) {
   uint32_t u = __float_as_uint(f);
@@ -73,6 +72,10 @@ __global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, cons
   if (MODE == 1) {
 #pragma unroll
     for (int i = 0; i < W; ++i) { mean[i] = stats[cg * W + i]; istd[i] = stats[c + cg * W + i]; }
+  } else {
+    // forward statistics are accumulated about a per-channel pivot (row 0, the same for every block) so that
+    // var = E[(x-k)^2] - E[x-k]^2 does not cancel catastrophically when |mean| >> std
+    if (n > 0) Vec<T>::load(x + cg * W, mean);
   }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(r0 + rows_per_block, n);
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, cons
       Vec<T>::load(x + r * c + cg * W, xv);
       if (MODE == 0) {
 #pragma unroll
-        for (int i = 0; i < W; ++i) { s0[i] += xv[i]; s1[i] += xv[i] * xv[i]; }
+        for (int i = 0; i < W; ++i) { const float d = xv[i] - mean[i]; s0[i] += d; s1[i] += d * d; }
       } else {
         float gv[W];
         Vec<T>::load(dy + r * c + cg * W, gv);
@@ -128,17 +131,20 @@ __device__ inline void fold_sums(const float *__restrict__ scratch, int nblocks,
     for (int q = 1; q < 4; ++q) { s += red[q][0][threadIdx.x & 63]; ss += red[q][1][threadIdx.x & 63]; }
   }
 }
-__global__ __launch_bounds__(256) void k_fold_fwd(const float *__restrict__ scratch, int nblocks, int c, int64_t n, float eps,
-                                                  float momentum, float *__restrict__ running_mean,
+template <typename T>
+__global__ __launch_bounds__(256) void k_fold_fwd(const float *__restrict__ scratch, const T *__restrict__ x, int nblocks, int c,
+                                                  int64_t n, float eps, float momentum, float *__restrict__ running_mean,
                                                   float *__restrict__ running_var, float *__restrict__ stats) {
   __shared__ double red[4][2][64];
   const int ch = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
   double s, ss;
   fold_sums(scratch, nblocks, c, ch, part, s, ss, red);
   if (part != 0 || ch >= c) return;
-  double mean = n > 0 ? s / (double)n : 0.0;
-  double var = n > 0 ? ss / (double)n - mean * mean : 0.0;
+  const double pivot = n > 0 ? (double)ld_elem(x + ch) : 0.0;
+  double dm = n > 0 ? s / (double)n : 0.0;
+  double var = n > 0 ? ss / (double)n - dm * dm : 0.0;
   if (var < 0.0) var = 0.0;
+  const double mean = pivot + dm;
   stats[ch] = (float)mean;
   stats[c + ch] = (float)(1.0 / sqrt(var + (double)eps));
   if (running_mean) {
@@ -237,7 +243,7 @@ int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const flo
   const T *x = reinterpret_cast<const T *>(xv);
   hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, n, c, 0,
                      rpb, scratch);
-  hipLaunchKernelGGL(k_fold_fwd, (c + 63) / 64, 256, 0, s, scratch, nb, c, n, eps, momentum, rm, rv, stats);
+  hipLaunchKernelGGL((k_fold_fwd<T>), (c + 63) / 64, 256, 0, s, scratch, x, nb, c, n, eps, momentum, rm, rv, stats);
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
