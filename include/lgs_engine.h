@@ -115,16 +115,18 @@ int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const 
  *   /root/reference/models/modules/common.py:17-19, models/modules/resnet_block.py:41-57
  * Training-mode batch statistics over all n rows.  stats = float32 [2*C] workspace:
  * on return mean[C], invstd[C].  running_mean/var (float32 [C]) updated with `momentum`
- * (unbiased variance), may be NULL.  residual may be NULL.  y may alias x. */
+ * (unbiased variance), may be NULL.  residual may be NULL.  y may alias x.
+ * workspace: lgs_bn_workspace_bytes(n, c) bytes of caller-owned device scratch (no allocation inside). */
+int64_t lgs_bn_workspace_bytes(int64_t n, int c);
 int lgs_bn_forward(const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps,
                    float momentum, float *running_mean, float *running_var, const void *residual, int relu,
-                   void *y, float *stats, int dtype, void *stream);
+                   void *y, float *stats, int dtype, void *workspace, void *stream);
 /* Backward of the fused op.  y is the forward OUTPUT (used for the ReLU mask), x the forward input.
  * Writes dx, dgamma[C], dbeta[C]; if dresidual != NULL also the gradient flowing to the residual
  * (= dy masked by ReLU).  stats = the forward's mean/invstd. */
 int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
                     const float *stats, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta,
-                    int dtype, void *stream);
+                    int dtype, void *workspace, void *stream);
 
 /* ---- CLIP text-anchor contraction (MFMA) ----------------------------------------------------
  * replaces ContrastiveLanguageLoss.feat_dist (cos) + feature_sim

@@ -35,16 +35,23 @@ template <> struct Tr<bf16_t> {
 
 
 // one 16-byte operand pair: bf16 = one 32x32x16 MFMA, fp32 = four 32x32x2 MFMAs
-template <typename T> __device__ inline void mma16(f32x16 &acc, const uint4 &w, const uint4 &f);
-template <> __device__ inline void mma16<bf16_t>(f32x16 &acc, const uint4 &w, const uint4 &f) {
+// 16-byte operands are native ext-vectors (not the HIP_vector_type struct): struct copies between address spaces
+// lower to llvm.memcpy, which keeps the staging array in scratch memory instead of registers.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ inline void mma16(f32x16 &acc, const u32x4 &w, const u32x4 &f);
+template <> __device__ inline void mma16<bf16_t>(f32x16 &acc, const u32x4 &w, const u32x4 &f) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, f), acc, 0, 0, 0);
 }
-template <> __device__ inline void mma16<float>(f32x16 &acc, const uint4 &w, const uint4 &f) {
+template <> __device__ inline void mma16<float>(f32x16 &acc, const u32x4 &w, const u32x4 &f) {
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(f.x), acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(f.y), acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(f.z), acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(f.w), acc, 0, 0, 0);
 }
+
+// Missing neighbours / padded channels are not branched around (hipcc would fence every such load with
+// s_waitcnt vmcnt(0) and serialise the whole gather pipeline): their lane simply points at a zero page.
+constexpr int kZeroPage = 4096;  // bytes, at the start of every conv workspace
 
 // ------------------------------------------------------------------------------------ weight packing
 // dst[kd][c][nb][t][lane] (16 B each): element e of lane (j = lane&31, h = lane>>5) is
@@ -55,9 +62,11 @@ template <> __device__ inline void mma16<float>(f32x16 &acc, const uint4 &w, con
 // Out-of-range g / o are zero (channel padding to multiples of 32).
 template <typename T>
 __global__ void k_pack_weights(const float *__restrict__ w, int K, int cin_w, int cout_w, int transposed, int mirror,
-                               int g_real, int o_real, int nc, int nb_total, uint4 *__restrict__ dst) {
+                               int g_real, int o_real, int nc /*padded chunks*/, int nb_total /*padded blocks*/,
+                               uint4 *__restrict__ dst, uint4 *__restrict__ zero_page) {
   constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < kZeroPage / 16) zero_page[idx] = make_uint4(0, 0, 0, 0);  // the page missing neighbours are read from
   int64_t total = (int64_t)K * nc * nb_total * LD * 64;
   if (idx >= total) return;
   int lane = (int)(idx & 63);
@@ -110,20 +119,27 @@ __global__ void k_unpad_rows(const T *__restrict__ src, int64_t n, int c, int cp
 
 // ------------------------------------------------------------------------------------ forward / dgrad
 // Tile: WM x WN waves; each wave owns RB*32 positions x NCB*32 output channels.
-template <typename T, int RB, int NCB, int WM, int WN>
+template <typename T, int RB, int NCB, int WM, int WN, int SC, int D>
 __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__restrict__ in, int cin_real, int nc,
-                                                             const uint4 *__restrict__ wp, int nb_total,
+                                                             const u32x4 *__restrict__ wp, int nb_total,
+                                                             int ncp, int nbp,
                                                              T *__restrict__ out, int cout_real,
                                                              const float *__restrict__ bias,
                                                              float *__restrict__ out_f32,
-                                                             const float *__restrict__ row_scale) {
+                                                             const float *__restrict__ row_scale,
+                                                             const u32x4 *__restrict__ zpage) {
+  // SC = 32-channel chunks per weight SLAB: the weights of (offset, slab) are staged in LDS once per workgroup
+  // and one barrier separates slabs, while the gathered feature fragments stream chunk by chunk through a
+  // D-deep register ring (loads issued D-1 chunks = several hundred MFMA cycles ahead of their use) that runs
+  // across slab and offset boundaries.
   constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
   constexpr int NT = WM * WN * 64;
   constexpr int TM = WM * RB * 32;
-  constexpr int WB = WN * NCB;            // weight blocks staged per step
-  constexpr int WCH = WB * LD * 64;       // uint4 per staged chunk
-  constexpr int WR = (WCH + NT - 1) / NT; // staging registers per thread
-  __shared__ uint4 lds[2][WCH];
+  constexpr int WB = WN * NCB;                 // weight blocks per chunk
+  constexpr int WCH = WB * LD * 64;            // uint4 per chunk
+  constexpr int SLAB = SC * WCH;               // uint4 per slab
+  constexpr int WR = (SLAB + NT - 1) / NT;     // staging registers per thread
+  __shared__ u32x4 lds[2][SLAB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -161,63 +177,89 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rb][nb][r] = 0.f;
 
-  // ---- issue-side iterator state
-  uint32_t rem = smask;           // slots not yet issued
-  int islot = -1, ichunk = nc;    // force "advance to first slot" on first call
-  int32_t idx_i[RB];              // gather rows of the slot being issued
-  auto load_idx = [&](int slot, int32_t (&dst)[RB]) {
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-      int64_t p = pos_w + rb * 32 + vx;
-      dst[rb] = v.nbr ? v.nbr[(int64_t)slot * v.n_pad + p] : (p < v.n_in ? (int32_t)p : -1);
+  // ---- gather indices of every visited slot are parked in LDS once (coalesced), so that the per-offset index
+  // fetch is a ds_read (lgkmcnt) and never sits in the VMEM queue in front of the gather ring
+  __shared__ int32_t l_idx[27 * TM];
+  if (v.nbr) {
+    for (uint32_t m = smask; m; m &= m - 1) {
+      const int sl = __builtin_ctz(m);
+      for (int r = tid; r < TM; r += NT) l_idx[sl * TM + r] = v.nbr[(int64_t)sl * v.n_pad + pos_wg + r];
     }
-  };
-  // advance to next (slot, chunk); returns false when exhausted
-  auto advance = [&]() -> bool {
+    __syncthreads();
+  }
+  // ---- feature-side iterator: flat sequence of (slot, chunk)
+  uint32_t rem = smask;
+  int islot = -1, ichunk = nc;  // forces "advance to first slot" on the first call
+  int32_t idx_i[RB];
+  auto advance = [&]() __attribute__((always_inline)) -> bool {
     if (++ichunk < nc) return true;
     if (rem == 0) return false;
     islot = __builtin_ctz(rem);
     rem &= rem - 1;
     ichunk = 0;
-    load_idx(islot, idx_i);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int r = wm * RB * 32 + rb * 32 + vx;
+      const int64_t p = pos_wg + r;
+      idx_i[rb] = v.nbr ? l_idx[islot * TM + r] : (p < v.n_in ? (int32_t)p : -1);
+    }
     return true;
   };
-  auto issue = [&](uint4 (&F)[RB][LD], uint4 (&wreg)[WR], uint32_t &act) {
+  auto issue = [&](u32x4 (&F)[RB][LD], uint32_t &act) __attribute__((always_inline)) {
     act = 0;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       const bool ok = idx_i[rb] >= 0;
       if (__ballot(ok)) act |= 1u << rb;
-      const T *src = in + (int64_t)idx_i[rb] * cin_real + ichunk * 32 + h * 16;
+      const T *src = in + (int64_t)(ok ? idx_i[rb] : 0) * cin_real + ichunk * 32 + h * 16;
 #pragma unroll
       for (int t = 0; t < LD; ++t) {
         const int ch = ichunk * 32 + h * 16 + t * EPL;
-        F[rb][t] = (ok && ch + EPL <= cin_real) ? *reinterpret_cast<const uint4 *>(src + t * EPL) : make_uint4(0, 0, 0, 0);
+        // branch-free: every lane loads 16 bytes, either its row piece or the zero page
+        const u32x4 *p = (ok && ch + EPL <= cin_real) ? reinterpret_cast<const u32x4 *>(src + t * EPL) : zpage;
+        F[rb][t] = *p;
       }
     }
-    const int kw = v.KS > 1 ? islot : kw_single;  // 3^3 dgrad mirroring (K-1-k) is folded into the weight packing
-    const uint4 *wsrc = wp + (((int64_t)kw * nc + ichunk) * nb_total + nb_wg) * (LD * 64);
-    const int wvalid = min(WB, nb_total - nb_wg) * LD * 64;
+  };
+  // ---- weight-side iterator: (slot, slab) in the same order
+  const int nslab = (nc + SC - 1) / SC;
+  uint32_t wrem = smask;
+  int wslot = -1, wslab = nslab;
+  auto wadvance = [&]() __attribute__((always_inline)) -> bool {
+    if (++wslab < nslab) return true;
+    if (wrem == 0) return false;
+    wslot = __builtin_ctz(wrem);
+    wrem &= wrem - 1;
+    wslab = 0;
+    return true;
+  };
+  // The packed weights are padded to whole slabs (ncp chunks) and whole cout tiles (nbp blocks), zero filled,
+  // so a slab is fetched with unconditional, fully coalesced 16-byte loads.
+  auto wissue = [&](u32x4 (&wreg)[WR]) __attribute__((always_inline)) {
+    const int kw = v.KS > 1 ? wslot : kw_single;  // 3^3 dgrad mirroring (K-1-k) is folded into the weight packing
+    const u32x4 *base = wp + (((int64_t)kw * ncp + wslab * SC) * nbp + nb_wg) * (LD * 64);
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
-      int e = tid + i * NT;
-      wreg[i] = (e < wvalid) ? wsrc[e] : make_uint4(0, 0, 0, 0);
+      const int e = min(tid + i * NT, SLAB - 1);
+      const int cc = e / WCH, ee = e - cc * WCH;
+      wreg[i] = base[(int64_t)cc * nbp * (LD * 64) + ee];
     }
   };
-  auto stage = [&](int buf, const uint4 (&wreg)[WR]) {
+  auto wstage = [&](int buf, const u32x4 (&wreg)[WR]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
-      int e = tid + i * NT;
-      if (e < WCH) lds[buf][e] = wreg[i];
+      const int e = tid + i * NT;
+      if (e < SLAB) lds[buf][e] = wreg[i];
     }
   };
-  auto compute = [&](int buf, const uint4 (&F)[RB][LD], uint32_t act) {
+  auto compute = [&](int buf, int cc, const u32x4 (&F)[RB][LD], uint32_t act) __attribute__((always_inline)) {
     if (act == 0) return;
+    const u32x4 *wl = &lds[buf][cc * WCH + (wn * NCB) * LD * 64 + lane];
 #pragma unroll
     for (int t = 0; t < LD; ++t) {
-      uint4 wf[NCB];
+      u32x4 wf[NCB];
 #pragma unroll
-      for (int nb = 0; nb < NCB; ++nb) wf[nb] = lds[buf][((wn * NCB + nb) * LD + t) * 64 + lane];
+      for (int nb = 0; nb < NCB; ++nb) wf[nb] = wl[(nb * LD + t) * 64];
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
         if (act & (1u << rb)) {
@@ -228,28 +270,63 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     }
   };
 
-  uint4 F0[RB][LD], F1[RB][LD], wreg[WR];
-  uint32_t act0 = 0, act1 = 0;
-  bool more = advance();
-  if (more) {
-    issue(F0, wreg, act0);
-    stage(0, wreg);
+  u32x4 F[D][RB][LD], wreg[WR];
+  uint32_t act[D];
+  int buf = 0, cc = 0;       // LDS buffer holding the current slab, chunk index inside it
+  int ncs = 0;               // chunks in the current slab
+  bool wnext = false;        // is a following slab prefetched in wreg?
+  const int total = __builtin_popcount(smask) * nc;  // chunks of this workgroup
+  int issued = 0, computed = 0;
+  if (wadvance()) {
+    wissue(wreg);
+    wstage(0, wreg);
+    ncs = min(SC, nc - wslab * SC);
+    wnext = wadvance();
+    if (wnext) wissue(wreg);
   }
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) {
+    act[d] = 0;
+    if (issued < total) { advance(); issue(F[d], act[d]); ++issued; }
+  }
+  act[D - 1] = 0;
   __syncthreads();
-  while (more) {
-    // even phase: compute buffer 0 while buffer 1 fills
-    bool nxt = advance();
-    if (nxt) issue(F1, wreg, act1);
-    compute(0, F0, act0);
-    if (nxt) stage(1, wreg);
+  // at the end of a slab publish the prefetched next slab and cross one barrier
+  auto slab_end = [&]() __attribute__((always_inline)) {
+    if (wnext) wstage(buf ^ 1, wreg);
     __syncthreads();
-    if (!nxt) break;
-    // odd phase
-    more = advance();
-    if (more) issue(F0, wreg, act0);
-    compute(1, F1, act1);
-    if (more) stage(0, wreg);
-    __syncthreads();
+    buf ^= 1;
+    cc = 0;
+    if (wnext) {
+      ncs = min(SC, nc - wslab * SC);
+      wnext = wadvance();
+      if (wnext) wissue(wreg);
+    }
+  };
+  // steady state: every sub-step issues one chunk and computes one chunk UNCONDITIONALLY, so the compiler can
+  // count outstanding loads (s_waitcnt vmcnt(N), N > 0) instead of draining the queue before every MFMA group
+  while (total - issued >= D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      advance();
+      issue(F[(d + D - 1) % D], act[(d + D - 1) % D]);
+      compute(buf, cc, F[d], act[d]);
+      if (++cc == ncs) slab_end();
+    }
+    issued += D;
+    computed += D;
+  }
+  // tail (< 2D chunks)
+  while (computed < total) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (computed < total) {
+        if (issued < total) { advance(); issue(F[(d + D - 1) % D], act[(d + D - 1) % D]); ++issued; }
+        compute(buf, cc, F[d], act[d]);
+        ++computed;
+        if (++cc == ncs) slab_end();
+      }
+    }
   }
 
   // ---- epilogue: lane (voxel vx, half h) owns channels nb*32 + 8q + 4h + {0..3}
@@ -290,27 +367,44 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
 
 // ------------------------------------------------------------------------------------ host side
 
+// Tile choice: 256 positions x up to 128 channels when the map fills the chip, otherwise 64-position x 64-channel
+// tiles (coarse levels: few rows, many channels -- parallelism matters more than weight re-reads).
+// SC = chunks per weight slab (sized to ~6-8 staging registers per thread), D = depth of the gather ring.
+struct GatherCfg { int id, sc, wb; };
 template <typename T>
-int launch_gather(const View &v, const T *in, int cin_real, int nc, const uint4 *wp, int nb_total, T *out, int cout_real,
-                  const float *bias, hipStream_t s, float *out_f32 = nullptr, const float *row_scale = nullptr) {
-  if (v.n_pad == 0) return 0;
-  // Tile choice: big tiles (256 positions x up to 128 channels) when the map is large enough to
-  // fill 256 CUs, otherwise 64-position tiles with the channel dimension split over waves.
+GatherCfg gather_cfg(const View &v, int nb_total) {
+  constexpr bool kF32 = (sizeof(T) == 4);
   const bool big = v.n_pad >= 256 * 256;
-#define LGS_LAUNCH(RB, NCB, WM, WN)                                                                               \
+  if (big) {
+    if (nb_total == 1) return {0, kF32 ? 2 : 4, 1};
+    if (nb_total == 2) return {1, kF32 ? 2 : 4, 2};
+    if (nb_total == 3 || (nb_total % 3 == 0 && nb_total % 4 != 0)) return {2, kF32 ? 2 : 4, 3};
+    return {3, kF32 ? 1 : 2, 4};
+  }
+  if (nb_total == 1) return {4, kF32 ? 2 : 4, 1};
+  return {5, kF32 ? 2 : 4, 2};
+}
+
+template <typename T>
+int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real, int nc, const uint4 *wp, const uint4 *zpage,
+                  int nb_total, int ncp, int nbp, T *out, int cout_real, const float *bias, hipStream_t s,
+                  float *out_f32 = nullptr, const float *row_scale = nullptr) {
+  if (v.n_pad == 0) return 0;
+  constexpr bool kF32 = (sizeof(T) == 4);
+#define LGS_LAUNCH(RB, NCB, WM, WN, SC, D)                                                                        \
   do {                                                                                                            \
     dim3 grid((unsigned)(v.n_pad / (WM * RB * 32)), (unsigned)((nb_total + WN * NCB - 1) / (WN * NCB)));         \
-    hipLaunchKernelGGL((k_conv_gather<T, RB, NCB, WM, WN>), grid, dim3(WM *WN * 64), 0, s, v, in, cin_real, nc, wp, \
-                       nb_total, out, cout_real, bias, out_f32, row_scale);                                       \
+    hipLaunchKernelGGL((k_conv_gather<T, RB, NCB, WM, WN, SC, D>), grid, dim3(WM *WN * 64), 0, s, v, in, cin_real, nc,    \
+                       reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, out, cout_real, bias, out_f32, row_scale, \
+                       reinterpret_cast<const u32x4 *>(zpage));                      \
   } while (0)
-  if (big) {
-    if (nb_total == 1) LGS_LAUNCH(2, 1, 4, 1);
-    else if (nb_total == 2) LGS_LAUNCH(2, 2, 4, 1);
-    else if (nb_total == 3 || nb_total % 3 == 0 && nb_total % 4 != 0) LGS_LAUNCH(2, 3, 4, 1);
-    else LGS_LAUNCH(2, 4, 4, 1);
-  } else {
-    if (nb_total == 1) LGS_LAUNCH(1, 1, 2, 1);
-    else LGS_LAUNCH(1, 1, 2, 2);
+  switch (cfg.id) {
+    case 0: LGS_LAUNCH(2, 1, 4, 1, (kF32 ? 2 : 4), (kF32 ? 3 : 4)); break;
+    case 1: LGS_LAUNCH(2, 2, 4, 1, (kF32 ? 2 : 4), (kF32 ? 3 : 4)); break;
+    case 2: LGS_LAUNCH(2, 3, 4, 1, (kF32 ? 2 : 4), (kF32 ? 3 : 4)); break;
+    case 3: LGS_LAUNCH(2, 4, 4, 1, (kF32 ? 1 : 2), (kF32 ? 2 : 3)); break;
+    case 4: LGS_LAUNCH(1, 1, 2, 1, (kF32 ? 2 : 4), (kF32 ? 4 : 8)); break;
+    default: LGS_LAUNCH(1, 1, 2, 2, (kF32 ? 2 : 4), (kF32 ? 4 : 8)); break;
   }
 #undef LGS_LAUNCH
   LGS_HIP(hipGetLastError());
@@ -325,8 +419,11 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
   constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
   const int g_pad = pad32(g_real), nc = g_pad / 32, nb_total = pad32(o_real) / 32;
   char *ws = reinterpret_cast<char *>(workspace);
-  uint4 *wp = reinterpret_cast<uint4 *>(ws);
-  int64_t wbytes = align256((int64_t)K * nc * nb_total * LD * 64 * 16);
+  uint4 *zpage = reinterpret_cast<uint4 *>(ws);
+  uint4 *wp = reinterpret_cast<uint4 *>(ws + kZeroPage);
+  const GatherCfg cfg = gather_cfg<T>(v, nb_total);
+  const int ncp = (nc + cfg.sc - 1) / cfg.sc * cfg.sc, nbp = (nb_total + cfg.wb - 1) / cfg.wb * cfg.wb;
+  int64_t wbytes = kZeroPage + align256((int64_t)K * (nc + 3) * (nb_total + 3) * LD * 64 * 16);
   if (o_real % 4 != 0) {
     // rows are written in 4-channel groups: route odd widths (e.g. the 3-channel input gradient of a
     // test) through a 4-aligned scratch image placed after the packed weights and the padded input
@@ -353,11 +450,11 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
     in = padded;
     g_stride = g_pad;
   }
-  int64_t total = (int64_t)K * nc * nb_total * LD * 64;
+  int64_t total = (int64_t)K * ncp * nbp * LD * 64;
   hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, weight, K, cin_w, cout_w, transposed_w,
-                     v.mirror, g_real, w_o_real, nc, nb_total, wp);
+                     v.mirror, g_real, w_o_real, ncp, nbp, wp, zpage);
   LGS_HIP(hipGetLastError());
-  return launch_gather<T>(v, in, g_stride, nc, wp, nb_total, reinterpret_cast<T *>(out_v), o_real, bias, s);
+  return launch_gather<T>(v, cfg, in, g_stride, nc, wp, zpage, nb_total, ncp, nbp, reinterpret_cast<T *>(out_v), o_real, bias, s);
 }
 
 // ------------------------------------------------------------------------------------ CLIP contraction
@@ -397,21 +494,24 @@ int clip_similarity_t(const void *feat, int64_t n, int c, const float *anchors, 
   if (n == 0) return 0;
   const int nc = pad32(c) / 32, nb_total = pad32(na) / 32;
   char *ws = reinterpret_cast<char *>(workspace);
-  float *tn = reinterpret_cast<float *>(ws);
-  int64_t off = align256((int64_t)na * c * 4);
+  uint4 *zpage = reinterpret_cast<uint4 *>(ws);
+  float *tn = reinterpret_cast<float *>(ws + kZeroPage);
+  int64_t off = kZeroPage + align256((int64_t)na * c * 4);
   uint4 *wp = reinterpret_cast<uint4 *>(ws + off);
-  off += align256((int64_t)nc * nb_total * LD * 64 * 16);
+  off += align256((int64_t)(nc + 3) * (nb_total + 3) * LD * 64 * 16);
   float *inv = inv_norm_f ? inv_norm_f : reinterpret_cast<float *>(ws + off);
   const T *f = reinterpret_cast<const T *>(feat);
   hipLaunchKernelGGL(k_normalize_anchors, na, 64, 0, s, anchors, na, c, tn);
-  int64_t total = (int64_t)nc * nb_total * LD * 64;
-  // T^[a][c] read as w[o = a][g = c]  ("transposed" form of the packer with cin_w = na, cout_w = c)
-  hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, tn, 1, na, c, 1, 0, c, na, nc, nb_total, wp);
-  hipLaunchKernelGGL((k_row_invnorm<T>), (unsigned)((n * 64 + 255) / 256), 256, 0, s, f, n, c, inv);
   View v;
   v.n_pad = pad_rows(n); v.n_out = n; v.n_in = n; v.KS = 1; v.K = 1;
+  const GatherCfg cfg = gather_cfg<T>(v, nb_total);
+  const int ncp = (nc + cfg.sc - 1) / cfg.sc * cfg.sc, nbp = (nb_total + cfg.wb - 1) / cfg.wb * cfg.wb;
+  int64_t total = (int64_t)ncp * nbp * LD * 64;
+  // T^[a][c] read as w[o = a][g = c]  ("transposed" form of the packer with cin_w = na, cout_w = c)
+  hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, tn, 1, na, c, 1, 0, c, na, ncp, nbp, wp, zpage);
+  hipLaunchKernelGGL((k_row_invnorm<T>), (unsigned)((n * 64 + 255) / 256), 256, 0, s, f, n, c, inv);
   LGS_HIP(hipGetLastError());
-  return launch_gather<T>(v, f, c, nc, wp, nb_total, (T *)nullptr, na, nullptr, s, sim, inv);
+  return launch_gather<T>(v, cfg, f, c, nc, wp, zpage, nb_total, ncp, nbp, (T *)nullptr, na, nullptr, s, sim, inv);
 }
 
 }  // namespace lgs
@@ -425,7 +525,7 @@ int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtyp
   const int e = esize(dtype);
   if (op == 2) return lgs::wgrad_workspace_bytes(km, cin, cout, dtype);
   int g = op == 0 ? cin : cout, o = op == 0 ? cout : cin;
-  int64_t bytes = align256((int64_t)km->K * pad32(g) * pad32(o) * e);
+  int64_t bytes = kZeroPage + align256((int64_t)km->K * (pad32(g) + 96) * (pad32(o) + 96) * e);
   int64_t nmax = km->fwd.n_in > km->bwd.n_in ? km->fwd.n_in : km->bwd.n_in;
   if (g % epl(dtype) != 0) bytes += align256(nmax * pad32(g) * e);
   if (o % 4 != 0) bytes += align256(nmax * (int64_t)((o + 3) / 4 * 4) * e);
@@ -461,7 +561,7 @@ int lgs_conv_dgrad(lgs_kmap *km, int transposed, const void *grad_out, int cout,
 extern "C" {
 
 int64_t lgs_clip_workspace_bytes(int c, int n_anchor, int dtype) {
-  int64_t b = align256((int64_t)n_anchor * c * 4) + align256((int64_t)pad32(c) * pad32(n_anchor) * esize(dtype));
+  int64_t b = kZeroPage + align256((int64_t)n_anchor * c * 4) + align256((int64_t)(pad32(c) + 96) * (pad32(n_anchor) + 96) * esize(dtype));
   return b + 256;
 }
 

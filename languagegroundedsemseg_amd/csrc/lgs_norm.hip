@@ -233,13 +233,12 @@ inline int reduce_blocks(int64_t n, int64_t *rows_per_block) {
 
 template <typename T>
 int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const float *beta, float eps, float momentum,
-                 float *rm, float *rv, const void *res, int relu, void *yv, float *stats, hipStream_t s) {
+                 float *rm, float *rv, const void *res, int relu, void *yv, float *stats, void *workspace, hipStream_t s) {
   constexpr int W = Vec<T>::W;
   LGS_REQUIRE(c % W == 0 && c / W <= kNT && c <= 2048, "lgs_bn_forward: channel count unsupported");
   int64_t rpb;
   int nb = reduce_blocks(n, &rpb);
-  float *scratch = nullptr;
-  LGS_HIP(hipMallocAsync((void **)&scratch, sizeof(float) * 2 * (size_t)c * nb, s));
+  float *scratch = reinterpret_cast<float *>(workspace);  // caller-owned: no allocator call (and no implicit sync) here
   const T *x = reinterpret_cast<const T *>(xv);
   hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, n, c, 0,
                      rpb, scratch);
@@ -251,19 +250,17 @@ int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const flo
                        reinterpret_cast<T *>(yv));
   }
   LGS_HIP(hipGetLastError());
-  LGS_HIP(hipFreeAsync(scratch, s));
   return 0;
 }
 
 template <typename T>
 int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *gamma, const float *stats,
-                  int relu, void *dxv, void *dresv, float *dgamma, float *dbeta, hipStream_t s) {
+                  int relu, void *dxv, void *dresv, float *dgamma, float *dbeta, void *workspace, hipStream_t s) {
   constexpr int W = Vec<T>::W;
   LGS_REQUIRE(c % W == 0 && c / W <= kNT && c <= 2048, "lgs_bn_backward: channel count unsupported");
   int64_t rpb;
   int nb = reduce_blocks(n, &rpb);
-  float *scratch = nullptr;
-  LGS_HIP(hipMallocAsync((void **)&scratch, sizeof(float) * 2 * (size_t)c * (nb + 1), s));
+  float *scratch = reinterpret_cast<float *>(workspace);
   float *sums = scratch + (size_t)2 * c * nb;
   const T *x = reinterpret_cast<const T *>(xv), *y = reinterpret_cast<const T *>(yv), *dy = reinterpret_cast<const T *>(dyv);
   hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, x, y, dy, stats, n, c, relu, rpb, scratch);
@@ -275,7 +272,6 @@ int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, in
                        reinterpret_cast<T *>(dresv));
   }
   LGS_HIP(hipGetLastError());
-  LGS_HIP(hipFreeAsync(scratch, s));
   return 0;
 }
 
@@ -285,23 +281,30 @@ using namespace lgs;
 
 extern "C" {
 
+int64_t lgs_bn_workspace_bytes(int64_t n, int c) {
+  int64_t rpb;
+  int nb = reduce_blocks(n, &rpb);
+  return (int64_t)sizeof(float) * 2 * c * (nb + 1) + 256;
+}
+
 int lgs_bn_forward(const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps, float momentum,
                    float *running_mean, float *running_var, const void *residual, int relu, void *y, float *stats,
-                   int dtype, void *stream) {
-  LGS_REQUIRE(x && y && gamma && beta && stats, "lgs_bn_forward: null argument");
+                   int dtype, void *workspace, void *stream) {
+  LGS_REQUIRE(x && y && gamma && beta && stats && workspace, "lgs_bn_forward: null argument");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == LGS_F32) return bn_forward_t<float>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, y, stats, s);
-  if (dtype == LGS_BF16) return bn_forward_t<bf16_t>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, y, stats, s);
+  if (dtype == LGS_F32) return bn_forward_t<float>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, y, stats, workspace, s);
+  if (dtype == LGS_BF16) return bn_forward_t<bf16_t>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, y, stats, workspace, s);
   LGS_REQUIRE(false, "lgs_bn_forward: unknown dtype");
 }
 
 int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma, const float *stats,
-                    int relu, void *dx, void *dresidual, float *dgamma, float *dbeta, int dtype, void *stream) {
-  LGS_REQUIRE(x && dy && dx && gamma && stats && dgamma && dbeta, "lgs_bn_backward: null argument");
+                    int relu, void *dx, void *dresidual, float *dgamma, float *dbeta, int dtype, void *workspace,
+                    void *stream) {
+  LGS_REQUIRE(x && dy && dx && gamma && stats && dgamma && dbeta && workspace, "lgs_bn_backward: null argument");
   LGS_REQUIRE(!relu || y, "lgs_bn_backward: relu needs the forward output");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == LGS_F32) return bn_backward_t<float>(x, y, dy, n, c, gamma, stats, relu, dx, dresidual, dgamma, dbeta, s);
-  if (dtype == LGS_BF16) return bn_backward_t<bf16_t>(x, y, dy, n, c, gamma, stats, relu, dx, dresidual, dgamma, dbeta, s);
+  if (dtype == LGS_F32) return bn_backward_t<float>(x, y, dy, n, c, gamma, stats, relu, dx, dresidual, dgamma, dbeta, workspace, s);
+  if (dtype == LGS_BF16) return bn_backward_t<bf16_t>(x, y, dy, n, c, gamma, stats, relu, dx, dresidual, dgamma, dbeta, workspace, s);
   LGS_REQUIRE(false, "lgs_bn_backward: unknown dtype");
 }
 

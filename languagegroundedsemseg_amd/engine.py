@@ -20,7 +20,7 @@ EXPORTS = [
     "lgs_manager_parent_of", "lgs_manager_map_size", "lgs_manager_get_coords", "lgs_manager_kernel_map",
     "lgs_kmap_export",
     "lgs_conv_workspace_bytes", "lgs_conv_forward", "lgs_conv_dgrad", "lgs_conv_wgrad",
-    "lgs_bn_forward", "lgs_bn_backward",
+    "lgs_bn_workspace_bytes", "lgs_bn_forward", "lgs_bn_backward",
     "lgs_clip_similarity", "lgs_clip_workspace_bytes",
     "lgs_ce_forward_backward",
 ]
@@ -61,8 +61,8 @@ def lib():
         "lgs_conv_forward": [vp, ci, vp, ci, vp, ci, vp, vp, ci, vp, vp],
         "lgs_conv_dgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp],
         "lgs_conv_wgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp],
-        "lgs_bn_forward": [vp, i64, ci, vp, vp, cf, cf, vp, vp, vp, ci, vp, vp, ci, vp],
-        "lgs_bn_backward": [vp, vp, vp, i64, ci, vp, vp, ci, vp, vp, vp, vp, ci, vp],
+        "lgs_bn_forward": [vp, i64, ci, vp, vp, cf, cf, vp, vp, vp, ci, vp, vp, ci, vp, vp],
+        "lgs_bn_backward": [vp, vp, vp, i64, ci, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp],
         "lgs_clip_similarity": [vp, i64, ci, vp, ci, vp, vp, ci, vp, vp],
         "lgs_ce_forward_backward": [vp, i64, ci, vp, i64, vp, vp, vp, ci, vp],
     }
@@ -72,6 +72,8 @@ def lib():
         f.argtypes = args
     L.lgs_conv_workspace_bytes.restype = i64
     L.lgs_conv_workspace_bytes.argtypes = [vp, ci, ci, ci, ci]
+    L.lgs_bn_workspace_bytes.restype = i64
+    L.lgs_bn_workspace_bytes.argtypes = [i64, ci]
     L.lgs_clip_workspace_bytes.restype = i64
     L.lgs_clip_workspace_bytes.argtypes = [ci, ci, ci]
     if L.lgs_abi_version() != 1:

@@ -200,9 +200,10 @@ class HipBackend:
             y = torch.empty_like(x)
             stats = torch.empty(2 * c, dtype=torch.float32, device=x.device)
             res = residual.contiguous() if residual is not None else None
+            ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
             engine.check(L.lgs_bn_forward(_ptr(x), n, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
                                           _ptr(running_mean), _ptr(running_var), _ptr(res), int(relu), _ptr(y),
-                                          _ptr(stats), dt, _stream()))
+                                          _ptr(stats), dt, _ptr(ws), _stream()))
         return y, stats
 
     def bn_backward(self, x, y, dy, gamma, stats, relu, want_residual):
@@ -215,8 +216,9 @@ class HipBackend:
             dres = torch.empty_like(x) if want_residual else None
             dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
             dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+            ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
             engine.check(L.lgs_bn_backward(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(stats), int(relu), _ptr(dx),
-                                           _ptr(dres), _ptr(dgamma), _ptr(dbeta), dt, _stream()))
+                                           _ptr(dres), _ptr(dgamma), _ptr(dbeta), dt, _ptr(ws), _stream()))
         return dx, dres, dgamma, dbeta
 
     # ---- CLIP contraction: lgs_clip_similarity
