@@ -126,7 +126,9 @@ __global__ __launch_bounds__(256) void k_wgrad_f32(View v, const T *__restrict__
 }
 
 // ------------------------------------------------------------------------------------ bf16 MFMA path
-constexpr int kQ = 512;  // positions compacted per wave chunk
+constexpr int kQ = 1024;       // positions compacted per wave chunk
+constexpr int kWgZero = 4096;  // zero page at the start of the wgrad workspace (missing rows point here: branch-free loads)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // row stride (bytes) of a [16 pairs][C channels] bf16 tile, = 64 (mod 256) -> conflict-free tr reads
 __host__ __device__ constexpr int tile_stride(int c) {
@@ -137,11 +139,18 @@ __host__ __device__ constexpr int tile_stride(int c) {
 
 typedef short short4v __attribute__((ext_vector_type(4)));
 
-template <int NCI, int NCO>
+// Grid: 1-D.  Workgroup L runs on XCD L % 8 (dispatcher behaviour, used for speed only).  A workgroup owns ONE
+// position range (a few thousand Morton-consecutive voxels: its rows + halo fit the XCD's L2) and its four waves
+// take four different kernel offsets k of that range (or four sub-ranges when K = 1); the offset groups of a range
+// are consecutive in dispatch order on the same XCD.  Every row of the range is therefore fetched from HBM about
+// once and re-read ~K times from L1/L2 -- without this ordering the gathers were 98 % L2 misses (PMC) and the
+// kernel ran at the random-access rate of HBM.
+template <int NCI, int NCO, int D>
 __global__ __launch_bounds__(256) void k_wgrad_bf16(View v, const bf16_t *__restrict__ in, int cin_real,
                                                     const bf16_t *__restrict__ gout, int cout_real, int cin_pad,
-                                                    int cout_pad, int64_t span, int n_ci_tasks,
-                                                    float *__restrict__ partial) {
+                                                    int cout_pad, int64_t range, int kpw, int n_ci_tasks, int n_tasks,
+                                                    int n_ranges, float *__restrict__ partial,
+                                                    const u32x4 *__restrict__ zpage) {
   constexpr int CA = 32 * NCI, CG = 32 * NCO;
   constexpr int SA = tile_stride(CA), SG = tile_stride(CG);
   constexpr int LA = (16 * CA / 8 + 63) / 64, LG = (16 * CG / 8 + 63) / 64;  // 16-byte loads per lane per group
@@ -154,13 +163,24 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(View v, const bf16_t *__rest
   char *stA = wbase + 2 * kQ * 4;
   char *stG = stA + 16 * SA;
 
-  const int k = blockIdx.y;
-  const int cit = blockIdx.z % n_ci_tasks, cot = blockIdx.z / n_ci_tasks;
+  const int K = v.K;
+  const int KG = (K + kpw - 1) / kpw;   // offset groups per range
+  const int wpk = 4 / kpw;              // waves sharing one offset (sub-ranges)
+  const unsigned L = blockIdx.x, xcd = L & 7u, t = L >> 3;
+  const int kg = (int)(t % (unsigned)KG);
+  const int task = (int)((t / (unsigned)KG) % (unsigned)n_tasks);
+  const int rg_i = (int)(t / (unsigned)(KG * n_tasks)) * 8 + (int)xcd;
+  if (rg_i >= n_ranges) return;
+  const int k = kg * kpw + wave / wpk;
+  const int sub = wave % wpk;
+  if (k >= K) return;  // wave-uniform; no workgroup barriers in this kernel
+  const int cit = task % n_ci_tasks, cot = task / n_ci_tasks;
   const int ci0 = cit * CA, co0 = cot * CG;
   const int slot = v.KS > 1 ? k : 0;
-  const int64_t wslot = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t p_begin = wslot * span;
-  const int64_t p_end = min(p_begin + span, v.n_pad);
+  const int64_t wslot = rg_i;           // one partial slab per (range, offset): sub-range waves are folded in LDS below
+  const int64_t sub_len = range / wpk;
+  const int64_t p_begin = (int64_t)rg_i * range + sub * sub_len;
+  const int64_t p_end = min(p_begin + sub_len, v.n_pad);
 
   f32x16 acc[NCI][NCO];
 #pragma unroll
@@ -170,13 +190,82 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(View v, const bf16_t *__rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // lane roles
-  // loads: chunk id = q*64 + lane -> (row, 16-byte column chunk)
   // tr read: 16-lane group g = lane>>4: cb = g&1 (16-channel half), h = g>>1 (pairs 8h..8h+7); lane i = lane&15
-  //          supplies the 8-byte address (row 8h + 4*rd + i/4, channel 32*blk + 16*cb + 4*(i%4))
+  // supplies the 8-byte address (row 8h + 4*rd + i/4, channel 32*blk + 16*cb + 4*(i%4))
   const int g16 = lane >> 4, i16 = lane & 15;
   const int tr_row = 8 * (g16 >> 1) + (i16 >> 2);
   const int tr_col = 16 * (g16 & 1) + 4 * (i16 & 3);
+
+  u32x4 ra[D][LA], rg[D][LG];
+  // every lane issues exactly LA + LG 16-byte loads per group, from its row piece or from the zero page
+  auto issue = [&](int g, u32x4 (&xa)[LA], u32x4 (&xg2)[LG]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < LA; ++q) {
+      const int id = q * 64 + lane;
+      const int row = (id / (CA / 8)) & 15, ch = (id % (CA / 8)) * 8;
+      const int32_t r = q_in[g * 16 + row];
+      const bool ok = id < 16 * (CA / 8) && r >= 0 && ci0 + ch + 8 <= cin_real;
+      const u32x4 *p = ok ? reinterpret_cast<const u32x4 *>(in + (int64_t)r * cin_real + ci0 + ch) : zpage;
+      xa[q] = *p;
+    }
+#pragma unroll
+    for (int q = 0; q < LG; ++q) {
+      const int id = q * 64 + lane;
+      const int row = (id / (CG / 8)) & 15, ch = (id % (CG / 8)) * 8;
+      const int32_t r = q_out[g * 16 + row];
+      const bool ok = id < 16 * (CG / 8) && r >= 0 && co0 + ch + 8 <= cout_real;
+      const u32x4 *p = ok ? reinterpret_cast<const u32x4 *>(gout + (int64_t)r * cout_real + co0 + ch) : zpage;
+      xg2[q] = *p;
+    }
+  };
+  auto consume = [&](const u32x4 (&xa)[LA], const u32x4 (&xg2)[LG]) __attribute__((always_inline)) {
+    // park the 16 x CA and 16 x CG row pieces row-major in the wave's LDS tile
+#pragma unroll
+    for (int q = 0; q < LA; ++q) {
+      const int id = q * 64 + lane;
+      const int row = id / (CA / 8), ch = (id % (CA / 8)) * 8;
+      if (row < 16) *reinterpret_cast<u32x4 *>(stA + row * SA + ch * 2) = xa[q];
+    }
+#pragma unroll
+    for (int q = 0; q < LG; ++q) {
+      const int id = q * 64 + lane;
+      const int row = id / (CG / 8), ch = (id % (CG / 8)) * 8;
+      if (row < 16) *reinterpret_cast<u32x4 *>(stG + row * SG + ch * 2) = xg2[q];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // transposing reads -> MFMA operands (lane: channel = lane&31 of the block, pairs 8h..8h+7)
+    bf16x8 fa[NCI], fg[NCO];
+#pragma unroll
+    for (int a = 0; a < NCI; ++a) {
+      const char *p0 = stA + tr_row * SA + (32 * a + tr_col) * 2;
+      short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(p0));
+      short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(p0 + 4 * SA));
+      u32x4 pk;
+      pk.x = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+      pk.y = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+      pk.z = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+      pk.w = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+      fa[a] = __builtin_bit_cast(bf16x8, pk);
+    }
+#pragma unroll
+    for (int b = 0; b < NCO; ++b) {
+      const char *p0 = stG + tr_row * SG + (32 * b + tr_col) * 2;
+      short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(p0));
+      short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(p0 + 4 * SG));
+      u32x4 pk;
+      pk.x = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+      pk.y = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+      pk.z = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+      pk.w = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+      fg[b] = __builtin_bit_cast(bf16x8, pk);
+    }
+#pragma unroll
+    for (int a = 0; a < NCI; ++a)
+#pragma unroll
+      for (int b = 0; b < NCO; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fg[b], acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+  };
 
   for (int64_t base = p_begin; base < p_end; base += kQ) {
     // ---- ballot-compact the valid pairs of up to kQ positions (wave-private, in order)
@@ -202,81 +291,56 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(View v, const bf16_t *__rest
     if (lane < 16 && n + lane < ngroups * 16) { q_in[n + lane] = -1; q_out[n + lane] = -1; }
     __builtin_amdgcn_wave_barrier();
 
-    uint4 ra[LA], rg[LG];
-    auto issue = [&](int g) {
+    // ---- D-deep ring: the rows of group g+D-1 are in flight while group g goes through LDS and the MFMAs
+    int issued = 0, done = 0;
 #pragma unroll
-      for (int q = 0; q < LA; ++q) {
-        const int id = q * 64 + lane;
-        const int row = id / (CA / 8), ch = (id % (CA / 8)) * 8;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (row < 16) {
-          const int32_t r = q_in[g * 16 + row];
-          if (r >= 0 && ci0 + ch + 8 <= cin_real) val = *reinterpret_cast<const uint4 *>(in + (int64_t)r * cin_real + ci0 + ch);
-        }
-        ra[q] = val;
+    for (int d = 0; d < D - 1; ++d)
+      if (issued < ngroups) { issue(issued, ra[d], rg[d]); ++issued; }
+    while (ngroups - issued >= D) {   // steady state: unconditional issue -> counted vmcnt waits
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        issue(issued + d, ra[(d + D - 1) % D], rg[(d + D - 1) % D]);
+        consume(ra[d], rg[d]);
       }
-#pragma unroll
-      for (int q = 0; q < LG; ++q) {
-        const int id = q * 64 + lane;
-        const int row = id / (CG / 8), ch = (id % (CG / 8)) * 8;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (row < 16) {
-          const int32_t r = q_out[g * 16 + row];
-          if (r >= 0 && co0 + ch + 8 <= cout_real) val = *reinterpret_cast<const uint4 *>(gout + (int64_t)r * cout_real + co0 + ch);
-        }
-        rg[q] = val;
-      }
-    };
-    if (ngroups > 0) issue(0);
-    for (int g = 0; g < ngroups; ++g) {
-      // park the 16 x CA and 16 x CG row pieces row-major in the wave's LDS tile
-#pragma unroll
-      for (int q = 0; q < LA; ++q) {
-        const int id = q * 64 + lane;
-        const int row = id / (CA / 8), ch = (id % (CA / 8)) * 8;
-        if (row < 16) *reinterpret_cast<uint4 *>(stA + row * SA + ch * 2) = ra[q];
-      }
-#pragma unroll
-      for (int q = 0; q < LG; ++q) {
-        const int id = q * 64 + lane;
-        const int row = id / (CG / 8), ch = (id % (CG / 8)) * 8;
-        if (row < 16) *reinterpret_cast<uint4 *>(stG + row * SG + ch * 2) = rg[q];
-      }
-      if (g + 1 < ngroups) issue(g + 1);  // next group's rows fly under the transposing reads + MFMAs
-      __builtin_amdgcn_wave_barrier();
-      // transposing reads -> MFMA operands (lane: channel = lane&31 of the block, pairs 8h..8h+7)
-      bf16x8 fa[NCI], fg[NCO];
-#pragma unroll
-      for (int a = 0; a < NCI; ++a) {
-        const char *p0 = stA + tr_row * SA + (32 * a + tr_col) * 2;
-        short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(p0));
-        short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(p0 + 4 * SA));
-        uint4 pk;
-        pk.x = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
-        pk.y = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
-        pk.z = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
-        pk.w = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
-        fa[a] = __builtin_bit_cast(bf16x8, pk);
-      }
-#pragma unroll
-      for (int b = 0; b < NCO; ++b) {
-        const char *p0 = stG + tr_row * SG + (32 * b + tr_col) * 2;
-        short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(p0));
-        short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(p0 + 4 * SG));
-        uint4 pk;
-        pk.x = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
-        pk.y = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
-        pk.z = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
-        pk.w = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
-        fg[b] = __builtin_bit_cast(bf16x8, pk);
-      }
-#pragma unroll
-      for (int a = 0; a < NCI; ++a)
-#pragma unroll
-        for (int b = 0; b < NCO; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fg[b], acc[a][b], 0, 0, 0);
-      __builtin_amdgcn_wave_barrier();
+      issued += D;
+      done += D;
     }
+    while (done < ngroups) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if (done < ngroups) {
+          if (issued < ngroups) { issue(issued, ra[(d + D - 1) % D], rg[(d + D - 1) % D]); ++issued; }
+          consume(ra[d], rg[d]);
+          ++done;
+        }
+      }
+    }
+  }
+  // ---- waves that split one offset's range (wpk > 1: all waves of the workgroup are alive, same k) fold their
+  // accumulators into wave 0 through the now idle staging LDS, in a fixed order
+  if (wpk > 1) {
+    float *red = reinterpret_cast<float *>(smem);
+    for (int rr = 1; rr < wpk; ++rr) {
+      __syncthreads();
+      if (sub == rr) {
+#pragma unroll
+        for (int a = 0; a < NCI; ++a)
+#pragma unroll
+          for (int b = 0; b < NCO; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((a * NCO + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+      }
+      __syncthreads();
+      if (sub == 0) {
+#pragma unroll
+        for (int a = 0; a < NCI; ++a)
+#pragma unroll
+          for (int b = 0; b < NCO; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] += red[((a * NCO + b) * 16 + r) * 64 + lane];
+      }
+    }
+    if (sub != 0) return;
   }
   // ---- partial[wslot][k][ci][co]: D[i = ci][j = co], lane holds column j = lane&31, rows (r&3)+8(r>>2)+4h
   const int vx = lane & 31, h = lane >> 5;
@@ -315,6 +379,7 @@ struct WgradPlan {
   int ncb;        // fp32 path: co blocks per wave
   int nci, nco;   // bf16 path: wave tile in 32-channel blocks
   int n_ci_tasks, n_co_tasks;
+  int kpw;        // bf16 path: kernel offsets per workgroup (one per wave)
 };
 
 inline WgradPlan wgrad_plan(const View &v, int cin, int cout, int dtype) {
@@ -331,15 +396,22 @@ inline WgradPlan wgrad_plan(const View &v, int cin, int cout, int dtype) {
     if (nbo % 4 == 0 && p.nci <= 3) p.nco = 4;
     p.n_ci_tasks = (nbi + p.nci - 1) / p.nci;
     p.n_co_tasks = (nbo + p.nco - 1) / p.nco;
-    int64_t tasks = (int64_t)v.K * p.n_ci_tasks * p.n_co_tasks;
-    int64_t want = (2048 + tasks - 1) / tasks;           // wave slots so that ~2048 waves are in flight
-    int64_t maxs = (v.n_pad + 1023) / 1024;              // at least 1024 positions per slot
-    int64_t S = want < maxs ? want : maxs;
-    if (S < 1) S = 1;
-    S = (S + 3) / 4 * 4;                                  // 4 waves per workgroup
-    while (S > 4 && S * per > (1ll << 30)) S -= 4;
-    p.span = ((v.n_pad + S - 1) / S + 63) / 64 * 64;
-    p.S = (int)S;
+    // large maps: one offset per wave (4 offsets share a range's rows in L1/L2); small maps and the grouped views
+    // (whose positions are sorted by offset, so a range holds a single offset): one offset per workgroup, the four
+    // waves split the range
+    p.kpw = (v.n_pad >= 65536 && v.KS > 1) ? (v.K >= 4 ? 4 : (v.K >= 2 ? 2 : 1)) : 1;
+    const int wpk = 4 / p.kpw;
+    // position range per workgroup: 4096 voxels (rows + halo ~1.6 MB at 96 channels: L2 resident), larger only to
+    // bound the partial buffer
+    int64_t range = 4096;
+    // small maps (coarse levels): shrink the range (>= 1024) only while fewer than ~512 workgroups exist; every
+    // (range, offset) costs one partial slab of Cin x Cout floats, so ranges must stay large next to it
+    const int64_t KG = (v.K + p.kpw - 1) / p.kpw, tasks = (int64_t)p.n_ci_tasks * p.n_co_tasks;
+    while (range > 1024 && ((v.n_pad + range - 1) / range) * KG * tasks < 512) range /= 2;
+    while (((v.n_pad + range - 1) / range) * per > (1ll << 30) && range < (1ll << 24)) range *= 2;
+    p.span = range;
+    p.S = (int)((v.n_pad + range - 1) / range);
+    (void)wpk;
   } else {
     p.ncb = (nbo % 4 == 0) ? 4 : (nbo % 3 == 0) ? 3 : (nbo % 2 == 0) ? 2 : 1;
     int64_t chunks = (v.n_pad + kWgChunk - 1) / kWgChunk;
@@ -358,7 +430,7 @@ inline WgradPlan wgrad_plan(const View &v, int cin, int cout, int dtype) {
 int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype) {
   WgradPlan a = wgrad_plan(km->fwd, cin, cout, dtype), b = wgrad_plan(km->bwd, cin, cout, dtype);
   int64_t per = (int64_t)km->K * pad32(cin) * pad32(cout) * 4;
-  int64_t bytes = align256((int64_t)(a.S > b.S ? a.S : b.S) * per) + 256;
+  int64_t bytes = kWgZero + align256((int64_t)(a.S > b.S ? a.S : b.S) * per) + 256;
   if (dtype == LGS_BF16 && cin % 8 != 0) {
     int64_t nmax = km->fwd.n_in > km->bwd.n_in ? km->fwd.n_in : km->bwd.n_in;
     bytes += align256(nmax * (int64_t)((cin + 7) / 8 * 8) * 2);
@@ -368,12 +440,17 @@ int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype) 
 
 template <int NCI, int NCO>
 int launch_wgrad_bf16(const View &v, const WgradPlan &p, const bf16_t *in, int cin, const bf16_t *go, int cout,
-                      float *partial, hipStream_t s) {
+                      float *partial, const void *zpage, hipStream_t s) {
   constexpr int CA = 32 * NCI, CG = 32 * NCO;
+  constexpr int D = (NCI * NCO >= 9) ? 3 : 4;
   constexpr int WAVE_BYTES = 2 * kQ * 4 + 16 * tile_stride(CA) + 16 * tile_stride(CG);
-  dim3 grid((unsigned)(p.S / 4), (unsigned)v.K, (unsigned)(p.n_ci_tasks * p.n_co_tasks));
-  hipLaunchKernelGGL((k_wgrad_bf16<NCI, NCO>), grid, 256, 4 * WAVE_BYTES, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span,
-                     p.n_ci_tasks, partial);
+  static_assert(4 * WAVE_BYTES >= NCI * NCO * 16 * 64 * 4, "staging LDS must hold one accumulator tile");
+  const int n_tasks = p.n_ci_tasks * p.n_co_tasks;
+  const int n_ranges = p.S;
+  const int KG = (v.K + p.kpw - 1) / p.kpw;
+  const unsigned nblocks = (unsigned)(((n_ranges + 7) / 8) * 8 * KG * n_tasks);
+  hipLaunchKernelGGL((k_wgrad_bf16<NCI, NCO, D>), dim3(nblocks), 256, 4 * WAVE_BYTES, s, v, in, cin, go, cout, p.cin_pad,
+                     p.cout_pad, p.span, p.kpw, p.n_ci_tasks, n_tasks, n_ranges, partial, reinterpret_cast<const u32x4 *>(zpage));
   return 0;
 }
 
@@ -389,20 +466,21 @@ int conv_wgrad_bf16(const View &v, const void *in_v, int cin, const void *gout_v
                     hipStream_t s) {
   LGS_REQUIRE(cout % 8 == 0, "bf16 wgrad: output channel count must be a multiple of 8 (16-byte rows)");
   WgradPlan p = wgrad_plan(v, cin, cout, LGS_BF16);
-  float *partial = reinterpret_cast<float *>(workspace);
+  char *wsb = reinterpret_cast<char *>(workspace);
+  LGS_HIP(hipMemsetAsync(wsb, 0, kWgZero, s));
+  float *partial = reinterpret_cast<float *>(wsb + kWgZero);
   const bf16_t *in = reinterpret_cast<const bf16_t *>(in_v), *go = reinterpret_cast<const bf16_t *>(gout_v);
   const int cin_real = cin;
   if (cin % 8 != 0) {  // e.g. the 3-channel colour input of conv0p1s1: zero-pad rows to 8 channels behind the partials
     const int c8 = (cin + 7) / 8 * 8;
-    bf16_t *padded = reinterpret_cast<bf16_t *>(reinterpret_cast<char *>(workspace) +
-                                                align256((int64_t)p.S * v.K * p.cin_pad * p.cout_pad * 4));
+    bf16_t *padded = reinterpret_cast<bf16_t *>(wsb + kWgZero + align256((int64_t)p.S * v.K * p.cin_pad * p.cout_pad * 4));
     int64_t tot = v.n_in * (int64_t)c8;
     if (tot > 0) hipLaunchKernelGGL(k_pad_rows_bf16, (unsigned)((tot + 255) / 256), 256, 0, s, in, v.n_in, cin, c8, padded);
     in = padded;
     cin = c8;
   }
   // every (slot, k, ci, co) element of `partial` is written exactly once by the wave that owns it
-#define LGS_WG(A, B) if (p.nci == A && p.nco == B) { launch_wgrad_bf16<A, B>(v, p, in, cin, go, cout, partial, s); } else
+#define LGS_WG(A, B) if (p.nci == A && p.nco == B) { launch_wgrad_bf16<A, B>(v, p, in, cin, go, cout, partial, wsb, s); } else
   LGS_WG(1, 1) LGS_WG(1, 2) LGS_WG(1, 3) LGS_WG(1, 4)
   LGS_WG(2, 1) LGS_WG(2, 2) LGS_WG(2, 3) LGS_WG(2, 4)
   LGS_WG(3, 1) LGS_WG(3, 2) LGS_WG(3, 3) LGS_WG(3, 4)
