@@ -1,0 +1,112 @@
+"""N > 1 path on CPU: world_size-2 gloo processes.  Covers the bucketed gradient all-reduce (overlapped with
+backward through post-accumulate hooks), unused-parameter flushing (the reference runs DDP with
+find_unused_parameters=True, main.py:193) and the packed SyncBatchNorm statistics exchange (main.py:122-123)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def run_distributed(fn, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 16)
+        self.b = nn.Linear(16, 4)
+        self.unused = nn.Linear(3, 3)       # never touched in forward
+
+    def forward(self, x):
+        return self.b(torch.relu(self.a(x)))
+
+
+def _ddp_job(rank, world):
+    from languagegroundedsemseg_amd.ddp import BucketedDDP
+    torch.manual_seed(100 + rank)            # different init per rank: the wrapper must broadcast rank 0's
+    net = Net()
+    ddp = BucketedDDP(net, bucket_mb=0.0005)  # tiny buckets -> several async all-reduces
+    assert len(ddp.buckets) > 1
+    torch.manual_seed(7)
+    full = torch.randn(8, 8)
+    target = torch.randn(8, 4)
+    x, y = full[rank * 4:(rank + 1) * 4], target[rank * 4:(rank + 1) * 4]
+    for step in range(2):
+        ddp.zero_grad()
+        loss = ((ddp(x) - y) ** 2).mean()
+        loss.backward()
+        ddp.finalize()
+    grads = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    params = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    return grads, params
+
+
+def test_bucketed_allreduce_equals_full_batch_gradient():
+    (g0, p0), (g1, p1) = run_distributed(_ddp_job)
+    assert torch.equal(p0, p1), "parameters must be broadcast from rank 0"
+    assert torch.allclose(g0, g1, atol=1e-7), "gradients must be identical on all ranks"
+    # reference: single process on the concatenated batch with rank 0's weights
+    torch.manual_seed(100)
+    net = Net()
+    torch.manual_seed(7)
+    full, target = torch.randn(8, 8), torch.randn(8, 4)
+    loss = ((net(full) - target) ** 2).mean()
+    loss.backward()
+    ref = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in net.parameters()])
+    assert torch.allclose(g0, ref, atol=1e-6)
+
+
+def _syncbn_job(rank, world):
+    import MinkowskiEngine as ME
+    from languagegroundedsemseg_amd.ddp import sync_batch_norm
+    torch.manual_seed(3)
+    full = torch.randn(10, 6) * 2 + 1
+    x = full[:4] if rank == 0 else full[4:]            # ragged shards: 4 and 6 rows
+    x = x.clone().requires_grad_(True)
+    mod = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(nn.Sequential(ME.MinkowskiBatchNorm(6, momentum=0.02)))
+    assert isinstance(mod[0], ME.MinkowskiSyncBatchNorm)
+    bn = mod[0].bn
+    y = sync_batch_norm(x, bn)
+    w = torch.arange(1, 7, dtype=torch.float32)
+    (y * w).sum().backward()
+    return y.detach(), x.grad, bn.running_mean.clone(), bn.running_var.clone(), bn.weight.grad.clone()
+
+
+def test_sync_batch_norm_matches_full_batch():
+    r0, r1 = run_distributed(_syncbn_job)
+    torch.manual_seed(3)
+    full = (torch.randn(10, 6) * 2 + 1).requires_grad_(True)
+    bn = nn.BatchNorm1d(6, momentum=0.02)
+    y = bn(full)
+    w = torch.arange(1, 7, dtype=torch.float32)
+    (y * w).sum().backward()
+    assert torch.allclose(torch.cat([r0[0], r1[0]]), y.detach(), atol=1e-5)
+    assert torch.allclose(torch.cat([r0[1], r1[1]]), full.grad, atol=1e-5)
+    assert torch.allclose(r0[2], bn.running_mean, atol=1e-6) and torch.allclose(r1[3], bn.running_var, atol=1e-6)
+    # parameter grads stay local per rank (DDP averages them afterwards): their sum is the full-batch gradient
+    assert torch.allclose(r0[4] + r1[4], bn.weight.grad, atol=1e-5)
