@@ -201,6 +201,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--sync-bn", type=int, default=1, help="convert to MinkowskiSyncBatchNorm when gpus > 1 (main.py:122)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
+                                                       "N>1 code path with several ranks on ONE GPU)")
+    ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (single-GPU dry run of the N>1 path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -208,11 +211,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X (the engine has no CPU fallback)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
     # ---- data: scenes shard over ranks (rank r owns seeds r*S .. r*S+S-1); resident in HBM before timing

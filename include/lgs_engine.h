@@ -128,6 +128,21 @@ int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t n, int
                     const float *stats, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta,
                     int dtype, void *workspace, void *stream);
 
+/* The same op in two halves per direction, so that data-parallel training can exchange the statistics between
+ * ranks in the middle (ME.MinkowskiSyncBatchNorm, /root/reference/main.py:122-123):
+ *   lgs_bn_stats           -> mean_m2[2C] = local mean, local M2 (sum of squared deviations from the local mean)
+ *   lgs_bn_apply           <- stats[2C] = (global) mean, invstd
+ *   lgs_bn_backward_reduce -> sums[2C] = local sum dy', local sum dy' * xhat   (dy' = dy masked by ReLU)
+ *   lgs_bn_backward_apply  <- sums[2C] (all-reduced), inv_n_total = 1 / global row count */
+int lgs_bn_stats(const void *x, int64_t n, int c, float *mean_m2, int dtype, void *workspace, void *stream);
+int lgs_bn_apply(const void *x, int64_t n, int c, const float *gamma, const float *beta, const float *stats,
+                 const void *residual, int relu, void *y, int dtype, void *stream);
+int lgs_bn_backward_reduce(const void *x, const void *y, const void *dy, int64_t n, int c, const float *stats, int relu,
+                           float *sums, int dtype, void *workspace, void *stream);
+int lgs_bn_backward_apply(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
+                          const float *stats, const float *sums, float inv_n_total, int relu, void *dx, void *dresidual,
+                          int dtype, void *stream);
+
 /* ---- CLIP text-anchor contraction (MFMA) ----------------------------------------------------
  * replaces ContrastiveLanguageLoss.feat_dist (cos) + feature_sim
  *   /root/reference/lib/losses/ContrastiveLanguageLoss.py:73-95,185-192

@@ -153,6 +153,23 @@ __global__ __launch_bounds__(256) void k_fold_fwd(const float *__restrict__ scra
     running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
   }
 }
+// split API (SyncBN): local mean and M2 = sum (x - mean)^2, to be combined across ranks with Chan's formula
+template <typename T>
+__global__ __launch_bounds__(256) void k_fold_stats(const float *__restrict__ scratch, const T *__restrict__ x, int nblocks, int c,
+                                                    int64_t n, float *__restrict__ mean_m2) {
+  __shared__ double red[4][2][64];
+  const int ch = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  double s, ss;
+  fold_sums(scratch, nblocks, c, ch, part, s, ss, red);
+  if (part != 0 || ch >= c) return;
+  const double pivot = n > 0 ? (double)ld_elem(x + ch) : 0.0;
+  const double dm = n > 0 ? s / (double)n : 0.0;
+  double m2 = ss - (double)n * dm * dm;
+  if (m2 < 0.0) m2 = 0.0;
+  mean_m2[ch] = (float)(pivot + dm);
+  mean_m2[c + ch] = (float)m2;
+}
+
 __global__ __launch_bounds__(256) void k_fold_bwd(const float *__restrict__ scratch, int nblocks, int c, float *__restrict__ dgamma,
                                                   float *__restrict__ dbeta, float *__restrict__ sums) {
   __shared__ double red[4][2][64];
@@ -195,10 +212,9 @@ template <typename T>
 __global__ __launch_bounds__(kNT) void k_bn_bwd_apply(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy,
                                                       int64_t n, int c, const float *__restrict__ gamma,
                                                       const float *__restrict__ stats, const float *__restrict__ sums,
-                                                      int relu, T *__restrict__ dx, T *__restrict__ dres) {
+                                                      float inv_n, int relu, T *__restrict__ dx, T *__restrict__ dres) {
   constexpr int W = Vec<T>::W;
   const int64_t total = n * (int64_t)(c / W);
-  const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
   for (int64_t i = (int64_t)blockIdx.x * kNT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kNT) {
     const int cg = (int)(i % (c / W));
     float xv[W], gv[W];
@@ -268,7 +284,66 @@ int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, in
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
-    hipLaunchKernelGGL((k_bn_bwd_apply<T>), grid, kNT, 0, s, x, y, dy, n, c, gamma, stats, sums, relu, reinterpret_cast<T *>(dxv),
+    hipLaunchKernelGGL((k_bn_bwd_apply<T>), grid, kNT, 0, s, x, y, dy, n, c, gamma, stats, sums, n > 0 ? 1.f / (float)n : 0.f, relu, reinterpret_cast<T *>(dxv),
+                       reinterpret_cast<T *>(dresv));
+  }
+  LGS_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int bn_stats_t(const void *xv, int64_t n, int c, float *mean_m2, void *workspace, hipStream_t s) {
+  constexpr int W = Vec<T>::W;
+  LGS_REQUIRE(c % W == 0 && c / W <= kNT && c <= 2048, "lgs_bn_stats: channel count unsupported");
+  int64_t rpb;
+  int nb = reduce_blocks(n, &rpb);
+  float *scratch = reinterpret_cast<float *>(workspace);
+  const T *x = reinterpret_cast<const T *>(xv);
+  hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, n, c, 0,
+                     rpb, scratch);
+  hipLaunchKernelGGL((k_fold_stats<T>), (c + 63) / 64, 256, 0, s, scratch, x, nb, c, n, mean_m2);
+  LGS_HIP(hipGetLastError());
+  return 0;
+}
+template <typename T>
+int bn_apply_t(const void *xv, int64_t n, int c, const float *gamma, const float *beta, const float *stats, const void *res,
+               int relu, void *yv, hipStream_t s) {
+  constexpr int W = Vec<T>::W;
+  LGS_REQUIRE(c % W == 0, "lgs_bn_apply: channel count unsupported");
+  int64_t total = n * (int64_t)(c / W);
+  if (total > 0) {
+    int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
+    hipLaunchKernelGGL((k_bn_apply<T>), grid, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(res), n, c,
+                       gamma, beta, stats, relu, reinterpret_cast<T *>(yv));
+  }
+  LGS_HIP(hipGetLastError());
+  return 0;
+}
+template <typename T>
+int bn_bwd_reduce_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *stats, int relu, float *sums,
+                    void *workspace, hipStream_t s) {
+  constexpr int W = Vec<T>::W;
+  LGS_REQUIRE(c % W == 0 && c / W <= kNT && c <= 2048, "lgs_bn_backward_reduce: channel count unsupported");
+  int64_t rpb;
+  int nb = reduce_blocks(n, &rpb);
+  float *scratch = reinterpret_cast<float *>(workspace);
+  float *tmp = scratch + (size_t)2 * c * nb;  // dgamma/dbeta duplicates (unused by the caller)
+  hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
+                     reinterpret_cast<const T *>(dyv), stats, n, c, relu, rpb, scratch);
+  hipLaunchKernelGGL(k_fold_bwd, (c + 63) / 64, 256, 0, s, scratch, nb, c, tmp + c, tmp, sums);
+  LGS_HIP(hipGetLastError());
+  return 0;
+}
+template <typename T>
+int bn_bwd_apply_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *gamma, const float *stats,
+                   const float *sums, float inv_n_total, int relu, void *dxv, void *dresv, hipStream_t s) {
+  constexpr int W = Vec<T>::W;
+  LGS_REQUIRE(c % W == 0, "lgs_bn_backward_apply: channel count unsupported");
+  int64_t total = n * (int64_t)(c / W);
+  if (total > 0) {
+    int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
+    hipLaunchKernelGGL((k_bn_bwd_apply<T>), grid, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
+                       reinterpret_cast<const T *>(dyv), n, c, gamma, stats, sums, inv_n_total, relu, reinterpret_cast<T *>(dxv),
                        reinterpret_cast<T *>(dresv));
   }
   LGS_HIP(hipGetLastError());
@@ -281,10 +356,40 @@ using namespace lgs;
 
 extern "C" {
 
+int lgs_bn_stats(const void *x, int64_t n, int c, float *mean_m2, int dtype, void *workspace, void *stream) {
+  LGS_REQUIRE(x && mean_m2 && workspace, "lgs_bn_stats: null argument");
+  if (dtype == LGS_F32) return bn_stats_t<float>(x, n, c, mean_m2, workspace, (hipStream_t)stream);
+  if (dtype == LGS_BF16) return bn_stats_t<bf16_t>(x, n, c, mean_m2, workspace, (hipStream_t)stream);
+  LGS_REQUIRE(false, "lgs_bn_stats: unknown dtype");
+}
+int lgs_bn_apply(const void *x, int64_t n, int c, const float *gamma, const float *beta, const float *stats,
+                 const void *residual, int relu, void *y, int dtype, void *stream) {
+  LGS_REQUIRE(x && y && gamma && beta && stats, "lgs_bn_apply: null argument");
+  if (dtype == LGS_F32) return bn_apply_t<float>(x, n, c, gamma, beta, stats, residual, relu, y, (hipStream_t)stream);
+  if (dtype == LGS_BF16) return bn_apply_t<bf16_t>(x, n, c, gamma, beta, stats, residual, relu, y, (hipStream_t)stream);
+  LGS_REQUIRE(false, "lgs_bn_apply: unknown dtype");
+}
+int lgs_bn_backward_reduce(const void *x, const void *y, const void *dy, int64_t n, int c, const float *stats, int relu,
+                           float *sums, int dtype, void *workspace, void *stream) {
+  LGS_REQUIRE(x && dy && stats && sums && workspace, "lgs_bn_backward_reduce: null argument");
+  LGS_REQUIRE(!relu || y, "lgs_bn_backward_reduce: relu needs the forward output");
+  if (dtype == LGS_F32) return bn_bwd_reduce_t<float>(x, y, dy, n, c, stats, relu, sums, workspace, (hipStream_t)stream);
+  if (dtype == LGS_BF16) return bn_bwd_reduce_t<bf16_t>(x, y, dy, n, c, stats, relu, sums, workspace, (hipStream_t)stream);
+  LGS_REQUIRE(false, "lgs_bn_backward_reduce: unknown dtype");
+}
+int lgs_bn_backward_apply(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
+                          const float *stats, const float *sums, float inv_n_total, int relu, void *dx, void *dresidual,
+                          int dtype, void *stream) {
+  LGS_REQUIRE(x && dy && dx && gamma && stats && sums, "lgs_bn_backward_apply: null argument");
+  if (dtype == LGS_F32) return bn_bwd_apply_t<float>(x, y, dy, n, c, gamma, stats, sums, inv_n_total, relu, dx, dresidual, (hipStream_t)stream);
+  if (dtype == LGS_BF16) return bn_bwd_apply_t<bf16_t>(x, y, dy, n, c, gamma, stats, sums, inv_n_total, relu, dx, dresidual, (hipStream_t)stream);
+  LGS_REQUIRE(false, "lgs_bn_backward_apply: unknown dtype");
+}
+
 int64_t lgs_bn_workspace_bytes(int64_t n, int c) {
   int64_t rpb;
   int nb = reduce_blocks(n, &rpb);
-  return (int64_t)sizeof(float) * 2 * c * (nb + 1) + 256;
+  return (int64_t)sizeof(float) * 2 * c * (nb + 2) + 256;
 }
 
 int lgs_bn_forward(const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps, float momentum,

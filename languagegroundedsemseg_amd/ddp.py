@@ -125,9 +125,65 @@ class _SyncBNFunction(torch.autograd.Function):
         return dx.to(dy.dtype), dgamma.to(weight.dtype), dbeta.to(weight.dtype), None, None, None, None, None
 
 
-def sync_batch_norm(x, bn, group=None):
+class _SyncBNFused(torch.autograd.Function):
+    """SyncBN on the engine's split kernels (lgs_bn_stats / lgs_bn_apply / lgs_bn_backward_reduce /
+    lgs_bn_backward_apply): local (mean, M2, count) -> ONE all_gather of 2C+1 floats per rank -> Chan's parallel
+    combination -> fused normalise(+residual)(+ReLU); backward: local sums -> ONE all_reduce of 2C floats."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, eps, momentum, relu, group, backend):
+        c = x.shape[1]
+        world = dist.get_world_size(group)
+        local = torch.empty(2 * c + 1, dtype=torch.float32, device=x.device)
+        local[:2 * c] = backend.bn_stats(x)
+        local[2 * c] = float(x.shape[0])
+        allst = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=x.device)
+        dist.all_gather_into_tensor(allst, local, group=group)
+        cnt = allst[:, 2 * c].double()
+        n = cnt.sum()
+        means = allst[:, :c].double()
+        mean = (means * cnt[:, None]).sum(0) / n
+        m2 = allst[:, c:2 * c].double().sum(0) + (cnt[:, None] * (means - mean) ** 2).sum(0)
+        var = m2 / n
+        stats = torch.cat([mean, torch.rsqrt(var + eps)]).float()
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean.float() * momentum)
+                running_var.mul_(1 - momentum).add_((m2 / (n - 1).clamp_min(1)).float() * momentum)
+        y = backend.bn_apply(x, weight, bias, stats, residual, relu)
+        ctx.backend, ctx.relu, ctx.group, ctx.has_res = backend, relu, group, residual is not None
+        ctx.save_for_backward(x, weight, stats, y if relu else x.new_empty(0), (1.0 / n).float())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, stats, y, inv_n = ctx.saved_tensors
+        dy = dy.contiguous()
+        yy = y if ctx.relu else None
+        sums = ctx.backend.bn_backward_reduce(x, yy, dy, stats, ctx.relu)
+        c = x.shape[1]
+        dbeta, dgamma = sums[:c].clone(), sums[c:].clone()      # parameter grads stay local; DDP averages them
+        dist.all_reduce(sums, group=ctx.group)
+        # fold 1/N into the sums so the kernel's scalar stays 1.0 (no host sync for the global row count)
+        sums = sums * inv_n
+        dx, dres = ctx.backend.bn_backward_apply(x, yy, dy, weight, stats, sums, 1.0, ctx.relu,
+                                                 ctx.has_res and ctx.needs_input_grad[3])
+        return dx, dgamma.to(weight.dtype), dbeta.to(weight.dtype), dres, None, None, None, None, None, None, None
+
+
+def sync_batch_norm(x, bn, group=None, residual=None, relu=False):
+    """Batch statistics over the rows of all ranks.  Device tensors run on the engine's fused kernels; the pure
+    torch formulation below is only reachable with CPU tensors (the gloo host-logic tests)."""
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
-    return _SyncBNFunction.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, group)
+    if x.is_cuda:
+        from .me.core import get_backend
+        return _SyncBNFused.apply(x, bn.weight, bn.bias, residual, rm, rv, bn.eps, bn.momentum, relu, group, get_backend())
+    y = _SyncBNFunction.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, group)
+    if residual is not None:
+        y = y + residual
+    if relu:
+        y = torch.relu(y)
+    return y

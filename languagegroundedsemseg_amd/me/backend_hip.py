@@ -221,6 +221,48 @@ class HipBackend:
                                            _ptr(dres), _ptr(dgamma), _ptr(dbeta), dt, _ptr(ws), _stream()))
         return dx, dres, dgamma, dbeta
 
+    # ---- the same op in halves (SyncBN: statistics are exchanged between ranks in the middle)
+    def bn_stats(self, x):
+        L = engine.lib()
+        x = x.contiguous()
+        n, c = x.shape
+        with torch.cuda.device(x.device):
+            out = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+            ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
+            engine.check(L.lgs_bn_stats(_ptr(x), n, c, _ptr(out), _dtype_code(x), _ptr(ws), _stream()))
+        return out
+
+    def bn_apply(self, x, gamma, beta, stats, residual, relu):
+        L = engine.lib()
+        x = x.contiguous()
+        n, c = x.shape
+        with torch.cuda.device(x.device):
+            y = torch.empty_like(x)
+            res = residual.contiguous() if residual is not None else None
+            engine.check(L.lgs_bn_apply(_ptr(x), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(res), int(relu), _ptr(y),
+                                        _dtype_code(x), _stream()))
+        return y
+
+    def bn_backward_reduce(self, x, y, dy, stats, relu):
+        L = engine.lib()
+        n, c = x.shape
+        with torch.cuda.device(x.device):
+            sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+            ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
+            engine.check(L.lgs_bn_backward_reduce(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(stats), int(relu), _ptr(sums),
+                                                  _dtype_code(x), _ptr(ws), _stream()))
+        return sums
+
+    def bn_backward_apply(self, x, y, dy, gamma, stats, sums, inv_n_total, relu, want_residual):
+        L = engine.lib()
+        n, c = x.shape
+        with torch.cuda.device(x.device):
+            dx = torch.empty_like(x)
+            dres = torch.empty_like(x) if want_residual else None
+            engine.check(L.lgs_bn_backward_apply(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(stats), _ptr(sums),
+                                                 float(inv_n_total), int(relu), _ptr(dx), _ptr(dres), _dtype_code(x), _stream()))
+        return dx, dres
+
     # ---- CLIP contraction: lgs_clip_similarity
     def clip_similarity(self, feats, anchors):
         _require_dev(feats, "features")

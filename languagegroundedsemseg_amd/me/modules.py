@@ -210,11 +210,8 @@ class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
         if not (self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1):
             return super().forward(input, relu=relu, residual=residual)
         from ..ddp import sync_batch_norm
-        y = sync_batch_norm(input.F, self.bn, self.process_group)
-        if residual is not None:
-            y = y + (residual.F if isinstance(residual, SparseTensor) else residual)
-        if relu:
-            y = torch.relu(y)
+        res = residual.F if isinstance(residual, SparseTensor) else residual
+        y = sync_batch_norm(input.F, self.bn, self.process_group, residual=res, relu=relu)
         return SparseTensor(y, coordinate_map_key=input.coordinate_map_key, coordinate_manager=input.coordinate_manager)
 
     @classmethod
