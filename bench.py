@@ -99,9 +99,11 @@ class ConvLog:
         self._patched = True
 
     def summarize(self):
+        """-> (family totals of k_conv_gather launches, wgrad totals, per-shape groups sorted by time)"""
         torch.cuda.synchronize()
         fam = dict(bytes=0.0, ms=0.0, n=0)      # k_conv_gather family = fwd + dgrad launches
         wg = dict(bytes=0.0, ms=0.0, n=0)
+        groups = {}
         for r in self.rows:
             t = r["ev"][0].elapsed_time(r["ev"][1])
             e, M, K = r["e"], r["M"], r["K"]
@@ -112,7 +114,11 @@ class ConvLog:
             else:
                 b = M * r["cin"] * e + r["n_out"] * r["cout"] * e + idx + K * r["cin"] * r["cout"] * e
                 fam["bytes"] += b; fam["ms"] += t; fam["n"] += 1
-        return fam, wg
+                key = "%s K=%d %d->%d rows=%d" % ("conv_gather", K, r["cin"], r["cout"], r["n_out"])
+                g = groups.setdefault(key, dict(bytes=0.0, ms=0.0, n=0, flop=0.0))
+                g["bytes"] += b; g["ms"] += t; g["n"] += 1; g["flop"] += 2.0 * M * r["cin"] * r["cout"]
+        top = sorted(groups.items(), key=lambda kv: -kv[1]["ms"])
+        return fam, wg, top
 
 
 # ----------------------------------------------------------------------------------------------- the step
@@ -292,7 +298,7 @@ def main():
         train_step(model, ddp, opt, coords, feats, labels, dtype, args.warmup + args.steps)
         if clog is not None:
             e_ev.record()
-            fam, wg = clog.summarize()
+            fam, wg, top = clog.summarize()
             clog.enabled = False
             step_ms = s_ev.elapsed_time(e_ev)
             e = 2 if args.dtype == "bf16" else 4
@@ -303,18 +309,28 @@ def main():
             for r in fwd_rows[:-1]:
                 bn_bytes += 8.0 * r["n_out"] * r["cout"] * e
             b_alg_step = fam["bytes"] + wg["bytes"] + bn_bytes
-            achieved = fam["bytes"] / (fam["ms"] * 1e-3) if fam["ms"] > 0 else 0.0
+            # dominant kernel = the k_conv_gather launch shape with the largest total time in the step
+            dom_key, dom = top[0]
+            achieved = dom["bytes"] / (dom["ms"] * 1e-3) if dom["ms"] > 0 else 0.0
+            fam_ach = fam["bytes"] / (fam["ms"] * 1e-3) if fam["ms"] > 0 else 0.0
             out["roofline"] = {
-                "bound": "hbm", "kernel": "k_conv_gather (sparse-conv forward + dgrad implicit GEMM, all instances)",
+                "bound": "hbm",
+                "kernel": "k_conv_gather (sparse-conv forward/dgrad implicit GEMM), dominant launch shape: " + dom_key,
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                 "traffic": None,
-                "launches_per_step": fam["n"], "avg_launch_ms": fam["ms"] / max(fam["n"], 1),
-                "alg_bytes_per_launch": fam["bytes"] / max(fam["n"], 1),
-                "wgrad": {"kernel": "k_wgrad", "achieved": (wg["bytes"] / (wg["ms"] * 1e-3) / 1e9) if wg["ms"] > 0 else 0.0,
-                          "launches_per_step": wg["n"], "avg_launch_ms": wg["ms"] / max(wg["n"], 1)},
+                "launches": dom["n"], "avg_launch_ms": dom["ms"] / max(dom["n"], 1),
+                "alg_bytes_per_launch": dom["bytes"] / max(dom["n"], 1),
+                "mfma_tflops_on_real_pairs": dom["flop"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0,
+                "family": {"kernel": "k_conv_gather, all %d launches of the step" % fam["n"], "achieved": fam_ach / 1e9,
+                           "frac": fam_ach / HBM_PEAK, "total_ms": fam["ms"], "avg_launch_ms": fam["ms"] / max(fam["n"], 1)},
+                "wgrad": {"kernel": "k_wgrad_bf16 + k_wgrad_reduce, all %d launches" % wg["n"],
+                          "achieved": (wg["bytes"] / (wg["ms"] * 1e-3) / 1e9) if wg["ms"] > 0 else 0.0,
+                          "frac": (wg["bytes"] / (wg["ms"] * 1e-3) / HBM_PEAK) if wg["ms"] > 0 else 0.0, "total_ms": wg["ms"]},
                 "step": {"b_alg_bytes": b_alg_step, "b_alg_per_voxel": b_alg_step / n_vox,
                          "frac_of_hbm_peak": b_alg_step / (ms_per_step * 1e-3) / HBM_PEAK,
                          "conv_gather_ms": fam["ms"], "wgrad_ms": wg["ms"], "instrumented_step_ms": step_ms},
+                "note": "durations are HIP events on torch's current stream around each engine call (pack + kernel); "
+                        "traffic: see profiles/ for the PMC passes",
             }
     log("roofline pass done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

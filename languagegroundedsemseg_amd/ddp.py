@@ -138,7 +138,10 @@ class _SyncBNFused(torch.autograd.Function):
         local[:2 * c] = backend.bn_stats(x)
         local[2 * c] = float(x.shape[0])
         allst = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=x.device)
-        dist.all_gather_into_tensor(allst, local, group=group)
+        if dist.get_backend(group) == "nccl":
+            dist.all_gather_into_tensor(allst, local, group=group)
+        else:  # gloo (single-GPU dry runs / CPU tests) has no flat all-gather
+            dist.all_gather(list(allst.unbind(0)), local, group=group)
         cnt = allst[:, 2 * c].double()
         n = cnt.sum()
         means = allst[:, :c].double()
