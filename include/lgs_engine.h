@@ -121,12 +121,13 @@ int64_t lgs_bn_workspace_bytes(int64_t n, int c);
 int lgs_bn_forward(const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps,
                    float momentum, float *running_mean, float *running_var, const void *residual, int relu,
                    void *y, float *stats, int dtype, void *workspace, void *stream);
-/* Backward of the fused op.  y is the forward OUTPUT (used for the ReLU mask), x the forward input.
- * Writes dx, dgamma[C], dbeta[C]; if dresidual != NULL also the gradient flowing to the residual
- * (= dy masked by ReLU).  stats = the forward's mean/invstd. */
+/* Backward of the fused op.  x = forward input, stats = the forward's mean/invstd.
+ * relu: 0 = none; 1 = ReLU mask taken from the forward OUTPUT y (required when a residual was added);
+ *       2 = mask recomputed from x as (xhat*gamma + beta > 0), y may be NULL (one tensor read fewer).
+ * Writes dx, dgamma[C], dbeta[C]; if dresidual != NULL also the gradient flowing to the residual (= masked dy). */
 int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
-                    const float *stats, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta,
-                    int dtype, void *workspace, void *stream);
+                    const float *beta, const float *stats, int relu, void *dx, void *dresidual, float *dgamma,
+                    float *dbeta, int dtype, void *workspace, void *stream);
 
 /* The same op in two halves per direction, so that data-parallel training can exchange the statistics between
  * ranks in the middle (ME.MinkowskiSyncBatchNorm, /root/reference/main.py:122-123):
@@ -137,11 +138,12 @@ int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t n, int
 int lgs_bn_stats(const void *x, int64_t n, int c, float *mean_m2, int dtype, void *workspace, void *stream);
 int lgs_bn_apply(const void *x, int64_t n, int c, const float *gamma, const float *beta, const float *stats,
                  const void *residual, int relu, void *y, int dtype, void *stream);
-int lgs_bn_backward_reduce(const void *x, const void *y, const void *dy, int64_t n, int c, const float *stats, int relu,
-                           float *sums, int dtype, void *workspace, void *stream);
+int lgs_bn_backward_reduce(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
+                           const float *beta, const float *stats, int relu, float *sums, int dtype, void *workspace,
+                           void *stream);
 int lgs_bn_backward_apply(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
-                          const float *stats, const float *sums, float inv_n_total, int relu, void *dx, void *dresidual,
-                          int dtype, void *stream);
+                          const float *beta, const float *stats, const float *sums, float inv_n_total, int relu, void *dx,
+                          void *dresidual, int dtype, void *stream);
 
 /* ---- CLIP text-anchor contraction (MFMA) ----------------------------------------------------
  * replaces ContrastiveLanguageLoss.feat_dist (cos) + feature_sim

@@ -255,16 +255,20 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   auto compute = [&](int buf, int cc, const u32x4 (&F)[RB][LD], uint32_t act) __attribute__((always_inline)) {
     if (act == 0) return;
     const u32x4 *wl = &lds[buf][cc * WCH + (wn * NCB) * LD * 64 + lane];
+    // all weight fragments of the chunk are requested up front: the LDS latency of step t+1 hides under the
+    // MFMAs of step t (the compiler otherwise waits lgkmcnt(0) in front of every MFMA triple)
+    u32x4 wf[LD][NCB];
+#pragma unroll
+    for (int t = 0; t < LD; ++t)
+#pragma unroll
+      for (int nb = 0; nb < NCB; ++nb) wf[t][nb] = wl[(nb * LD + t) * 64];
 #pragma unroll
     for (int t = 0; t < LD; ++t) {
-      u32x4 wf[NCB];
-#pragma unroll
-      for (int nb = 0; nb < NCB; ++nb) wf[nb] = wl[(nb * LD + t) * 64];
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
         if (act & (1u << rb)) {
 #pragma unroll
-          for (int nb = 0; nb < NCB; ++nb) mma16<T>(acc[rb][nb], wf[nb], F[rb][t]);
+          for (int nb = 0; nb < NCB; ++nb) mma16<T>(acc[rb][nb], wf[t][nb], F[rb][t]);
         }
       }
     }
@@ -376,6 +380,9 @@ GatherCfg gather_cfg(const View &v, int nb_total) {
   constexpr bool kF32 = (sizeof(T) == 4);
   const bool big = v.n_pad >= 256 * 256;
   if (big) {
+    // 5..7 blocks (e.g. the 200 classes / 200 CLIP anchors = 7 blocks): one 128-position tile spans ALL output
+    // channels, so the [N, C] feature matrix is streamed exactly once (dense GEMM with a small N)
+    if (nb_total >= 5 && nb_total <= 7 && v.nbr == nullptr) return {6, kF32 ? 1 : 2, 7};
     if (nb_total == 1) return {0, kF32 ? 2 : 4, 1};
     if (nb_total == 2) return {1, kF32 ? 2 : 4, 2};
     if (nb_total == 3 || (nb_total % 3 == 0 && nb_total % 4 != 0)) return {2, kF32 ? 2 : 4, 3};
@@ -404,6 +411,7 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
     case 2: LGS_LAUNCH(2, 3, 4, 1, (kF32 ? 2 : 4), (kF32 ? 3 : 4)); break;
     case 3: LGS_LAUNCH(2, 4, 4, 1, (kF32 ? 1 : 2), (kF32 ? 2 : 3)); break;
     case 4: LGS_LAUNCH(1, 1, 2, 1, (kF32 ? 2 : 4), (kF32 ? 4 : 8)); break;
+    case 6: LGS_LAUNCH(1, 7, 4, 1, (kF32 ? 1 : 2), (kF32 ? 3 : 4)); break;
     default: LGS_LAUNCH(1, 1, 2, 2, (kF32 ? 2 : 4), (kF32 ? 4 : 8)); break;
   }
 #undef LGS_LAUNCH

@@ -56,9 +56,12 @@ constexpr int kNT = 256;
 // MODE 1: (dy', dy' * xhat) where dy' = dy masked by (y > 0) when relu  [backward reductions]
 // Each block handles a contiguous slab of rows; thread layout: cg = tid % G channel groups, rl = tid / G.
 // out: scratch[blocks][2][C]
+// relu: 0 = none, 1 = mask from the saved output y (needed when a residual was added), 2 = mask recomputed from x
+// as (xhat * gamma + beta > 0) -- one tensor read fewer.
 template <typename T, int MODE>
 __global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy,
-                                                   const float *__restrict__ stats, int64_t n, int c, int relu,
+                                                   const float *__restrict__ stats, const float *__restrict__ gamma,
+                                                   const float *__restrict__ beta, int64_t n, int c, int relu,
                                                    int64_t rows_per_block, float *__restrict__ scratch) {
   constexpr int W = Vec<T>::W;
   const int G = c / W;              // channel groups per row
@@ -68,10 +71,13 @@ __global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, cons
   float s0[W], s1[W];
 #pragma unroll
   for (int i = 0; i < W; ++i) s0[i] = s1[i] = 0.f;
-  float mean[W], istd[W];
+  float mean[W], istd[W], gm[W], bt[W];
   if (MODE == 1) {
 #pragma unroll
-    for (int i = 0; i < W; ++i) { mean[i] = stats[cg * W + i]; istd[i] = stats[c + cg * W + i]; }
+    for (int i = 0; i < W; ++i) {
+      mean[i] = stats[cg * W + i]; istd[i] = stats[c + cg * W + i];
+      gm[i] = relu == 2 ? gamma[cg * W + i] : 0.f; bt[i] = relu == 2 ? beta[cg * W + i] : 0.f;
+    }
   } else {
     // forward statistics are accumulated about a per-channel pivot (row 0, the same for every block) so that
     // var = E[(x-k)^2] - E[x-k]^2 does not cancel catastrophically when |mean| >> std
@@ -89,11 +95,14 @@ __global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, cons
       } else {
         float gv[W];
         Vec<T>::load(dy + r * c + cg * W, gv);
-        if (relu) {
+        if (relu == 1) {
           float yv[W];
           Vec<T>::load(y + r * c + cg * W, yv);
 #pragma unroll
           for (int i = 0; i < W; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
+        } else if (relu == 2) {
+#pragma unroll
+          for (int i = 0; i < W; ++i) gv[i] = ((xv[i] - mean[i]) * (istd[i] * gm[i]) + bt[i]) > 0.f ? gv[i] : 0.f;  // same expression as k_bn_apply
         }
 #pragma unroll
         for (int i = 0; i < W; ++i) { s0[i] += gv[i]; s1[i] += gv[i] * (xv[i] - mean[i]) * istd[i]; }
@@ -211,6 +220,7 @@ __global__ __launch_bounds__(kNT) void k_bn_apply(const T *__restrict__ x, const
 template <typename T>
 __global__ __launch_bounds__(kNT) void k_bn_bwd_apply(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy,
                                                       int64_t n, int c, const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta,
                                                       const float *__restrict__ stats, const float *__restrict__ sums,
                                                       float inv_n, int relu, T *__restrict__ dx, T *__restrict__ dres) {
   constexpr int W = Vec<T>::W;
@@ -220,11 +230,17 @@ __global__ __launch_bounds__(kNT) void k_bn_bwd_apply(const T *__restrict__ x, c
     float xv[W], gv[W];
     Vec<T>::load(x + i * W, xv);
     Vec<T>::load(dy + i * W, gv);
-    if (relu) {
+    if (relu == 1) {
       float yv[W];
       Vec<T>::load(y + i * W, yv);
 #pragma unroll
       for (int k = 0; k < W; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
+    } else if (relu == 2) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        const int ch = cg * W + k;
+        gv[k] = ((xv[k] - stats[ch]) * (stats[c + ch] * gamma[ch]) + beta[ch]) > 0.f ? gv[k] : 0.f;  // same expression as k_bn_apply
+      }
     }
     if (dres) Vec<T>::store(dres + i * W, gv);
 #pragma unroll
@@ -256,7 +272,7 @@ int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const flo
   int nb = reduce_blocks(n, &rpb);
   float *scratch = reinterpret_cast<float *>(workspace);  // caller-owned: no allocator call (and no implicit sync) here
   const T *x = reinterpret_cast<const T *>(xv);
-  hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, n, c, 0,
+  hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, n, c, 0,
                      rpb, scratch);
   hipLaunchKernelGGL((k_fold_fwd<T>), (c + 63) / 64, 256, 0, s, scratch, x, nb, c, n, eps, momentum, rm, rv, stats);
   int64_t total = n * (int64_t)(c / W);
@@ -270,8 +286,9 @@ int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const flo
 }
 
 template <typename T>
-int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *gamma, const float *stats,
-                  int relu, void *dxv, void *dresv, float *dgamma, float *dbeta, void *workspace, hipStream_t s) {
+int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *gamma, const float *beta,
+                  const float *stats, int relu, void *dxv, void *dresv, float *dgamma, float *dbeta, void *workspace,
+                  hipStream_t s) {
   constexpr int W = Vec<T>::W;
   LGS_REQUIRE(c % W == 0 && c / W <= kNT && c <= 2048, "lgs_bn_backward: channel count unsupported");
   int64_t rpb;
@@ -279,12 +296,12 @@ int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, in
   float *scratch = reinterpret_cast<float *>(workspace);
   float *sums = scratch + (size_t)2 * c * nb;
   const T *x = reinterpret_cast<const T *>(xv), *y = reinterpret_cast<const T *>(yv), *dy = reinterpret_cast<const T *>(dyv);
-  hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, x, y, dy, stats, n, c, relu, rpb, scratch);
+  hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, x, y, dy, stats, gamma, beta, n, c, relu, rpb, scratch);
   hipLaunchKernelGGL(k_fold_bwd, (c + 63) / 64, 256, 0, s, scratch, nb, c, dgamma, dbeta, sums);
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
-    hipLaunchKernelGGL((k_bn_bwd_apply<T>), grid, kNT, 0, s, x, y, dy, n, c, gamma, stats, sums, n > 0 ? 1.f / (float)n : 0.f, relu, reinterpret_cast<T *>(dxv),
+    hipLaunchKernelGGL((k_bn_bwd_apply<T>), grid, kNT, 0, s, x, y, dy, n, c, gamma, beta, stats, sums, n > 0 ? 1.f / (float)n : 0.f, relu, reinterpret_cast<T *>(dxv),
                        reinterpret_cast<T *>(dresv));
   }
   LGS_HIP(hipGetLastError());
@@ -299,7 +316,7 @@ int bn_stats_t(const void *xv, int64_t n, int c, float *mean_m2, void *workspace
   int nb = reduce_blocks(n, &rpb);
   float *scratch = reinterpret_cast<float *>(workspace);
   const T *x = reinterpret_cast<const T *>(xv);
-  hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, n, c, 0,
+  hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, n, c, 0,
                      rpb, scratch);
   hipLaunchKernelGGL((k_fold_stats<T>), (c + 63) / 64, 256, 0, s, scratch, x, nb, c, n, mean_m2);
   LGS_HIP(hipGetLastError());
@@ -320,8 +337,8 @@ int bn_apply_t(const void *xv, int64_t n, int c, const float *gamma, const float
   return 0;
 }
 template <typename T>
-int bn_bwd_reduce_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *stats, int relu, float *sums,
-                    void *workspace, hipStream_t s) {
+int bn_bwd_reduce_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *gamma, const float *beta,
+                    const float *stats, int relu, float *sums, void *workspace, hipStream_t s) {
   constexpr int W = Vec<T>::W;
   LGS_REQUIRE(c % W == 0 && c / W <= kNT && c <= 2048, "lgs_bn_backward_reduce: channel count unsupported");
   int64_t rpb;
@@ -329,21 +346,21 @@ int bn_bwd_reduce_t(const void *xv, const void *yv, const void *dyv, int64_t n, 
   float *scratch = reinterpret_cast<float *>(workspace);
   float *tmp = scratch + (size_t)2 * c * nb;  // dgamma/dbeta duplicates (unused by the caller)
   hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
-                     reinterpret_cast<const T *>(dyv), stats, n, c, relu, rpb, scratch);
+                     reinterpret_cast<const T *>(dyv), stats, gamma, beta, n, c, relu, rpb, scratch);
   hipLaunchKernelGGL(k_fold_bwd, (c + 63) / 64, 256, 0, s, scratch, nb, c, tmp + c, tmp, sums);
   LGS_HIP(hipGetLastError());
   return 0;
 }
 template <typename T>
-int bn_bwd_apply_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *gamma, const float *stats,
-                   const float *sums, float inv_n_total, int relu, void *dxv, void *dresv, hipStream_t s) {
+int bn_bwd_apply_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *gamma, const float *beta,
+                   const float *stats, const float *sums, float inv_n_total, int relu, void *dxv, void *dresv, hipStream_t s) {
   constexpr int W = Vec<T>::W;
   LGS_REQUIRE(c % W == 0, "lgs_bn_backward_apply: channel count unsupported");
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
     hipLaunchKernelGGL((k_bn_bwd_apply<T>), grid, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
-                       reinterpret_cast<const T *>(dyv), n, c, gamma, stats, sums, inv_n_total, relu, reinterpret_cast<T *>(dxv),
+                       reinterpret_cast<const T *>(dyv), n, c, gamma, beta, stats, sums, inv_n_total, relu, reinterpret_cast<T *>(dxv),
                        reinterpret_cast<T *>(dresv));
   }
   LGS_HIP(hipGetLastError());
@@ -369,20 +386,24 @@ int lgs_bn_apply(const void *x, int64_t n, int c, const float *gamma, const floa
   if (dtype == LGS_BF16) return bn_apply_t<bf16_t>(x, n, c, gamma, beta, stats, residual, relu, y, (hipStream_t)stream);
   LGS_REQUIRE(false, "lgs_bn_apply: unknown dtype");
 }
-int lgs_bn_backward_reduce(const void *x, const void *y, const void *dy, int64_t n, int c, const float *stats, int relu,
-                           float *sums, int dtype, void *workspace, void *stream) {
+int lgs_bn_backward_reduce(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
+                           const float *beta, const float *stats, int relu, float *sums, int dtype, void *workspace,
+                           void *stream) {
   LGS_REQUIRE(x && dy && stats && sums && workspace, "lgs_bn_backward_reduce: null argument");
-  LGS_REQUIRE(!relu || y, "lgs_bn_backward_reduce: relu needs the forward output");
-  if (dtype == LGS_F32) return bn_bwd_reduce_t<float>(x, y, dy, n, c, stats, relu, sums, workspace, (hipStream_t)stream);
-  if (dtype == LGS_BF16) return bn_bwd_reduce_t<bf16_t>(x, y, dy, n, c, stats, relu, sums, workspace, (hipStream_t)stream);
+  LGS_REQUIRE(relu != 1 || y, "lgs_bn_backward_reduce: relu mode 1 needs the forward output");
+  LGS_REQUIRE(relu != 2 || (gamma && beta), "lgs_bn_backward_reduce: relu mode 2 needs gamma and beta");
+  if (dtype == LGS_F32) return bn_bwd_reduce_t<float>(x, y, dy, n, c, gamma, beta, stats, relu, sums, workspace, (hipStream_t)stream);
+  if (dtype == LGS_BF16) return bn_bwd_reduce_t<bf16_t>(x, y, dy, n, c, gamma, beta, stats, relu, sums, workspace, (hipStream_t)stream);
   LGS_REQUIRE(false, "lgs_bn_backward_reduce: unknown dtype");
 }
 int lgs_bn_backward_apply(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
-                          const float *stats, const float *sums, float inv_n_total, int relu, void *dx, void *dresidual,
-                          int dtype, void *stream) {
+                          const float *beta, const float *stats, const float *sums, float inv_n_total, int relu, void *dx,
+                          void *dresidual, int dtype, void *stream) {
   LGS_REQUIRE(x && dy && dx && gamma && stats && sums, "lgs_bn_backward_apply: null argument");
-  if (dtype == LGS_F32) return bn_bwd_apply_t<float>(x, y, dy, n, c, gamma, stats, sums, inv_n_total, relu, dx, dresidual, (hipStream_t)stream);
-  if (dtype == LGS_BF16) return bn_bwd_apply_t<bf16_t>(x, y, dy, n, c, gamma, stats, sums, inv_n_total, relu, dx, dresidual, (hipStream_t)stream);
+  LGS_REQUIRE(relu != 1 || y, "lgs_bn_backward_apply: relu mode 1 needs the forward output");
+  LGS_REQUIRE(relu != 2 || beta, "lgs_bn_backward_apply: relu mode 2 needs beta");
+  if (dtype == LGS_F32) return bn_bwd_apply_t<float>(x, y, dy, n, c, gamma, beta, stats, sums, inv_n_total, relu, dx, dresidual, (hipStream_t)stream);
+  if (dtype == LGS_BF16) return bn_bwd_apply_t<bf16_t>(x, y, dy, n, c, gamma, beta, stats, sums, inv_n_total, relu, dx, dresidual, (hipStream_t)stream);
   LGS_REQUIRE(false, "lgs_bn_backward_apply: unknown dtype");
 }
 
@@ -402,14 +423,15 @@ int lgs_bn_forward(const void *x, int64_t n, int c, const float *gamma, const fl
   LGS_REQUIRE(false, "lgs_bn_forward: unknown dtype");
 }
 
-int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma, const float *stats,
-                    int relu, void *dx, void *dresidual, float *dgamma, float *dbeta, int dtype, void *workspace,
-                    void *stream) {
+int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma, const float *beta,
+                    const float *stats, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta, int dtype,
+                    void *workspace, void *stream) {
   LGS_REQUIRE(x && dy && dx && gamma && stats && dgamma && dbeta && workspace, "lgs_bn_backward: null argument");
-  LGS_REQUIRE(!relu || y, "lgs_bn_backward: relu needs the forward output");
+  LGS_REQUIRE(relu != 1 || y, "lgs_bn_backward: relu mode 1 needs the forward output");
+  LGS_REQUIRE(relu != 2 || beta, "lgs_bn_backward: relu mode 2 needs beta");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == LGS_F32) return bn_backward_t<float>(x, y, dy, n, c, gamma, stats, relu, dx, dresidual, dgamma, dbeta, workspace, s);
-  if (dtype == LGS_BF16) return bn_backward_t<bf16_t>(x, y, dy, n, c, gamma, stats, relu, dx, dresidual, dgamma, dbeta, workspace, s);
+  if (dtype == LGS_F32) return bn_backward_t<float>(x, y, dy, n, c, gamma, beta, stats, relu, dx, dresidual, dgamma, dbeta, workspace, s);
+  if (dtype == LGS_BF16) return bn_backward_t<bf16_t>(x, y, dy, n, c, gamma, beta, stats, relu, dx, dresidual, dgamma, dbeta, workspace, s);
   LGS_REQUIRE(false, "lgs_bn_backward: unknown dtype");
 }
 

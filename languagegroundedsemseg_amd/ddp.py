@@ -154,22 +154,23 @@ class _SyncBNFused(torch.autograd.Function):
                 running_mean.mul_(1 - momentum).add_(mean.float() * momentum)
                 running_var.mul_(1 - momentum).add_((m2 / (n - 1).clamp_min(1)).float() * momentum)
         y = backend.bn_apply(x, weight, bias, stats, residual, relu)
-        ctx.backend, ctx.relu, ctx.group, ctx.has_res = backend, relu, group, residual is not None
-        ctx.save_for_backward(x, weight, stats, y if relu else x.new_empty(0), (1.0 / n).float())
+        ctx.backend, ctx.group, ctx.has_res = backend, group, residual is not None
+        ctx.relu_mode = 0 if not relu else (1 if residual is not None else 2)
+        ctx.save_for_backward(x, weight, bias, stats, y if ctx.relu_mode == 1 else x.new_empty(0), (1.0 / n).float())
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, stats, y, inv_n = ctx.saved_tensors
+        x, weight, bias, stats, y, inv_n = ctx.saved_tensors
         dy = dy.contiguous()
-        yy = y if ctx.relu else None
-        sums = ctx.backend.bn_backward_reduce(x, yy, dy, stats, ctx.relu)
+        yy = y if ctx.relu_mode == 1 else None
+        sums = ctx.backend.bn_backward_reduce(x, yy, dy, weight, bias, stats, ctx.relu_mode)
         c = x.shape[1]
         dbeta, dgamma = sums[:c].clone(), sums[c:].clone()      # parameter grads stay local; DDP averages them
         dist.all_reduce(sums, group=ctx.group)
         # fold 1/N into the sums so the kernel's scalar stays 1.0 (no host sync for the global row count)
         sums = sums * inv_n
-        dx, dres = ctx.backend.bn_backward_apply(x, yy, dy, weight, stats, sums, 1.0, ctx.relu,
+        dx, dres = ctx.backend.bn_backward_apply(x, yy, dy, weight, bias, stats, sums, 1.0, ctx.relu_mode,
                                                  ctx.has_res and ctx.needs_input_grad[3])
         return dx, dgamma.to(weight.dtype), dbeta.to(weight.dtype), dres, None, None, None, None, None, None, None
 

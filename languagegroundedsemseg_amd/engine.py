@@ -63,11 +63,11 @@ def lib():
         "lgs_conv_dgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp],
         "lgs_conv_wgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp],
         "lgs_bn_forward": [vp, i64, ci, vp, vp, cf, cf, vp, vp, vp, ci, vp, vp, ci, vp, vp],
-        "lgs_bn_backward": [vp, vp, vp, i64, ci, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp],
+        "lgs_bn_backward": [vp, vp, vp, i64, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp],
         "lgs_bn_stats": [vp, i64, ci, vp, ci, vp, vp],
         "lgs_bn_apply": [vp, i64, ci, vp, vp, vp, vp, ci, vp, ci, vp],
-        "lgs_bn_backward_reduce": [vp, vp, vp, i64, ci, vp, ci, vp, ci, vp, vp],
-        "lgs_bn_backward_apply": [vp, vp, vp, i64, ci, vp, vp, vp, cf, ci, vp, vp, ci, vp],
+        "lgs_bn_backward_reduce": [vp, vp, vp, i64, ci, vp, vp, vp, ci, vp, ci, vp, vp],
+        "lgs_bn_backward_apply": [vp, vp, vp, i64, ci, vp, vp, vp, vp, cf, ci, vp, vp, ci, vp],
         "lgs_clip_similarity": [vp, i64, ci, vp, ci, vp, vp, ci, vp, vp],
         "lgs_ce_forward_backward": [vp, i64, ci, vp, i64, vp, vp, vp, ci, vp],
     }

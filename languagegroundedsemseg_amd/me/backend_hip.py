@@ -206,7 +206,8 @@ class HipBackend:
                                           _ptr(stats), dt, _ptr(ws), _stream()))
         return y, stats
 
-    def bn_backward(self, x, y, dy, gamma, stats, relu, want_residual):
+    def bn_backward(self, x, y, dy, gamma, beta, stats, relu, want_residual):
+        """relu: 0 none, 1 mask from y, 2 mask recomputed from x (y may be None)"""
         L = engine.lib()
         dy = dy.contiguous()
         n, c = x.shape
@@ -217,7 +218,7 @@ class HipBackend:
             dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
             dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
             ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
-            engine.check(L.lgs_bn_backward(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(stats), int(relu), _ptr(dx),
+            engine.check(L.lgs_bn_backward(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), int(relu), _ptr(dx),
                                            _ptr(dres), _ptr(dgamma), _ptr(dbeta), dt, _ptr(ws), _stream()))
         return dx, dres, dgamma, dbeta
 
@@ -243,23 +244,23 @@ class HipBackend:
                                         _dtype_code(x), _stream()))
         return y
 
-    def bn_backward_reduce(self, x, y, dy, stats, relu):
+    def bn_backward_reduce(self, x, y, dy, gamma, beta, stats, relu):
         L = engine.lib()
         n, c = x.shape
         with torch.cuda.device(x.device):
             sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
             ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
-            engine.check(L.lgs_bn_backward_reduce(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(stats), int(relu), _ptr(sums),
+            engine.check(L.lgs_bn_backward_reduce(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), int(relu), _ptr(sums),
                                                   _dtype_code(x), _ptr(ws), _stream()))
         return sums
 
-    def bn_backward_apply(self, x, y, dy, gamma, stats, sums, inv_n_total, relu, want_residual):
+    def bn_backward_apply(self, x, y, dy, gamma, beta, stats, sums, inv_n_total, relu, want_residual):
         L = engine.lib()
         n, c = x.shape
         with torch.cuda.device(x.device):
             dx = torch.empty_like(x)
             dres = torch.empty_like(x) if want_residual else None
-            engine.check(L.lgs_bn_backward_apply(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(stats), _ptr(sums),
+            engine.check(L.lgs_bn_backward_apply(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(sums),
                                                  float(inv_n_total), int(relu), _ptr(dx), _ptr(dres), _dtype_code(x), _stream()))
         return dx, dres
 

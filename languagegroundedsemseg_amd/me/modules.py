@@ -144,19 +144,22 @@ class FusedBatchNormFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, backend):
         y, stats = backend.bn_forward(x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu)
-        ctx.backend, ctx.relu, ctx.has_res = backend, relu, residual is not None
-        if relu:
-            ctx.save_for_backward(x, gamma, stats, y)
+        # ReLU mask in the backward: recomputed from x when there is no residual (mode 2, y is not kept alive),
+        # taken from the saved output otherwise (mode 1)
+        ctx.backend, ctx.has_res = backend, residual is not None
+        ctx.relu_mode = 0 if not relu else (1 if residual is not None else 2)
+        if ctx.relu_mode == 1:
+            ctx.save_for_backward(x, gamma, beta, stats, y)
         else:
-            ctx.save_for_backward(x, gamma, stats)
+            ctx.save_for_backward(x, gamma, beta, stats)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         saved = ctx.saved_tensors
-        x, gamma, stats = saved[0], saved[1], saved[2]
-        y = saved[3] if ctx.relu else None
-        dx, dres, dgamma, dbeta = ctx.backend.bn_backward(x, y, dy, gamma, stats, ctx.relu,
+        x, gamma, beta, stats = saved[0], saved[1], saved[2], saved[3]
+        y = saved[4] if ctx.relu_mode == 1 else None
+        dx, dres, dgamma, dbeta = ctx.backend.bn_backward(x, y, dy, gamma, beta, stats, ctx.relu_mode,
                                                           ctx.has_res and ctx.needs_input_grad[3])
         return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), dres, None, None, None, None, None, None
 

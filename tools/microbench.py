@@ -73,5 +73,23 @@ def main():
         print("%-9s BN+ReLU fwd 96ch %.3f ms (%.2f TB/s of 3*N*C*e)" % (str(dtype).split(".")[1], tb, 3 * n * 96 * e / tb / 1e9))
 
 
+def clip():
+    """MFMA sub-report: S = normalize(F) . normalize(T)^T, [N,C] x [C,200]"""
+    n = 1200000
+    for c in (512, 96):
+        for dtype in (torch.bfloat16, torch.float32):
+            f = torch.randn(n, c, device=DEV).to(dtype)
+            t = torch.randn(200, c, device=DEV)
+            be = ME.get_backend()
+            ms = timeit(lambda: be.clip_similarity(f, t))
+            flop = 2.0 * n * c * 200
+            byts = n * c * f.element_size() + n * 200 * 4
+            print("clip similarity N=%d C=%d %-8s %.3f ms  %.1f TFLOP/s  %.2f TB/s (read F + write S)" % (
+                n, c, str(dtype).split(".")[1], ms, flop / ms / 1e9, byts / ms / 1e9))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "clip":
+        clip()
+        sys.exit(0)
     main()
