@@ -268,22 +268,32 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(View v, const bf16_t *__rest
   };
 
   for (int64_t base = p_begin; base < p_end; base += kQ) {
-    // ---- ballot-compact the valid pairs of up to kQ positions (wave-private, in order)
+    // ---- ballot-compact the valid pairs of up to kQ positions (wave-private, in order).  All index loads of the
+    // chunk are issued first (16 independent loads in flight instead of 16 dependent round trips), then compacted.
     int n = 0;
-    const int64_t cend = min(base + kQ, p_end);
-    for (int64_t b = base; b < cend; b += 64) {
-      bool grp_ok = true;
-      if (v.KS > 1) grp_ok = (v.mask64[b >> 6] >> slot) & 1u;
-      else if (v.tile_k) grp_ok = v.tile_k[b >> 6] == k;
-      if (!grp_ok) continue;  // wave-uniform
-      const int64_t p = b + lane;
-      int32_t o = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
-      int32_t i = v.nbr ? v.nbr[(int64_t)slot * v.n_pad + p] : (p < v.n_in ? (int32_t)p : -1);
-      const bool ok = (i >= 0) && (o >= 0);
+    constexpr int NIT = kQ / 64;
+    int32_t iv[NIT], ov[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      const int64_t b = base + u * 64;
+      const bool in_rng = b < p_end;                      // wave-uniform (ranges are multiples of 64)
+      const int64_t bb = in_rng ? b : p_begin;            // clamp: loads stay in bounds, result masked below
+      bool grp_ok = in_rng;
+      if (v.KS > 1) grp_ok = grp_ok && ((v.mask64[bb >> 6] >> slot) & 1u);
+      else if (v.tile_k) grp_ok = grp_ok && (v.tile_k[bb >> 6] == k);
+      const int64_t p = bb + lane;
+      const int32_t o = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
+      const int32_t i = v.nbr ? v.nbr[(int64_t)slot * v.n_pad + p] : (p < v.n_in ? (int32_t)p : -1);
+      iv[u] = grp_ok ? i : -1;
+      ov[u] = o;
+    }
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      const bool ok = (iv[u] >= 0) && (ov[u] >= 0);
       const unsigned long long bal = __ballot(ok);
       if (ok) {
         const int at = n + (int)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
-        q_in[at] = i; q_out[at] = o;
+        q_in[at] = iv[u]; q_out[at] = ov[u];
       }
       n += (int)__builtin_popcountll(bal);
     }
