@@ -46,39 +46,72 @@ class BucketedDDP:
         n = sum(p.numel() for p in params)
         flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
         off = 0
-        bucket = {"flat": flat, "params": params, "pending": len(params), "n": len(params)}
+        bucket = {"flat": flat, "params": params, "pending": len(params), "n": len(params), "views": []}
         for p in params:
-            p.grad = flat[off:off + p.numel()].view_as(p)
+            # the engine's backward kernels write gradients straight into this slot (me.modules.grad_slot_view);
+            # any other producer falls back to autograd's own accumulation into the same memory
+            p._lgs_grad_slot = (flat, off, tuple(p.shape))
+            bucket["views"].append((p, off))
             off += p.numel()
             if self.world > 1:
                 p.register_post_accumulate_grad_hook(self._hook(bucket))
         self.buckets.append(bucket)
 
+    def _side_streams(self):
+        from .me.core import get_backend
+        be = get_backend()
+        return list(getattr(be, "_side", {}).values())
+
+    def _join_side(self):
+        """weight gradients are produced on the backend's side stream: order them before any consumer"""
+        if self.buckets and self.buckets[0]["flat"].is_cuda:
+            cur = torch.cuda.current_stream()
+            for s in self._side_streams():
+                cur.wait_stream(s)
+
     def _hook(self, bucket):
         def fn(param):
             bucket["pending"] -= 1
             if bucket["pending"] == 0:
-                bucket["flat"].div_(self.world)
-                self._handles.append(dist.all_reduce(bucket["flat"], group=self.group, async_op=True))
+                self._launch(bucket)
         return fn
+
+    def _launch(self, bucket):
+        self._join_side()
+        # parameters whose gradient did not land in its slot (produced outside the engine): copy it in
+        for p, off in bucket["views"]:
+            g = p.grad
+            if g is not None and g.data_ptr() != bucket["flat"].data_ptr() + off * 4:
+                bucket["flat"][off:off + p.numel()].copy_(g.reshape(-1))
+                p.grad = bucket["flat"][off:off + p.numel()].view_as(p)
+        bucket["flat"].div_(self.world)
+        self._handles.append(dist.all_reduce(bucket["flat"], group=self.group, async_op=True))
 
     def zero_grad(self):
         for b in self.buckets:
             b["flat"].zero_()
             b["pending"] = b["n"]
+            for p, _ in b["views"]:
+                p.grad = None
 
     def finalize(self):
-        """call after backward(): waits for the in-flight bucket all-reduces (and flushes buckets whose
-        parameters received no gradient this step -- the reference runs find_unused_parameters=True)."""
+        """call after backward(): waits for the side-stream weight gradients and the in-flight bucket all-reduces
+        (and flushes buckets whose parameters received no gradient this step -- the reference runs
+        find_unused_parameters=True)."""
+        self._join_side()
         if self.world > 1:
             for b in self.buckets:
-                if 0 < b["pending"]:
-                    if b["pending"] <= b["n"]:
-                        b["flat"].div_(self.world)
-                        self._handles.append(dist.all_reduce(b["flat"], group=self.group, async_op=True))
+                if b["pending"] > 0:
+                    self._launch(b)
                     b["pending"] = 0
             for h in self._handles:
                 h.wait()
+        else:
+            for b in self.buckets:
+                for p, off in b["views"]:
+                    g = p.grad
+                    if g is not None and g.data_ptr() != b["flat"].data_ptr() + off * 4:
+                        pass  # single process: a gradient living outside its slot is fine as it is
         self._handles = []
 
     def __call__(self, *a, **k):

@@ -94,14 +94,19 @@ class HipKernelMap:
                                           _stream()))
         return gin
 
-    def conv_wgrad(self, x, gout, transposed):
+    def conv_wgrad(self, x, gout, transposed, out=None):
+        """-> grad_weight [K,cin,cout] fp32; written straight into `out` (e.g. a view of a gradient bucket) if given"""
         L = engine.lib()
         x, gout = x.contiguous(), gout.contiguous()
         cin, cout = x.shape[1], gout.shape[1]
         dt = _dtype_code(x)
         assert gout.dtype == x.dtype
         with torch.cuda.device(x.device):
-            gw = torch.empty((self.K, cin, cout), dtype=torch.float32, device=x.device)
+            if out is not None:
+                assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == self.K * cin * cout
+                gw = out
+            else:
+                gw = torch.empty((self.K, cin, cout), dtype=torch.float32, device=x.device)
             ws = _ws(L.lgs_conv_workspace_bytes(self.h, cin, cout, dt, 2), x.device)
             engine.check(L.lgs_conv_wgrad(self.h, int(transposed), _ptr(x), cin, _ptr(gout), cout, _ptr(gw), dt, _ptr(ws),
                                           _stream()))
@@ -186,8 +191,18 @@ class HipManager:
 class HipBackend:
     name = "hip"
 
+    def __init__(self):
+        self._side = {}
+
     def new_manager(self, device):
         return HipManager(device)
+
+    def side_stream(self, device):
+        """second HIP stream per device: weight gradients run here, concurrently with the dgrad / BN chain"""
+        key = torch.device(device).index
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=device)
+        return self._side[key]
 
     # ---- fused BN(+residual)(+ReLU): lgs_bn_forward / lgs_bn_backward
     def bn_forward(self, x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu):
@@ -206,7 +221,7 @@ class HipBackend:
                                           _ptr(stats), dt, _ptr(ws), _stream()))
         return y, stats
 
-    def bn_backward(self, x, y, dy, gamma, beta, stats, relu, want_residual):
+    def bn_backward(self, x, y, dy, gamma, beta, stats, relu, want_residual, dgamma_out=None, dbeta_out=None):
         """relu: 0 none, 1 mask from y, 2 mask recomputed from x (y may be None)"""
         L = engine.lib()
         dy = dy.contiguous()
@@ -215,8 +230,8 @@ class HipBackend:
         with torch.cuda.device(x.device):
             dx = torch.empty_like(x)
             dres = torch.empty_like(x) if want_residual else None
-            dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
-            dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+            dgamma = dgamma_out if dgamma_out is not None else torch.empty(c, dtype=torch.float32, device=x.device)
+            dbeta = dbeta_out if dbeta_out is not None else torch.empty(c, dtype=torch.float32, device=x.device)
             ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
             engine.check(L.lgs_bn_backward(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), int(relu), _ptr(dx),
                                            _ptr(dres), _ptr(dgamma), _ptr(dbeta), dt, _ptr(ws), _stream()))

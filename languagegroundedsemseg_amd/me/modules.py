@@ -27,13 +27,31 @@ class MinkowskiNetwork(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------ convolution
+def grad_slot_view(param):
+    """Fresh view of the parameter's slot in a flat gradient bucket (languagegroundedsemseg_amd.ddp.BucketedDDP), or
+    None.  Returning such a view from backward() lets autograd adopt it as `.grad` without an accumulation kernel:
+    the engine has already written the gradient where the all-reduce and the optimiser will read it."""
+    slot = getattr(param, "_lgs_grad_slot", None)
+    if slot is None or param.grad is not None:
+        return None
+    flat, off, shape = slot
+    n = 1
+    for d in shape:
+        n *= d
+    return flat[off:off + n].view(shape)
+
+
 class MinkowskiConvolutionFunction(torch.autograd.Function):
-    """out = conv(in) over a cached kernel map; backward = dgrad + wgrad (+ bias grad) on the same map."""
+    """out = conv(in) over a cached kernel map; backward = dgrad + wgrad (+ bias grad) on the same map.
+    When the kernel parameter owns a bucket slot the weight gradient is written straight into it ON A SIDE STREAM:
+    wgrad is off the backward critical path (dgrad -> BN -> dgrad ...), and both kernels are latency-bound, so running
+    them concurrently fills the machine."""
 
     @staticmethod
     def forward(ctx, feats, kernel, bias, kmap, transposed):
         ctx.kmap, ctx.transposed, ctx.has_bias = kmap, transposed, bias is not None
         ctx.kshape = kernel.shape
+        ctx.kparam = kernel if isinstance(kernel, torch.nn.Parameter) else None
         ctx.save_for_backward(feats, kernel)
         return kmap.conv_forward(feats, kernel, bias, transposed)
 
@@ -42,10 +60,22 @@ class MinkowskiConvolutionFunction(torch.autograd.Function):
         feats, kernel = ctx.saved_tensors
         gout = gout.contiguous()
         gin = gw = gb = None
+        if ctx.needs_input_grad[1]:
+            view = grad_slot_view(ctx.kparam) if ctx.kparam is not None else None
+            backend = get_backend()
+            if view is not None and gout.is_cuda and hasattr(backend, "side_stream"):
+                main = torch.cuda.current_stream(gout.device)
+                side = backend.side_stream(gout.device)
+                side.wait_stream(main)                       # feats / gout are ready
+                with torch.cuda.stream(side):
+                    gw = ctx.kmap.conv_wgrad(feats, gout, ctx.transposed, out=view.view(ctx.kmap.K, -1, ctx.kshape[-1]))
+                feats.record_stream(side)
+                gout.record_stream(side)
+                gw = view                                    # consumers wait for the side stream in BucketedDDP
+            else:
+                gw = ctx.kmap.conv_wgrad(feats, gout, ctx.transposed).reshape(ctx.kshape).to(kernel.dtype)
         if ctx.needs_input_grad[0]:
             gin = ctx.kmap.conv_dgrad(gout, kernel, ctx.transposed)
-        if ctx.needs_input_grad[1]:
-            gw = ctx.kmap.conv_wgrad(feats, gout, ctx.transposed).reshape(ctx.kshape).to(kernel.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gout.float().sum(0, keepdim=True)
         return gin, gw, gb, None, None
@@ -143,6 +173,8 @@ class FusedBatchNormFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, backend):
+        ctx.gparam = gamma if isinstance(gamma, torch.nn.Parameter) else None
+        ctx.bparam = beta if isinstance(beta, torch.nn.Parameter) else None
         y, stats = backend.bn_forward(x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu)
         # ReLU mask in the backward: recomputed from x when there is no residual (mode 2, y is not kept alive),
         # taken from the saved output otherwise (mode 1)
@@ -159,8 +191,14 @@ class FusedBatchNormFunction(torch.autograd.Function):
         saved = ctx.saved_tensors
         x, gamma, beta, stats = saved[0], saved[1], saved[2], saved[3]
         y = saved[4] if ctx.relu_mode == 1 else None
+        gview = grad_slot_view(ctx.gparam) if ctx.gparam is not None else None
+        bview = grad_slot_view(ctx.bparam) if ctx.bparam is not None else None
+        if gview is None or bview is None or not hasattr(ctx.backend, "side_stream"):
+            gview = bview = None
         dx, dres, dgamma, dbeta = ctx.backend.bn_backward(x, y, dy, gamma, beta, stats, ctx.relu_mode,
-                                                          ctx.has_res and ctx.needs_input_grad[3])
+                                                          ctx.has_res and ctx.needs_input_grad[3], gview, bview)
+        if gview is not None:
+            return dx, gview, bview, dres, None, None, None, None, None, None
         return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), dres, None, None, None, None, None, None
 
 

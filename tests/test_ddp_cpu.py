@@ -61,7 +61,8 @@ def _ddp_job(rank, world):
         loss = ((ddp(x) - y) ** 2).mean()
         loss.backward()
         ddp.finalize()
-    grads = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    # parameters that received no gradient keep .grad = None (the optimiser skips them on every rank alike)
+    grads = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in net.parameters()])
     params = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     return grads, params
 
