@@ -35,7 +35,7 @@ if ROOT not in sys.path:
 
 import MinkowskiEngine as ME  # noqa: E402
 from languagegroundedsemseg_amd import models  # noqa: E402
-from languagegroundedsemseg_amd.ddp import BucketedDDP  # noqa: E402
+from languagegroundedsemseg_amd.ddp import BucketedDDP, FlatSGD  # noqa: E402
 from languagegroundedsemseg_amd.losses import fused_cross_entropy  # noqa: E402
 from languagegroundedsemseg_amd.synthetic import make_batch  # noqa: E402
 
@@ -132,9 +132,10 @@ def train_step(model, ddp, opt, coords, feats, labels, dtype, step_idx, shift=Tr
     c = coords
     if shift:  # pl_BaselineTrainer.py:294: random integer shift, same for the whole batch
         g = torch.Generator().manual_seed(1000 + step_idx)
-        sh = (torch.rand(3, generator=g) * 100).to(torch.int32)
+        sh = (torch.rand(3, generator=g) * 100).to(torch.int32).tolist()
         c = coords.clone()
-        c[:, 1:] += sh.to(coords.device)
+        for d in range(3):              # scalar adds: no host->device copy (and its implicit sync) on the step's critical path
+            c[:, 1 + d] += sh[d]
     ddp.zero_grad()
     sinput = ME.SparseTensor(feats.to(dtype), c)                       # coordinate hash + maps live for this step only
     logits, _ = model(sinput)
@@ -242,7 +243,7 @@ def main():
     if world > 1 and args.sync_bn:
         model = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)
     ddp = BucketedDDP(model, bucket_mb=32.0)
-    opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9, dampening=0.1, weight_decay=1e-4)  # lib/solvers.py
+    opt = FlatSGD(ddp, lr=1e-2, momentum=0.9, dampening=0.1, weight_decay=1e-4)  # same rule as lib/solvers.py's SGD
 
     for i in range(args.warmup):
         train_step(model, ddp, opt, coords, feats, labels, dtype, i)

@@ -38,6 +38,7 @@ def grad_slot_view(param):
     n = 1
     for d in shape:
         n *= d
+    param._lgs_engine_written = True   # BucketedDDP need not look for a stray gradient of this parameter again
     return flat[off:off + n].view(shape)
 
 

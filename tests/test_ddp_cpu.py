@@ -111,3 +111,26 @@ def test_sync_batch_norm_matches_full_batch():
     assert torch.allclose(r0[2], bn.running_mean, atol=1e-6) and torch.allclose(r1[3], bn.running_var, atol=1e-6)
     # parameter grads stay local per rank (DDP averages them afterwards): their sum is the full-batch gradient
     assert torch.allclose(r0[4] + r1[4], bn.weight.grad, atol=1e-5)
+
+
+def test_flat_sgd_equals_torch_sgd():
+    """FlatSGD over the gradient buckets == torch.optim.SGD(momentum, dampening, weight_decay) of lib/solvers.py"""
+    from languagegroundedsemseg_amd.ddp import BucketedDDP, FlatSGD
+    torch.manual_seed(0)
+    a, b = Net(), Net()
+    b.load_state_dict(a.state_dict())
+    ddp = BucketedDDP(a, bucket_mb=0.0005)
+    fo = FlatSGD(ddp, lr=0.05, momentum=0.9, dampening=0.1, weight_decay=1e-2)
+    to = torch.optim.SGD(b.parameters(), lr=0.05, momentum=0.9, dampening=0.1, weight_decay=1e-2)
+    x, y = torch.randn(16, 8), torch.randn(16, 4)
+    for step in range(4):
+        ddp.zero_grad()
+        ((a(x) - y) ** 2).mean().backward()
+        ddp.finalize()
+        fo.step()
+        to.zero_grad(set_to_none=True)
+        ((b(x) - y) ** 2).mean().backward()
+        to.step()
+    for (n1, p1), (n2, p2) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.allclose(p1, p2, atol=1e-6), n1
+    assert torch.equal(a.unused.weight, b.unused.weight)   # untouched on both sides

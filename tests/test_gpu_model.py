@@ -126,3 +126,36 @@ def test_bucket_slot_gradients_on_side_stream_equal_plain_autograd():
     assert out[0].keys() == out[1].keys()
     for k in out[0]:
         assert torch.equal(out[0][k], out[1][k]), k
+
+
+def test_clip_pretrain_step_matches_oracle():
+    """BASELINE config[2] shape: representation model (ReLU-free last block, representation_only) + the
+    contrastive CLIP loss on the MFMA contraction, forward + backward, HIP engine vs CPU oracle (fp32)."""
+    from languagegroundedsemseg_amd.losses import ContrastiveLanguageLoss
+    fx = np.load(os.path.join(G, "res16unet14a_forward.npz"))
+    coords, feats = fx["coords"], fx["feats"]
+    rng = np.random.default_rng(1)
+    labels = rng.integers(-1, 200, coords.shape[0]).astype(np.int64)
+    anchors = rng.standard_normal((200, 96)).astype(np.float32)
+    crit = ContrastiveLanguageLoss(num_labels=200, num_negative_samples=3)
+    neg = crit.sample_negatives(torch.from_numpy(labels), generator=torch.Generator().manual_seed(5))
+
+    def run(device):
+        m = deterministic_init(load_model("Res16UNet34CR")(3, 20, Cfg()), 42).to(device).train()
+        m.representation_only(True)
+        x = ME.SparseTensor(torch.from_numpy(feats).to(device), torch.from_numpy(coords).to(device))
+        out = m(x)
+        loss, pos, ngl = crit(out.F.float(), torch.from_numpy(labels).to(device), torch.from_numpy(anchors).to(device),
+                              neg_indices=neg.to(device))
+        loss.backward()
+        return float(loss), out.F.detach().float().cpu().numpy(), m.block8[1].conv2.kernel.grad.detach().cpu().numpy()
+
+    h = run(DEV)
+    prev = ME.set_backend(OracleBackend("c"))
+    try:
+        o = run("cpu")
+    finally:
+        ME.set_backend(prev)
+    assert abs(h[0] - o[0]) < 1e-4
+    assert np.abs(h[1] - o[1]).max() < 1e-3
+    assert np.linalg.norm(h[2] - o[2]) / np.linalg.norm(o[2]) < 2e-3

@@ -13,7 +13,8 @@ coords_np, feats_np, labels_np = make_batch(list(range(B)), voxel=0.02, n_target
 coords, feats, labels = [torch.from_numpy(a).to(dev) for a in (coords_np, feats_np, labels_np)]
 model = bench.build(dev, torch.bfloat16)
 ddp = BucketedDDP(model)
-opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9, dampening=0.1, weight_decay=1e-4)
+from languagegroundedsemseg_amd.ddp import FlatSGD
+opt = FlatSGD(ddp, lr=1e-2, momentum=0.9, dampening=0.1, weight_decay=1e-4)
 for i in range(3):
     bench.train_step(model, ddp, opt, coords, feats, labels, torch.bfloat16, i)
 torch.cuda.synchronize()
