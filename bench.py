@@ -128,16 +128,31 @@ def build(device, dtype, n_classes=200, model_name="Res16UNet34C"):
     return model
 
 
+_DATA_STREAM = {}
+
+
 def train_step(model, ddp, opt, coords, feats, labels, dtype, step_idx, shift=True):
-    c = coords
-    if shift:  # pl_BaselineTrainer.py:294: random integer shift, same for the whole batch
-        g = torch.Generator().manual_seed(1000 + step_idx)
-        sh = (torch.rand(3, generator=g) * 100).to(torch.int32).tolist()
-        c = coords.clone()
-        for d in range(3):              # scalar adds: no host->device copy (and its implicit sync) on the step's critical path
-            c[:, 1 + d] += sh[d]
+    """One fine-tune step.  The input side (the trainer's per-step coordinate shift, the feature cast and the
+    SparseTensor construction = coordinate insert) runs on a separate "data" stream, like a DataLoader's copy
+    stream: the engine builds all coordinate / kernel maps on the manager's own stream, so the maps of step t+1 are
+    constructed while step t's backward is still running on the compute stream."""
+    main = torch.cuda.current_stream()
+    dev = coords.device
+    ds = _DATA_STREAM.setdefault(dev.index, torch.cuda.Stream(device=dev))
+    with torch.cuda.stream(ds):
+        c = coords
+        if shift:  # pl_BaselineTrainer.py:294: random integer shift, same for the whole batch
+            g = torch.Generator().manual_seed(1000 + step_idx)
+            sh = (torch.rand(3, generator=g) * 100).to(torch.int32).tolist()
+            c = coords.clone()
+            for d in range(3):          # scalar adds: no host->device copy (and its implicit sync)
+                c[:, 1 + d] += sh[d]
+        f = feats.to(dtype)
+        sinput = ME.SparseTensor(f, c)                                 # coordinate hash; kernel maps follow lazily
+    main.wait_stream(ds)
+    for t in (c, f, sinput.F):
+        t.record_stream(main)
     ddp.zero_grad()
-    sinput = ME.SparseTensor(feats.to(dtype), c)                       # coordinate hash + maps live for this step only
     logits, _ = model(sinput)
     loss = fused_cross_entropy(logits.F, labels, ignore_index=-1)
     loss.backward()
@@ -199,8 +214,8 @@ def host_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--scenes", type=int, default=8, help="synthetic scenes per GPU per step")
     ap.add_argument("--voxels", type=int, default=150000, help="target voxels per scene (@2cm)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -245,6 +260,9 @@ def main():
     ddp = BucketedDDP(model, bucket_mb=32.0)
     opt = FlatSGD(ddp, lr=1e-2, momentum=0.9, dampening=0.1, weight_decay=1e-4)  # same rule as lib/solvers.py's SGD
 
+    import gc
+    gc.collect()
+    gc.disable()   # no cyclic-GC pauses inside the timed region (tensors are freed by refcount as usual)
     for i in range(args.warmup):
         train_step(model, ddp, opt, coords, feats, labels, dtype, i)
         torch.cuda.synchronize()
@@ -253,8 +271,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks[0].record()
     for i in range(args.steps):
         loss = train_step(model, ddp, opt, coords, feats, labels, dtype, args.warmup + i)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -271,6 +292,7 @@ def main():
     value = total_vox * args.steps / dt
     final_loss = float(loss.item())
     log("timed region done: %.2f ms/step, %.3g voxels/s" % (ms_per_step, value))
+    log("per-step ms (compute-stream events): " + " ".join("%.1f" % marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)))
 
     out = {
         "metric": "voxels/sec fwd+bwd Res16UNet34C @2cm ScanNet200", "value": value, "unit": "voxels/s",

@@ -11,9 +11,14 @@
  * Conventions
  *   - plain C types only; no torch types.  All `const void*` / `void*` buffers are DEVICE
  *     pointers owned by the caller (torch) and only borrowed for the duration of the call.
- *   - every function enqueues on the HIP stream passed in `stream` (a hipStream_t cast to
- *     void*; NULL = default stream) and does not synchronise, except the coordinate-map
- *     builders that must return a row count to the host (documented per function).
+ *   - compute entry points (conv / bn / ce / clip) enqueue on the HIP stream passed in `stream`
+ *     (a hipStream_t cast to void*; NULL = default stream) and never synchronise.
+ *   - coordinate-manager entry points build their maps on the manager's OWN stream; `stream` is the
+ *     caller's stream, used only for ordering (inputs produced on it are waited for, outputs written
+ *     to caller memory are published to it).  lgs_manager_insert / lgs_manager_stride2 /
+ *     lgs_kmap_export synchronise the manager's stream once to return a row count to the host; they
+ *     never wait for the caller's compute backlog.  Every compute call that takes an lgs_kmap
+ *     orders itself after the manager's map work with a stream-side event wait (no host sync).
  *   - return value: 0 = OK, non-zero = error; lgs_last_error() returns the message of the
  *     last failing call on this thread.  The Python side raises RuntimeError with it.
  *   - a manager and everything it owns is not thread-safe; one manager per input batch

@@ -73,6 +73,8 @@ __device__ inline float ld_elem(const bf16_t *p) { return bf16_to_f32(*p); }
 #endif
 
 int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype);
+// order `stream` after the construction of km's manager's maps (they are built on the manager's own stream)
+int kmap_wait(lgs_kmap *km, hipStream_t stream);
 
 }  // namespace lgs
 

@@ -547,6 +547,7 @@ int lgs_conv_forward(lgs_kmap *km, int transposed, const void *in, int cin, cons
   const View &v = transposed ? km->bwd : km->fwd;
   View vv = v; vv.mirror = 0;
   hipStream_t s = (hipStream_t)stream;
+  if (kmap_wait(km, s)) return 1;
   if (dtype == LGS_F32) return conv_gather_op<float>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s);
   if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s);
   LGS_REQUIRE(false, "lgs_conv_forward: unknown dtype");
@@ -559,6 +560,7 @@ int lgs_conv_dgrad(lgs_kmap *km, int transposed, const void *grad_out, int cout,
   const View &v = transposed ? km->fwd : km->bwd;  // the opposite direction of the forward
   View vv = v; vv.mirror = (km->ks == 3) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
+  if (kmap_wait(km, s)) return 1;
   if (dtype == LGS_F32) return conv_gather_op<float>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s);
   if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s);
   LGS_REQUIRE(false, "lgs_conv_dgrad: unknown dtype");

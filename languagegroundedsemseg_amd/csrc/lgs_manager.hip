@@ -322,6 +322,12 @@ using namespace lgs;
 
 struct lgs_manager {
   int device = 0;
+  // All map construction runs on the manager's OWN stream: the host-side row-count syncs then wait for map work
+  // only (never for the compute backlog of the caller's stream), and the maps of step t+1 are built while step t's
+  // backward is still running.  Consumers order themselves after `ev_ready` (lgs::kmap_wait).
+  hipStream_t ms = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_in = nullptr;
+  std::vector<hipStream_t> users;  // caller streams that consumed this manager's arrays (joined before freeing)
   hipStream_t last_stream = nullptr;
   std::vector<CoordMap> maps;
   std::vector<lgs_kmap *> kmaps;
@@ -344,6 +350,26 @@ int dfree_now(lgs_manager *m, void *q, hipStream_t s) {  // temp buffer: release
   for (size_t i = 0; i < m->allocs.size(); ++i)
     if (m->allocs[i] == q) { m->allocs[i] = m->allocs.back(); m->allocs.pop_back(); break; }
   LGS_HIP(hipFreeAsync(q, s));
+  return 0;
+}
+void add_user(lgs_manager *m, hipStream_t caller) {
+  for (hipStream_t u : m->users)
+    if (u == caller) return;
+  m->users.push_back(caller);
+}
+// inputs produced on the caller's stream must be complete before map work that reads them
+int begin_from_caller(lgs_manager *m, hipStream_t caller) {
+  LGS_HIP(hipEventRecord(m->ev_in, caller));
+  LGS_HIP(hipStreamWaitEvent(m->ms, m->ev_in, 0));
+  return 0;
+}
+// publish map work; if `caller` is given it is ordered after it (outputs written into caller-owned memory)
+int publish(lgs_manager *m, hipStream_t caller, bool caller_waits) {
+  LGS_HIP(hipEventRecord(m->ev_ready, m->ms));
+  if (caller_waits) {
+    LGS_HIP(hipStreamWaitEvent(caller, m->ev_ready, 0));
+    add_user(m, caller);
+  }
   return 0;
 }
 inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t > 0 ? (n + t - 1) / t : 1); }
@@ -375,6 +401,15 @@ int scan_incl(lgs_manager *m, const int32_t *in, int32_t *out, int64_t n, hipStr
 
 }  // namespace
 
+namespace lgs {
+int kmap_wait(lgs_kmap *km, hipStream_t stream) {
+  lgs_manager *m = km->mgr;
+  LGS_HIP(hipStreamWaitEvent(stream, m->ev_ready, 0));
+  add_user(m, stream);
+  return 0;
+}
+}  // namespace lgs
+
 extern "C" {
 
 int lgs_abi_version(void) { return LGS_ABI_VERSION; }
@@ -389,6 +424,14 @@ int lgs_manager_create(int device, lgs_manager **out) {
   LGS_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr));
   lgs_manager *m = new lgs_manager();
   m->device = device;
+  // one map stream per device for the whole process (creating / destroying a stream per batch costs host time and
+  // can block): managers of consecutive steps simply queue behind each other on it
+  static hipStream_t g_map_stream[64] = {nullptr};
+  LGS_REQUIRE(device >= 0 && device < 64, "lgs_manager_create: device index out of range");
+  if (!g_map_stream[device]) LGS_HIP(hipStreamCreateWithFlags(&g_map_stream[device], hipStreamNonBlocking));
+  m->ms = g_map_stream[device];
+  LGS_HIP(hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming));
+  LGS_HIP(hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming));
   *out = m;
   return 0;
 }
@@ -396,8 +439,14 @@ int lgs_manager_create(int device, lgs_manager **out) {
 int lgs_manager_destroy(lgs_manager *m) {
   if (!m) return 0;
   (void)hipSetDevice(m->device);
-  for (void *p : m->allocs) (void)hipFreeAsync(p, m->last_stream);
+  // every stream that read the maps must be done with them before the (stream-ordered) frees
+  for (hipStream_t u : m->users) {
+    if (hipEventRecord(m->ev_in, u) == hipSuccess) (void)hipStreamWaitEvent(m->ms, m->ev_in, 0);
+  }
+  for (void *p : m->allocs) (void)hipFreeAsync(p, m->ms);
   for (lgs_kmap *k : m->kmaps) delete k;
+  (void)hipEventDestroy(m->ev_ready);
+  (void)hipEventDestroy(m->ev_in);
   delete m;
   return 0;
 }
@@ -407,9 +456,11 @@ int lgs_manager_insert(lgs_manager *m, const int32_t *coords, int64_t n, int64_t
   LGS_REQUIRE(m && key && n_unique, "lgs_manager_insert: null argument");
   LGS_REQUIRE(m->maps.empty(), "lgs_manager_insert: manager already holds a stride-1 map");
   LGS_REQUIRE(n >= 0 && n < (1ll << 31) - 1024, "lgs_manager_insert: row count out of range");
-  hipStream_t s = (hipStream_t)stream;
+  hipStream_t caller = (hipStream_t)stream;
+  hipStream_t s = m->ms;
   LGS_HIP(hipSetDevice(m->device));
-  m->last_stream = s;
+  m->last_stream = caller;
+  if (begin_from_caller(m, caller)) return 1;   // `coords` was produced on the caller's stream
   CoordMap cm;
   if (n == 0) {
     cm.n = 0; cm.n_pad = 0;
@@ -457,15 +508,15 @@ int lgs_manager_insert(lgs_manager *m, const int32_t *coords, int64_t n, int64_t
     return 1;
   m->maps.push_back(cm);
   *key = 0; *n_unique = nu;
-  return 0;
+  return publish(m, caller, true);   // unique_index / inverse live in caller memory; `coords` may be reused after this
 }
 
 int lgs_manager_stride2(lgs_manager *m, int in_key, void *stream, int *out_key, int64_t *n_out) {
   LGS_REQUIRE(m && out_key && n_out, "lgs_manager_stride2: null argument");
   LGS_REQUIRE(in_key >= 0 && in_key < (int)m->maps.size(), "lgs_manager_stride2: bad key");
-  hipStream_t s = (hipStream_t)stream;
+  hipStream_t s = m->ms;
+  (void)stream;
   LGS_HIP(hipSetDevice(m->device));
-  m->last_stream = s;
   if (m->maps[in_key].coarse_key >= 0) {
     *out_key = m->maps[in_key].coarse_key; *n_out = m->maps[*out_key].n;
     return 0;
@@ -502,7 +553,7 @@ int lgs_manager_stride2(lgs_manager *m, int in_key, void *stream, int *out_key, 
   int ck = (int)m->maps.size() - 1;
   m->maps[in_key].coarse_key = ck;
   *out_key = ck; *n_out = nc;
-  return 0;
+  return publish(m, nullptr, false);
 }
 
 int lgs_manager_parent_of(lgs_manager *m, int key, int *fine_key) {
@@ -522,9 +573,8 @@ int lgs_manager_get_coords(lgs_manager *m, int key, int32_t *dst, void *stream) 
   LGS_REQUIRE(m && key >= 0 && key < (int)m->maps.size(), "lgs_manager_get_coords: bad key");
   const CoordMap &cm = m->maps[key];
   if (cm.n > 0)
-    LGS_HIP(hipMemcpyAsync(dst, cm.coords, sizeof(int32_t) * 4 * (size_t)cm.n, hipMemcpyDeviceToDevice,
-                           (hipStream_t)stream));
-  return 0;
+    LGS_HIP(hipMemcpyAsync(dst, cm.coords, sizeof(int32_t) * 4 * (size_t)cm.n, hipMemcpyDeviceToDevice, m->ms));
+  return publish(m, (hipStream_t)stream, true);
 }
 
 int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void *stream, lgs_kmap **out) {
@@ -533,9 +583,9 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
   LGS_REQUIRE(in_key >= 0 && in_key < nm && out_key >= 0 && out_key < nm, "lgs_manager_kernel_map: bad key");
   for (lgs_kmap *k : m->kmaps)
     if (k->in_key == in_key && k->out_key == out_key && k->ks == ks) { *out = k; return 0; }
-  hipStream_t s = (hipStream_t)stream;
+  hipStream_t s = m->ms;
+  (void)stream;
   LGS_HIP(hipSetDevice(m->device));
-  m->last_stream = s;
   lgs_kmap *km = new lgs_kmap();
   km->mgr = m; km->in_key = in_key; km->out_key = out_key; km->ks = ks;
   CoordMap &ci = m->maps[in_key];
@@ -627,14 +677,16 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
   }
   m->kmaps.push_back(km);
   *out = km;
-  return 0;
+  return publish(m, nullptr, false);
 }
 
 int lgs_kmap_export(lgs_kmap *km, int32_t *ek, int32_t *ein, int32_t *eout, void *stream, int64_t *mcount) {
   LGS_REQUIRE(km && mcount, "lgs_kmap_export: null argument");
-  hipStream_t s = (hipStream_t)stream;
   lgs_manager *m = km->mgr;
+  hipStream_t caller = (hipStream_t)stream;
+  hipStream_t s = m->ms;
   LGS_HIP(hipSetDevice(m->device));
+  if (begin_from_caller(m, caller)) return 1;   // the output buffers were allocated on the caller's stream
   const View &v = km->fwd;
   int32_t *cnt;
   LGS_HIP(hipMallocAsync((void **)&cnt, sizeof(int32_t), s));
@@ -648,7 +700,7 @@ int lgs_kmap_export(lgs_kmap *km, int32_t *ek, int32_t *ein, int32_t *eout, void
   LGS_HIP(hipStreamSynchronize(s));
   LGS_HIP(hipFreeAsync(cnt, s));
   *mcount = h;
-  return 0;
+  return publish(m, caller, true);
 }
 
 }  // extern "C"

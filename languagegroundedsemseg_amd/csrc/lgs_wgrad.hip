@@ -540,6 +540,7 @@ int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const 
   const View &v = transposed ? km->bwd : km->fwd;  // same view as the forward
   View vv = v; vv.mirror = 0;
   hipStream_t s = (hipStream_t)stream;
+  if (kmap_wait(km, s)) return 1;
   if (vv.n_pad == 0) {
     LGS_HIP(hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)km->K * cin * cout, s));
     return 0;
