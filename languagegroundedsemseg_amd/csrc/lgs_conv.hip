@@ -20,6 +20,8 @@
 // both operands so every lane's load is 16 contiguous bytes.
 #include "lgs_common.h"
 
+#include <stdlib.h>
+
 namespace lgs {
 
 
@@ -371,8 +373,8 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
 
 // ------------------------------------------------------------------------------------ host side
 
-// Tile choice: 256 positions x up to 128 channels when the map fills the chip, otherwise 64-position x 64-channel
-// tiles (coarse levels: few rows, many channels -- parallelism matters more than weight re-reads).
+// Tile choice: 256 positions x up to 128 channels when the map fills the chip, otherwise 128-position x 64-channel
+// tiles, one 32 x 64 block per wave (coarse levels: few rows, many channels).
 // SC = chunks per weight slab (sized to ~6-8 staging registers per thread), D = depth of the gather ring.
 struct GatherCfg { int id, sc, wb; };
 template <typename T>
@@ -386,10 +388,17 @@ GatherCfg gather_cfg(const View &v, int nb_total) {
     if (nb_total == 1) return {0, kF32 ? 2 : 4, 1};
     if (nb_total == 2) return {1, kF32 ? 2 : 4, 2};
     if (nb_total == 3 || (nb_total % 3 == 0 && nb_total % 4 != 0)) return {2, kF32 ? 2 : 4, 3};
+    if (!kF32) return {7, 2, 4};   // bf16: 128-position tiles, 4 column blocks per wave at 3 waves/SIMD
     return {3, kF32 ? 1 : 2, 4};
   }
   if (nb_total == 1) return {4, kF32 ? 2 : 4, 1};
-  return {5, kF32 ? 2 : 4, 2};
+  static const int small_override = getenv("LGS_SMALL_CFG") ? atoi(getenv("LGS_SMALL_CFG")) : 0;  // tuning knob
+  if (!kF32 && small_override == 5) return {5, 4, 2};
+  if (!kF32 && small_override == 9) return {9, 4, 4};
+  if (!kF32 && small_override == 10) return {10, 4, 2};
+  if (!kF32 && small_override == 11) return {11, 4, 4};
+  if (!kF32) return {8, 4, 2};   // measured best on the L3/L4 shapes (tools/microbench.py coarse): 128 positions x 64 channels
+  return {5, 2, 2};
 }
 
 template <typename T>
@@ -412,6 +421,11 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
     case 3: LGS_LAUNCH(2, 4, 4, 1, (kF32 ? 1 : 2), (kF32 ? 2 : 3)); break;
     case 4: LGS_LAUNCH(1, 1, 2, 1, (kF32 ? 2 : 4), (kF32 ? 4 : 8)); break;
     case 6: LGS_LAUNCH(1, 7, 4, 1, (kF32 ? 1 : 2), (kF32 ? 3 : 4)); break;
+    case 7: LGS_LAUNCH(1, 4, 4, 1, 2, 4); break;
+    case 8: LGS_LAUNCH(1, 2, 4, 1, 4, 6); break;
+    case 9: LGS_LAUNCH(1, 2, 2, 2, 4, 6); break;
+    case 10: LGS_LAUNCH(1, 2, 2, 1, 4, 6); break;
+    case 11: LGS_LAUNCH(1, 4, 2, 1, 4, 6); break;
     default: LGS_LAUNCH(1, 1, 2, 2, (kF32 ? 2 : 4), (kF32 ? 4 : 8)); break;
   }
 #undef LGS_LAUNCH

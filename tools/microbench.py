@@ -88,7 +88,33 @@ def clip():
                 n, c, str(dtype).split(".")[1], ms, flop / ms / 1e9, byts / ms / 1e9))
 
 
+def coarse():
+    """coarse-level layer shapes (L2..L4 of an 8-scene batch)"""
+    coords, feats, labels = make_batch(list(range(8)), n_target=150000, shift_seed=0)
+    c = torch.from_numpy(coords).to(DEV)
+    x = ME.SparseTensor(torch.zeros(coords.shape[0], 3, device=DEV), c)
+    m = x.coordinate_manager
+    k = x.coordinate_map_key
+    for lvl in range(1, 5):
+        k = m.stride(k, 2)
+        n = m.size(k)
+        km = m.kernel_map_handle(k, k, 3)
+        M = km.export()[0].shape[0]
+        for cin, cout in {1: [(32, 32), (96, 96)], 2: [(64, 64), (128, 128)], 3: [(128, 128), (256, 256)], 4: [(256, 256)]}[lvl]:
+            f = torch.randn(n, cin, device=DEV).bfloat16()
+            g = torch.randn(n, cout, device=DEV).bfloat16()
+            w = torch.randn(27, cin, cout, device=DEV) * 0.05
+            tf = timeit(lambda: km.conv_forward(f, w, None, False), 10, 3)
+            tw = timeit(lambda: km.conv_wgrad(f, g, False), 10, 3)
+            flop = 2.0 * M * cin * cout
+            print("L%d rows %7d pairs %8d  %3d->%3d  fwd %.3f ms (%.0f TF)  wgrad %.3f ms (%.0f TF)" % (
+                lvl, n, M, cin, cout, tf, flop / tf / 1e9, tw, flop / tw / 1e9))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "coarse":
+        coarse()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "clip":
         clip()
         sys.exit(0)
