@@ -86,7 +86,21 @@ __global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, cons
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(r0 + rows_per_block, n);
   if (active) {
-    for (int64_t r = r0 + rl; r < r1; r += RL) {
+    int64_t r = r0 + rl;
+    if (MODE == 0) {
+      // forward statistics: two independent row loads in flight per thread
+      for (; r + RL < r1; r += 2 * RL) {
+        float xa[W], xb[W];
+        Vec<T>::load(x + r * c + cg * W, xa);
+        Vec<T>::load(x + (r + RL) * c + cg * W, xb);
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+          const float da = xa[i] - mean[i], db = xb[i] - mean[i];
+          s0[i] += da + db; s1[i] += da * da + db * db;
+        }
+      }
+    }
+    for (; r < r1; r += RL) {
       float xv[W];
       Vec<T>::load(x + r * c + cg * W, xv);
       if (MODE == 0) {
@@ -193,26 +207,49 @@ __global__ __launch_bounds__(256) void k_fold_bwd(const float *__restrict__ scra
 }
 
 // y = relu?( (x - mean) * invstd * gamma + beta (+ residual) )
+// A thread owns ONE channel group (its per-channel constants live in registers) and walks rows: with
+// G = C / W groups, thread t handles group t % G of rows t / G, t / G + R, ...  (R = rows per sweep of the grid).
+// Two independent 16-byte loads are in flight per operand per thread.
 template <typename T>
 __global__ __launch_bounds__(kNT) void k_bn_apply(const T *__restrict__ x, const T *__restrict__ res, int64_t n, int c,
                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
                                                   const float *__restrict__ stats, int relu, T *__restrict__ y) {
   constexpr int W = Vec<T>::W;
-  const int64_t total = n * (int64_t)(c / W);
-  for (int64_t i = (int64_t)blockIdx.x * kNT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kNT) {
-    const int cg = (int)(i % (c / W));
-    float xv[W], rv[W];
-    Vec<T>::load(x + i * W, xv);
-    if (res) Vec<T>::load(res + i * W, rv);
+  const int G = c / W, RL = kNT / G;
+  const int cg = threadIdx.x % G, rl = threadIdx.x / G;
+  if (rl >= RL) return;
+  float sc[W], mean[W], bt[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    const int ch = cg * W + k;
+    sc[k] = stats[c + ch] * gamma[ch];
+    mean[k] = stats[ch];
+    bt[k] = beta[ch];
+  }
+  const int64_t stride = (int64_t)gridDim.x * RL;
+  for (int64_t r = (int64_t)blockIdx.x * RL + rl; r < n; r += 2 * stride) {
+    const int64_t r2 = r + stride;
+    const bool two = r2 < n;
+    float xa[W], xb[W], ra[W], rb[W];
+    Vec<T>::load(x + r * c + cg * W, xa);
+    if (two) Vec<T>::load(x + r2 * c + cg * W, xb);
+    if (res) { Vec<T>::load(res + r * c + cg * W, ra); if (two) Vec<T>::load(res + r2 * c + cg * W, rb); }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-      const int ch = cg * W + k;
-      float sc = stats[c + ch] * gamma[ch];
-      float o = (xv[k] - stats[ch]) * sc + beta[ch];
-      if (res) o += rv[k];
-      xv[k] = (relu && o < 0.f) ? 0.f : o;
+      float o = (xa[k] - mean[k]) * sc[k] + bt[k];   // keep this exact expression: the backward recomputes the ReLU mask from it
+      if (res) o += ra[k];
+      xa[k] = (relu && o < 0.f) ? 0.f : o;
     }
-    Vec<T>::store(y + i * W, xv);
+    Vec<T>::store(y + r * c + cg * W, xa);
+    if (two) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        float o = (xb[k] - mean[k]) * sc[k] + bt[k];
+        if (res) o += rb[k];
+        xb[k] = (relu && o < 0.f) ? 0.f : o;
+      }
+      Vec<T>::store(y + r2 * c + cg * W, xb);
+    }
   }
 }
 
@@ -224,33 +261,41 @@ __global__ __launch_bounds__(kNT) void k_bn_bwd_apply(const T *__restrict__ x, c
                                                       const float *__restrict__ stats, const float *__restrict__ sums,
                                                       float inv_n, int relu, T *__restrict__ dx, T *__restrict__ dres) {
   constexpr int W = Vec<T>::W;
-  const int64_t total = n * (int64_t)(c / W);
-  for (int64_t i = (int64_t)blockIdx.x * kNT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kNT) {
-    const int cg = (int)(i % (c / W));
+  const int G = c / W, RL = kNT / G;
+  const int cg = threadIdx.x % G, rl = threadIdx.x / G;
+  if (rl >= RL) return;
+  float mean[W], istd[W], sc[W], bt[W], gi[W], m1[W], m2[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    const int ch = cg * W + k;
+    mean[k] = stats[ch]; istd[k] = stats[c + ch];
+    sc[k] = istd[k] * (relu == 2 ? gamma[ch] : 0.f);
+    bt[k] = relu == 2 ? beta[ch] : 0.f;
+    gi[k] = gamma[ch] * istd[k];
+    m1[k] = sums[ch] * inv_n; m2[k] = sums[c + ch] * inv_n;
+  }
+  const int64_t stride = (int64_t)gridDim.x * RL;
+  for (int64_t r = (int64_t)blockIdx.x * RL + rl; r < n; r += stride) {
+    const int64_t o = r * c + cg * W;
     float xv[W], gv[W];
-    Vec<T>::load(x + i * W, xv);
-    Vec<T>::load(dy + i * W, gv);
+    Vec<T>::load(x + o, xv);
+    Vec<T>::load(dy + o, gv);
     if (relu == 1) {
       float yv[W];
-      Vec<T>::load(y + i * W, yv);
+      Vec<T>::load(y + o, yv);
 #pragma unroll
       for (int k = 0; k < W; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
     } else if (relu == 2) {
 #pragma unroll
-      for (int k = 0; k < W; ++k) {
-        const int ch = cg * W + k;
-        gv[k] = ((xv[k] - stats[ch]) * (stats[c + ch] * gamma[ch]) + beta[ch]) > 0.f ? gv[k] : 0.f;  // same expression as k_bn_apply
-      }
+      for (int k = 0; k < W; ++k) gv[k] = ((xv[k] - mean[k]) * sc[k] + bt[k]) > 0.f ? gv[k] : 0.f;  // same expression as k_bn_apply
     }
-    if (dres) Vec<T>::store(dres + i * W, gv);
+    if (dres) Vec<T>::store(dres + o, gv);
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-      const int ch = cg * W + k;
-      const float istd = stats[c + ch];
-      const float xh = (xv[k] - stats[ch]) * istd;
-      xv[k] = gamma[ch] * istd * (gv[k] - sums[ch] * inv_n - xh * sums[c + ch] * inv_n);
+      const float xh = (xv[k] - mean[k]) * istd[k];
+      xv[k] = gi[k] * (gv[k] - m1[k] - xh * m2[k]);
     }
-    Vec<T>::store(dx + i * W, xv);
+    Vec<T>::store(dx + o, xv);
   }
 }
 
@@ -326,7 +371,7 @@ template <typename T>
 int bn_apply_t(const void *xv, int64_t n, int c, const float *gamma, const float *beta, const float *stats, const void *res,
                int relu, void *yv, hipStream_t s) {
   constexpr int W = Vec<T>::W;
-  LGS_REQUIRE(c % W == 0, "lgs_bn_apply: channel count unsupported");
+  LGS_REQUIRE(c % W == 0 && c / W <= kNT, "lgs_bn_apply: channel count unsupported");
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
@@ -355,7 +400,7 @@ template <typename T>
 int bn_bwd_apply_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *gamma, const float *beta,
                    const float *stats, const float *sums, float inv_n_total, int relu, void *dxv, void *dresv, hipStream_t s) {
   constexpr int W = Vec<T>::W;
-  LGS_REQUIRE(c % W == 0, "lgs_bn_backward_apply: channel count unsupported");
+  LGS_REQUIRE(c % W == 0 && c / W <= kNT, "lgs_bn_backward_apply: channel count unsupported");
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
