@@ -236,6 +236,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--sync-bn", type=int, default=1, help="convert to MinkowskiSyncBatchNorm when gpus > 1 (main.py:122)")
+    ap.add_argument("--compute-priority", type=int, default=0, help="run the compute stream at this HIP stream priority "
+                                                                     "(-1 = high: dgrad/BN chain ahead of the side-stream wgrad)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
                                                        "N>1 code path with several ranks on ONE GPU)")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (single-GPU dry run of the N>1 path)")
@@ -273,6 +275,10 @@ def main():
     ddp = BucketedDDP(model, bucket_mb=32.0)
     opt = FlatSGD(ddp, lr=1e-2, momentum=0.9, dampening=0.1, weight_decay=1e-4)  # same rule as lib/solvers.py's SGD
 
+    if args.compute_priority != 0:
+        hp = torch.cuda.Stream(device=device, priority=args.compute_priority)
+        hp.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hp)
     import gc
     gc.collect()
     gc.disable()   # no cyclic-GC pauses inside the timed region (tensors are freed by refcount as usual)

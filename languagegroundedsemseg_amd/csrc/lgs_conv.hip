@@ -129,7 +129,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
                                                              const float *__restrict__ bias,
                                                              float *__restrict__ out_f32,
                                                              const float *__restrict__ row_scale,
-                                                             const u32x4 *__restrict__ zpage) {
+                                                             unsigned in_bytes, unsigned w_bytes) {
   // SC = 32-channel chunks per weight SLAB: the weights of (offset, slab) are staged in LDS once per workgroup
   // and one barrier separates slabs, while the gathered feature fragments stream chunk by chunk through a
   // D-deep register ring (loads issued D-1 chunks = several hundred MFMA cycles ahead of their use) that runs
@@ -207,19 +207,26 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     }
     return true;
   };
+  // Gathers and weight fetches are BUFFER loads (scalar descriptor + one 32-bit lane offset): a missing neighbour or
+  // a padded channel simply gets an out-of-range offset, for which the hardware returns zeros -- no branches, no
+  // 64-bit address arithmetic, no selects (the gather loop was spending ~10 VALU instructions per MFMA on those).
+  constexpr unsigned kOOB = 0xfffff000u;   // > any descriptor size accepted by the host wrapper, no wrap with small immediates
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(in), 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(wp), 0, (int)w_bytes, 0x00020000);
+  const unsigned row_bytes = (unsigned)cin_real * (unsigned)sizeof(T);
+  const bool ch_tail = (cin_real & 31) != 0;   // kernel-uniform: only then a chunk can run past the row
   auto issue = [&](u32x4 (&F)[RB][LD], uint32_t &act) __attribute__((always_inline)) {
     act = 0;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       const bool ok = idx_i[rb] >= 0;
       if (__ballot(ok)) act |= 1u << rb;
-      const T *src = in + (int64_t)(ok ? idx_i[rb] : 0) * cin_real + ichunk * 32 + h * 16;
+      const unsigned base = ok ? (unsigned)idx_i[rb] * row_bytes + (unsigned)(ichunk * 32 + h * 16) * (unsigned)sizeof(T) : kOOB;
 #pragma unroll
       for (int t = 0; t < LD; ++t) {
-        const int ch = ichunk * 32 + h * 16 + t * EPL;
-        // branch-free: every lane loads 16 bytes, either its row piece or the zero page
-        const u32x4 *p = (ok && ch + EPL <= cin_real) ? reinterpret_cast<const u32x4 *>(src + t * EPL) : zpage;
-        F[rb][t] = *p;
+        unsigned off = base + t * 16;
+        if (ch_tail && (ichunk * 32 + h * 16 + t * EPL + EPL > cin_real)) off = kOOB;
+        F[rb][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
       }
     }
   };
@@ -235,17 +242,21 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     wslab = 0;
     return true;
   };
-  // The packed weights are padded to whole slabs (ncp chunks) and whole cout tiles (nbp blocks), zero filled,
-  // so a slab is fetched with unconditional, fully coalesced 16-byte loads.
+  // The packed weights are padded to whole slabs (ncp chunks) and whole cout tiles (nbp blocks), zero filled, so a
+  // slab is fetched with unconditional, fully coalesced 16-byte buffer loads: per-thread offsets are loop invariant,
+  // the slab's base goes in the scalar offset.
+  unsigned woff[WR];
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    const int e = min(tid + i * NT, SLAB - 1);
+    const int cw = e / WCH, ee = e - cw * WCH;
+    woff[i] = (unsigned)(cw * nbp * (LD * 64) + ee) * 16u;
+  }
   auto wissue = [&](u32x4 (&wreg)[WR]) __attribute__((always_inline)) {
     const int kw = v.KS > 1 ? wslot : kw_single;  // 3^3 dgrad mirroring (K-1-k) is folded into the weight packing
-    const u32x4 *base = wp + (((int64_t)kw * ncp + wslab * SC) * nbp + nb_wg) * (LD * 64);
+    const unsigned sbase = (unsigned)((((int64_t)kw * ncp + wslab * SC) * nbp + nb_wg) * (LD * 64) * 16);
 #pragma unroll
-    for (int i = 0; i < WR; ++i) {
-      const int e = min(tid + i * NT, SLAB - 1);
-      const int cc = e / WCH, ee = e - cc * WCH;
-      wreg[i] = base[(int64_t)cc * nbp * (LD * 64) + ee];
-    }
+    for (int i = 0; i < WR; ++i) wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[i], sbase, 0);
   };
   auto wstage = [&](int buf, const u32x4 (&wreg)[WR]) __attribute__((always_inline)) {
 #pragma unroll
@@ -403,16 +414,23 @@ GatherCfg gather_cfg(const View &v, int nb_total) {
 
 template <typename T>
 int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real, int nc, const uint4 *wp, const uint4 *zpage,
-                  int nb_total, int ncp, int nbp, T *out, int cout_real, const float *bias, hipStream_t s,
+                  int nb_total, int ncp, int nbp, int K, T *out, int cout_real, const float *bias, hipStream_t s,
                   float *out_f32 = nullptr, const float *row_scale = nullptr) {
   if (v.n_pad == 0) return 0;
+  (void)zpage;
+  constexpr int LDc = Tr<T>::LD;
+  const uint64_t in_bytes64 = (uint64_t)v.n_in * (uint64_t)cin_real * sizeof(T);
+  const uint64_t w_bytes64 = (uint64_t)K * ncp * nbp * LDc * 64 * 16;
+  LGS_REQUIRE(in_bytes64 < 0xfffff000ull && w_bytes64 < 0xfffff000ull,
+              "sparse conv: a feature or weight tensor of 4 GiB or more is beyond the 32-bit buffer-descriptor path");
+  const unsigned in_bytes = (unsigned)in_bytes64, w_bytes = (unsigned)w_bytes64;
   constexpr bool kF32 = (sizeof(T) == 4);
 #define LGS_LAUNCH(RB, NCB, WM, WN, SC, D)                                                                        \
   do {                                                                                                            \
     dim3 grid((unsigned)(v.n_pad / (WM * RB * 32)), (unsigned)((nb_total + WN * NCB - 1) / (WN * NCB)));         \
     hipLaunchKernelGGL((k_conv_gather<T, RB, NCB, WM, WN, SC, D>), grid, dim3(WM *WN * 64), 0, s, v, in, cin_real, nc,    \
                        reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, out, cout_real, bias, out_f32, row_scale, \
-                       reinterpret_cast<const u32x4 *>(zpage));                      \
+                       in_bytes, w_bytes);                      \
   } while (0)
   switch (cfg.id) {
     case 0: LGS_LAUNCH(2, 1, 4, 1, (kF32 ? 2 : 4), (kF32 ? 3 : 4)); break;
@@ -476,7 +494,7 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
   hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, weight, K, cin_w, cout_w, transposed_w,
                      v.mirror, g_real, w_o_real, ncp, nbp, wp, zpage);
   LGS_HIP(hipGetLastError());
-  return launch_gather<T>(v, cfg, in, g_stride, nc, wp, zpage, nb_total, ncp, nbp, reinterpret_cast<T *>(out_v), o_real, bias, s);
+  return launch_gather<T>(v, cfg, in, g_stride, nc, wp, zpage, nb_total, ncp, nbp, K, reinterpret_cast<T *>(out_v), o_real, bias, s);
 }
 
 // ------------------------------------------------------------------------------------ CLIP contraction
@@ -533,7 +551,7 @@ int clip_similarity_t(const void *feat, int64_t n, int c, const float *anchors, 
   hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, tn, 1, na, c, 1, 0, c, na, ncp, nbp, wp, zpage);
   hipLaunchKernelGGL((k_row_invnorm<T>), (unsigned)((n * 64 + 255) / 256), 256, 0, s, f, n, c, inv);
   LGS_HIP(hipGetLastError());
-  return launch_gather<T>(v, cfg, f, c, nc, wp, zpage, nb_total, ncp, nbp, (T *)nullptr, na, nullptr, s, sim, inv);
+  return launch_gather<T>(v, cfg, f, c, nc, wp, zpage, nb_total, ncp, nbp, 1, (T *)nullptr, na, nullptr, s, sim, inv);
 }
 
 }  // namespace lgs
