@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(View v, const bf16_t *__rest
                                                     const bf16_t *__restrict__ gout, int cout_real, int cin_pad,
                                                     int cout_pad, int64_t range, int kpw, int n_ci_tasks, int n_tasks,
                                                     int n_ranges, float *__restrict__ partial,
-                                                    const u32x4 *__restrict__ zpage) {
+                                                    unsigned in_bytes, unsigned gout_bytes) {
   constexpr int CA = 32 * NCI, CG = 32 * NCO;
   constexpr int SA = tile_stride(CA), SG = tile_stride(CG);
   constexpr int LA = (16 * CA / 8 + 63) / 64, LG = (16 * CG / 8 + 63) / 64;  // 16-byte loads per lane per group
@@ -197,25 +197,39 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(View v, const bf16_t *__rest
   const int tr_col = 16 * (g16 & 1) + 4 * (i16 & 3);
 
   u32x4 ra[D][LA], rg[D][LG];
-  // every lane issues exactly LA + LG 16-byte loads per group, from its row piece or from the zero page
+  // every lane issues exactly LA + LG 16-byte BUFFER loads per group; a missing row or a padded channel gets an
+  // out-of-range offset and the hardware returns zeros (no branch, no 64-bit address math, no zero page)
+  constexpr unsigned kOOB = 0xfffff000u;
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(in), 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(gout), 0, (int)gout_bytes, 0x00020000);
+  const unsigned arow_b = (unsigned)cin_real * 2u, grow_b = (unsigned)cout_real * 2u;
+  unsigned a_ch[LA], g_ch[LG];   // loop-invariant per-lane channel byte offsets (kOOB when the piece is padding)
+#pragma unroll
+  for (int q = 0; q < LA; ++q) {
+    const int id = q * 64 + lane;
+    const int ch = (id % (CA / 8)) * 8;
+    a_ch[q] = (id < 16 * (CA / 8) && ci0 + ch + 8 <= cin_real) ? (unsigned)(ci0 + ch) * 2u : kOOB;
+  }
+#pragma unroll
+  for (int q = 0; q < LG; ++q) {
+    const int id = q * 64 + lane;
+    const int ch = (id % (CG / 8)) * 8;
+    g_ch[q] = (id < 16 * (CG / 8) && co0 + ch + 8 <= cout_real) ? (unsigned)(co0 + ch) * 2u : kOOB;
+  }
   auto issue = [&](int g, u32x4 (&xa)[LA], u32x4 (&xg2)[LG]) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < LA; ++q) {
-      const int id = q * 64 + lane;
-      const int row = (id / (CA / 8)) & 15, ch = (id % (CA / 8)) * 8;
+      const int row = ((q * 64 + lane) / (CA / 8)) & 15;
       const int32_t r = q_in[g * 16 + row];
-      const bool ok = id < 16 * (CA / 8) && r >= 0 && ci0 + ch + 8 <= cin_real;
-      const u32x4 *p = ok ? reinterpret_cast<const u32x4 *>(in + (int64_t)r * cin_real + ci0 + ch) : zpage;
-      xa[q] = *p;
+      const unsigned off = (r >= 0 && a_ch[q] != kOOB) ? (unsigned)r * arow_b + a_ch[q] : kOOB;
+      xa[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, off, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < LG; ++q) {
-      const int id = q * 64 + lane;
-      const int row = (id / (CG / 8)) & 15, ch = (id % (CG / 8)) * 8;
+      const int row = ((q * 64 + lane) / (CG / 8)) & 15;
       const int32_t r = q_out[g * 16 + row];
-      const bool ok = id < 16 * (CG / 8) && r >= 0 && co0 + ch + 8 <= cout_real;
-      const u32x4 *p = ok ? reinterpret_cast<const u32x4 *>(gout + (int64_t)r * cout_real + co0 + ch) : zpage;
-      xg2[q] = *p;
+      const unsigned off = (r >= 0 && g_ch[q] != kOOB) ? (unsigned)r * grow_b + g_ch[q] : kOOB;
+      xg2[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, off, 0, 0);
     }
   };
   auto consume = [&](const u32x4 (&xa)[LA], const u32x4 (&xg2)[LG]) __attribute__((always_inline)) {
@@ -450,8 +464,11 @@ int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype) 
 
 template <int NCI, int NCO>
 int launch_wgrad_bf16(const View &v, const WgradPlan &p, const bf16_t *in, int cin, const bf16_t *go, int cout,
-                      float *partial, const void *zpage, hipStream_t s) {
+                      float *partial, hipStream_t s) {
   constexpr int CA = 32 * NCI, CG = 32 * NCO;
+  const uint64_t in_b = (uint64_t)v.n_in * cin * 2, go_b = (uint64_t)v.n_out * cout * 2;
+  LGS_REQUIRE(in_b < 0xfffff000ull && go_b < 0xfffff000ull,
+              "bf16 wgrad: a feature tensor of 4 GiB or more is beyond the 32-bit buffer-descriptor path");
   constexpr int D = (NCI * NCO >= 9) ? 3 : 4;
   constexpr int WAVE_BYTES = 2 * kQ * 4 + 16 * tile_stride(CA) + 16 * tile_stride(CG);
   static_assert(4 * WAVE_BYTES >= NCI * NCO * 16 * 64 * 4, "staging LDS must hold one accumulator tile");
@@ -460,7 +477,7 @@ int launch_wgrad_bf16(const View &v, const WgradPlan &p, const bf16_t *in, int c
   const int KG = (v.K + p.kpw - 1) / p.kpw;
   const unsigned nblocks = (unsigned)(((n_ranges + 7) / 8) * 8 * KG * n_tasks);
   hipLaunchKernelGGL((k_wgrad_bf16<NCI, NCO, D>), dim3(nblocks), 256, 4 * WAVE_BYTES, s, v, in, cin, go, cout, p.cin_pad,
-                     p.cout_pad, p.span, p.kpw, p.n_ci_tasks, n_tasks, n_ranges, partial, reinterpret_cast<const u32x4 *>(zpage));
+                     p.cout_pad, p.span, p.kpw, p.n_ci_tasks, n_tasks, n_ranges, partial, (unsigned)in_b, (unsigned)go_b);
   return 0;
 }
 
@@ -477,7 +494,6 @@ int conv_wgrad_bf16(const View &v, const void *in_v, int cin, const void *gout_v
   LGS_REQUIRE(cout % 8 == 0, "bf16 wgrad: output channel count must be a multiple of 8 (16-byte rows)");
   WgradPlan p = wgrad_plan(v, cin, cout, LGS_BF16);
   char *wsb = reinterpret_cast<char *>(workspace);
-  LGS_HIP(hipMemsetAsync(wsb, 0, kWgZero, s));
   float *partial = reinterpret_cast<float *>(wsb + kWgZero);
   const bf16_t *in = reinterpret_cast<const bf16_t *>(in_v), *go = reinterpret_cast<const bf16_t *>(gout_v);
   const int cin_real = cin;
@@ -490,7 +506,7 @@ int conv_wgrad_bf16(const View &v, const void *in_v, int cin, const void *gout_v
     cin = c8;
   }
   // every (slot, k, ci, co) element of `partial` is written exactly once by the wave that owns it
-#define LGS_WG(A, B) if (p.nci == A && p.nco == B) { launch_wgrad_bf16<A, B>(v, p, in, cin, go, cout, partial, wsb, s); } else
+#define LGS_WG(A, B) if (p.nci == A && p.nco == B) { launch_wgrad_bf16<A, B>(v, p, in, cin, go, cout, partial, s); } else
   LGS_WG(1, 1) LGS_WG(1, 2) LGS_WG(1, 3) LGS_WG(1, 4)
   LGS_WG(2, 1) LGS_WG(2, 2) LGS_WG(2, 3) LGS_WG(2, 4)
   LGS_WG(3, 1) LGS_WG(3, 2) LGS_WG(3, 3) LGS_WG(3, 4)
