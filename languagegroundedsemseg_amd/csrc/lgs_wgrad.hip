@@ -145,11 +145,11 @@ typedef short short4v __attribute__((ext_vector_type(4)));
 // are consecutive in dispatch order on the same XCD.  Every row of the range is therefore fetched from HBM about
 // once and re-read ~K times from L1/L2 -- without this ordering the gathers were 98 % L2 misses (PMC) and the
 // kernel ran at the random-access rate of HBM.
-template <int NCI, int NCO, int D>
-__global__ __launch_bounds__(256) void k_wgrad_bf16(View v, const bf16_t *__restrict__ in, int cin_real,
+template <int NCI, int NCO, int D, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_wgrad_bf16(View v, const bf16_t *__restrict__ in, int cin_real,
                                                     const bf16_t *__restrict__ gout, int cout_real, int cin_pad,
                                                     int cout_pad, int64_t range, int kpw, int n_ci_tasks, int n_tasks,
-                                                    int n_ranges, float *__restrict__ partial,
+                                                    int n_ranges, int n_lanes, float *__restrict__ partial,
                                                     unsigned in_bytes, unsigned gout_bytes) {
   constexpr int CA = 32 * NCI, CG = 32 * NCO;
   constexpr int SA = tile_stride(CA), SG = tile_stride(CG);
@@ -169,18 +169,16 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(View v, const bf16_t *__rest
   const unsigned L = blockIdx.x, xcd = L & 7u, t = L >> 3;
   const int kg = (int)(t % (unsigned)KG);
   const int task = (int)((t / (unsigned)KG) % (unsigned)n_tasks);
-  const int rg_i = (int)(t / (unsigned)(KG * n_tasks)) * 8 + (int)xcd;
-  if (rg_i >= n_ranges) return;
-  const int k = kg * kpw + wave / wpk;
+  const int lane_i = (int)(t / (unsigned)(KG * n_tasks)) * 8 + (int)xcd;   // "range lane": ranges lane_i, lane_i + n_lanes, ...
+  if (lane_i >= n_lanes) return;
+  const int k = kg * kpw + wave / wpk;   // neighbouring offsets share a workgroup: their gathers overlap in L1
   const int sub = wave % wpk;
   if (k >= K) return;  // wave-uniform; no workgroup barriers in this kernel
   const int cit = task % n_ci_tasks, cot = task / n_ci_tasks;
   const int ci0 = cit * CA, co0 = cot * CG;
   const int slot = v.KS > 1 ? k : 0;
-  const int64_t wslot = rg_i;           // one partial slab per (range, offset): sub-range waves are folded in LDS below
+  const int64_t wslot = lane_i;         // one partial slab per (lane, offset): sub-range waves are folded in LDS below
   const int64_t sub_len = range / wpk;
-  const int64_t p_begin = (int64_t)rg_i * range + sub * sub_len;
-  const int64_t p_end = min(p_begin + sub_len, v.n_pad);
 
   f32x16 acc[NCI][NCO];
 #pragma unroll
@@ -281,6 +279,12 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(View v, const bf16_t *__rest
     __builtin_amdgcn_wave_barrier();
   };
 
+  // The grid is sized to the resident workgroup slots of the chip and every workgroup walks its lane's ranges with
+  // the accumulators kept in registers: one partial slab per LANE instead of one per range (4x fewer partial bytes
+  // to write and re-read at level 0), and the KG workgroups that share a range's rows are co-resident by construction.
+  for (int rg_i = lane_i; rg_i < n_ranges; rg_i += n_lanes) {
+  const int64_t p_begin = (int64_t)rg_i * range + sub * sub_len;
+  const int64_t p_end = min(p_begin + sub_len, v.n_pad);
   for (int64_t base = p_begin; base < p_end; base += kQ) {
     // ---- ballot-compact the valid pairs of up to kQ positions (wave-private, in order).  All index loads of the
     // chunk are issued first (16 independent loads in flight instead of 16 dependent round trips), then compacted.
@@ -339,6 +343,7 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(View v, const bf16_t *__rest
         }
       }
     }
+  }
   }
   // ---- waves that split one offset's range (wpk > 1: all waves of the workgroup are alive, same k) fold their
   // accumulators into wave 0 through the now idle staging LDS, in a fixed order
@@ -404,6 +409,7 @@ struct WgradPlan {
   int nci, nco;   // bf16 path: wave tile in 32-channel blocks
   int n_ci_tasks, n_co_tasks;
   int kpw;        // bf16 path: kernel offsets per workgroup (one per wave)
+  int n_ranges;   // bf16 path: position ranges of `span` voxels, dealt round-robin to the S lanes
 };
 
 inline WgradPlan wgrad_plan(const View &v, int cin, int cout, int dtype) {
@@ -418,24 +424,45 @@ inline WgradPlan wgrad_plan(const View &v, int cin, int cout, int dtype) {
     p.nco = nbo >= 3 ? 3 : nbo;
     if (nbo % 3 != 0 && nbo % 2 == 0 && nbo >= 2) p.nco = 2;
     if (nbo % 4 == 0 && p.nci <= 3) p.nco = 4;
+    // tiles whose accumulators + a 2-deep gather ring exceed ~192 registers would run one wave per SIMD: halve them
+    if (16 * p.nci * p.nco + 8 * (p.nci + p.nco) > 192) { if (p.nci == 4) p.nci = 2; else p.nco = 2; }
     p.n_ci_tasks = (nbi + p.nci - 1) / p.nci;
     p.n_co_tasks = (nbo + p.nco - 1) / p.nco;
     // large maps: one offset per wave (4 offsets share a range's rows in L1/L2); small maps and the grouped views
     // (whose positions are sorted by offset, so a range holds a single offset): one offset per workgroup, the four
     // waves split the range
     p.kpw = (v.n_pad >= 65536 && v.KS > 1) ? (v.K >= 4 ? 4 : (v.K >= 2 ? 2 : 1)) : 1;
-    const int wpk = 4 / p.kpw;
-    // position range per workgroup: 4096 voxels (rows + halo ~1.6 MB at 96 channels: L2 resident), larger only to
-    // bound the partial buffer
-    int64_t range = 4096;
-    // small maps (coarse levels): shrink the range (>= 1024) only while fewer than ~512 workgroups exist; every
-    // (range, offset) costs one partial slab of Cin x Cout floats, so ranges must stay large next to it
+    // smaller maps: ranges of 1024 positions, dealt round-robin to S "lanes" of co-resident workgroups (see the
+    // kernel): S is what fits the chip's workgroup slots (LDS bound, <= 4 per CU), a multiple of 8 (XCD pinning), and
+    // every lane costs one partial slab of K x Cin x Cout floats
     const int64_t KG = (v.K + p.kpw - 1) / p.kpw, tasks = (int64_t)p.n_ci_tasks * p.n_co_tasks;
-    while (range > 1024 && ((v.n_pad + range - 1) / range) * KG * tasks < 512) range /= 2;
-    while (((v.n_pad + range - 1) / range) * per > (1ll << 30) && range < (1ll << 24)) range *= 2;
+    const int wave_bytes = 2 * kQ * 4 + 16 * tile_stride(32 * p.nci) + 16 * tile_stride(32 * p.nco);
+    int wg_per_cu = (160 * 1024) / (4 * wave_bytes);
+    if (wg_per_cu > 4) wg_per_cu = 4;
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    const int64_t slots = 256 * (int64_t)wg_per_cu;
+    int64_t range = 4096, n_ranges = (v.n_pad + range - 1) / range, lanes = n_ranges;
+    if (n_ranges * KG * tasks >= 2 * slots && n_ranges * per <= (1ll << 30)) {
+      // big maps: one 4096-position range per workgroup, >= 2 rounds of workgroups over the chip.  The offsets of a
+      // 3^3 map differ 4x in density (centre 100 %, corners ~25 %), so dynamic dispatch is what balances the waves.
+    } else {
+      range = 1024;
+      n_ranges = (v.n_pad + range - 1) / range;
+      lanes = slots / (KG * tasks);
+      lanes = lanes / 8 * 8;
+      if (lanes < 8) lanes = 8;
+      while (lanes > 8 && lanes * per > (1ll << 30)) lanes -= 8;
+      if (n_ranges <= lanes + lanes / 4) {
+        lanes = n_ranges;                       // mild over-subscription beats a half-empty second round
+      } else {                                  // equalise the rounds per lane
+        const int64_t rounds = (n_ranges + lanes - 1) / lanes;
+        const int64_t l2 = ((n_ranges + rounds - 1) / rounds + 7) / 8 * 8;
+        if (l2 < lanes) lanes = l2;
+      }
+    }
     p.span = range;
-    p.S = (int)((v.n_pad + range - 1) / range);
-    (void)wpk;
+    p.n_ranges = (int)n_ranges;
+    p.S = (int)(lanes > 0 ? lanes : 1);
   } else {
     p.ncb = (nbo % 4 == 0) ? 4 : (nbo % 3 == 0) ? 3 : (nbo % 2 == 0) ? 2 : 1;
     int64_t chunks = (v.n_pad + kWgChunk - 1) / kWgChunk;
@@ -469,15 +496,19 @@ int launch_wgrad_bf16(const View &v, const WgradPlan &p, const bf16_t *in, int c
   const uint64_t in_b = (uint64_t)v.n_in * cin * 2, go_b = (uint64_t)v.n_out * cout * 2;
   LGS_REQUIRE(in_b < 0xfffff000ull && go_b < 0xfffff000ull,
               "bf16 wgrad: a feature tensor of 4 GiB or more is beyond the 32-bit buffer-descriptor path");
-  constexpr int D = (NCI * NCO >= 9) ? 3 : 4;
+  // two waves per SIMD (<= 256 registers) whenever accumulators + a >= 2-deep gather ring fit: the LDS/MFMA part of a
+  // group is a serial chain of latencies that only a second wave can hide (1 wave/SIMD ran 1.4x slower at 96x96)
+  constexpr int ACC = 16 * NCI * NCO, RING1 = 4 * (NCI + NCO);
+  constexpr int OCC = (ACC + 2 * RING1 <= 192) ? 2 : 1;
+  constexpr int D = OCC == 1 ? 3 : ((ACC + 4 * RING1 <= 192) ? 4 : (ACC + 3 * RING1 <= 192) ? 3 : 2);
   constexpr int WAVE_BYTES = 2 * kQ * 4 + 16 * tile_stride(CA) + 16 * tile_stride(CG);
   static_assert(4 * WAVE_BYTES >= NCI * NCO * 16 * 64 * 4, "staging LDS must hold one accumulator tile");
   const int n_tasks = p.n_ci_tasks * p.n_co_tasks;
-  const int n_ranges = p.S;
+  const int n_ranges = p.n_ranges, n_lanes = p.S;
   const int KG = (v.K + p.kpw - 1) / p.kpw;
-  const unsigned nblocks = (unsigned)(((n_ranges + 7) / 8) * 8 * KG * n_tasks);
-  hipLaunchKernelGGL((k_wgrad_bf16<NCI, NCO, D>), dim3(nblocks), 256, 4 * WAVE_BYTES, s, v, in, cin, go, cout, p.cin_pad,
-                     p.cout_pad, p.span, p.kpw, p.n_ci_tasks, n_tasks, n_ranges, partial, (unsigned)in_b, (unsigned)go_b);
+  const unsigned nblocks = (unsigned)(((n_lanes + 7) / 8) * 8 * KG * n_tasks);
+  hipLaunchKernelGGL((k_wgrad_bf16<NCI, NCO, D, OCC>), dim3(nblocks), 256, 4 * WAVE_BYTES, s, v, in, cin, go, cout, p.cin_pad,
+                     p.cout_pad, p.span, p.kpw, p.n_ci_tasks, n_tasks, n_ranges, n_lanes, partial, (unsigned)in_b, (unsigned)go_b);
   return 0;
 }
 

@@ -71,6 +71,19 @@ def main():
         sx = ME.SparseTensor(f.clone().requires_grad_(True), coordinate_map_key=k0, coordinate_manager=mgr)
         tb = timeit(lambda: bn(sx, relu=True))
         print("%-9s BN+ReLU fwd 96ch %.3f ms (%.2f TB/s of 3*N*C*e)" % (str(dtype).split(".")[1], tb, 3 * n * 96 * e / tb / 1e9))
+        be = ME.get_backend()
+        g1, b1 = torch.ones(96, device=DEV), torch.zeros(96, device=DEV)
+        rm, rv = torch.zeros(96, device=DEV), torch.ones(96, device=DEV)
+        y, st = be.bn_forward(f, g1, b1, 1e-5, 0.1, rm, rv, None, 1)
+        dy = torch.randn_like(f)
+        for mode, want in ((2, False), (1, True)):
+            t_all = timeit(lambda: be.bn_backward(f, y, dy, g1, b1, st, mode, want))
+            t_red = timeit(lambda: be.bn_backward_reduce(f, y, dy, g1, b1, st, mode))
+            sums = be.bn_backward_reduce(f, y, dy, g1, b1, st, mode)
+            t_app = timeit(lambda: be.bn_backward_apply(f, y, dy, g1, b1, st, sums, 1.0 / n, mode, want))
+            nt = (5 if mode == 2 else 7) + (1 if want else 0)
+            print("%-9s BN bwd 96ch relu-mode %d res %d: %.3f ms (%.2f TB/s of %d*N*C*e)  reduce %.3f  apply %.3f" % (
+                str(dtype).split(".")[1], mode, want, t_all, nt * n * 96 * e / t_all / 1e9, nt, t_red, t_app))
 
 
 def clip():
