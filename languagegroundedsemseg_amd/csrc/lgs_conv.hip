@@ -183,9 +183,29 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   // fetch is a ds_read (lgkmcnt) and never sits in the VMEM queue in front of the gather ring
   __shared__ int32_t l_idx[27 * TM];
   if (v.nbr) {
-    for (uint32_t m = smask; m; m &= m - 1) {
-      const int sl = __builtin_ctz(m);
-      for (int r = tid; r < TM; r += NT) l_idx[sl * TM + r] = v.nbr[(int64_t)sl * v.n_pad + pos_wg + r];
+    // all index loads of the tile are issued before the first one is consumed: a slot-by-slot copy loop was a chain
+    // of ~16 dependent global-load latencies at the head of every workgroup (a quarter of its lifetime)
+    constexpr int IT = (TM + NT - 1) / NT;
+    int32_t tmp[27][IT];
+#pragma unroll
+    for (int sl = 0; sl < 27; ++sl) {
+      if ((smask >> sl) & 1u) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+          const int r = tid + it * NT;
+          tmp[sl][it] = r < TM ? v.nbr[(int64_t)sl * v.n_pad + pos_wg + r] : -1;
+        }
+      }
+    }
+#pragma unroll
+    for (int sl = 0; sl < 27; ++sl) {
+      if ((smask >> sl) & 1u) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+          const int r = tid + it * NT;
+          if (r < TM) l_idx[sl * TM + r] = tmp[sl][it];
+        }
+      }
     }
     __syncthreads();
   }
