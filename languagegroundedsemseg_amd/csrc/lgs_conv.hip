@@ -182,33 +182,6 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   // ---- gather indices of every visited slot are parked in LDS once (coalesced), so that the per-offset index
   // fetch is a ds_read (lgkmcnt) and never sits in the VMEM queue in front of the gather ring
   __shared__ int32_t l_idx[27 * TM];
-  if (v.nbr) {
-    // all index loads of the tile are issued before the first one is consumed: a slot-by-slot copy loop was a chain
-    // of ~16 dependent global-load latencies at the head of every workgroup (a quarter of its lifetime)
-    constexpr int IT = (TM + NT - 1) / NT;
-    int32_t tmp[27][IT];
-#pragma unroll
-    for (int sl = 0; sl < 27; ++sl) {
-      if ((smask >> sl) & 1u) {
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-          const int r = tid + it * NT;
-          tmp[sl][it] = r < TM ? v.nbr[(int64_t)sl * v.n_pad + pos_wg + r] : -1;
-        }
-      }
-    }
-#pragma unroll
-    for (int sl = 0; sl < 27; ++sl) {
-      if ((smask >> sl) & 1u) {
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-          const int r = tid + it * NT;
-          if (r < TM) l_idx[sl * TM + r] = tmp[sl][it];
-        }
-      }
-    }
-    __syncthreads();
-  }
   // ---- feature-side iterator: flat sequence of (slot, chunk)
   uint32_t rem = smask;
   int islot = -1, ichunk = nc;  // forces "advance to first slot" on the first call
@@ -314,20 +287,48 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   bool wnext = false;        // is a following slab prefetched in wreg?
   const int total = __builtin_popcount(smask) * nc;  // chunks of this workgroup
   int issued = 0, computed = 0;
-  if (wadvance()) {
-    wissue(wreg);
+  // Prologue: the first weight slab and ALL index loads of the tile are in flight together, one barrier publishes
+  // both (a slot-by-slot index copy loop was a chain of ~16 dependent global-load latencies at the head of every
+  // workgroup -- a quarter of its lifetime -- and the first weight fetch only started behind it).
+  const bool whave = wadvance();
+  if (whave) wissue(wreg);
+  if (v.nbr) {
+    constexpr int IT = (TM + NT - 1) / NT;
+    int32_t tmp[27][IT];
+#pragma unroll
+    for (int sl = 0; sl < 27; ++sl) {
+      if ((smask >> sl) & 1u) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+          const int r = tid + it * NT;
+          tmp[sl][it] = r < TM ? v.nbr[(int64_t)sl * v.n_pad + pos_wg + r] : -1;
+        }
+      }
+    }
+#pragma unroll
+    for (int sl = 0; sl < 27; ++sl) {
+      if ((smask >> sl) & 1u) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+          const int r = tid + it * NT;
+          if (r < TM) l_idx[sl * TM + r] = tmp[sl][it];
+        }
+      }
+    }
+  }
+  if (whave) {
     wstage(0, wreg);
     ncs = min(SC, nc - wslab * SC);
     wnext = wadvance();
     if (wnext) wissue(wreg);
   }
+  __syncthreads();   // indices and the first weight slab are visible
 #pragma unroll
   for (int d = 0; d < D - 1; ++d) {
     act[d] = 0;
     if (issued < total) { advance(); issue(F[d], act[d]); ++issued; }
   }
   act[D - 1] = 0;
-  __syncthreads();
   // at the end of a slab publish the prefetched next slab and cross one barrier
   auto slab_end = [&]() __attribute__((always_inline)) {
     if (wnext) wstage(buf ^ 1, wreg);
