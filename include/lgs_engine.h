@@ -164,8 +164,9 @@ int64_t lgs_clip_workspace_bytes(int c, int n_anchor, int dtype);
  * replaces nn.CrossEntropyLoss(ignore_index=-1) on the [N,200] logits of the fine-tune step
  *   /root/reference/lib/train_test/pl_BaselineTrainer.py:94-99,350
  * One pass: loss_rows[n] (float32, 0 for ignored rows) and dlogits[n,c] = (softmax - onehot) * (*scale)
- * (same dtype as logits, zeros for ignored rows).  `scale` is a DEVICE float (e.g. 1 / #valid rows), so
- * the mean reduction needs no host sync. */
+ * (same dtype as logits, zeros for ignored rows).  `scale` is a DEVICE float (e.g. 1 / #valid rows, times
+ * the upstream gradient), so the mean reduction needs no host sync.  Either output may be NULL: the host
+ * wrapper asks for the loss in the forward pass and for the gradient in the backward pass. */
 int lgs_ce_forward_backward(const void *logits, int64_t n, int c, const int64_t *labels, int64_t ignore_index,
                             const float *scale, float *loss_rows, void *dlogits, int dtype, void *stream);
 

@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void k_ce_fwd_bwd(const T *__restrict__ logits
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) { se += __shfl_xor(se, o, 32); xl += __shfl_xor(xl, o, 32); }
   const float lse = mx + __logf(se);
-  if (lane == 0) loss_rows[row] = ignored ? 0.f : (lse - xl);
+  if (loss_rows && lane == 0) loss_rows[row] = ignored ? 0.f : (lse - xl);
+  if (!dlogits) return;   // loss only (the gradient is produced by a second call in the backward pass)
   const float scale = ignored ? 0.f : *scale_ptr;
   const float inv = scale / se;
 #pragma unroll
@@ -99,7 +100,7 @@ using namespace lgs;
 
 extern "C" int lgs_ce_forward_backward(const void *logits, int64_t n, int c, const int64_t *labels, int64_t ignore_index,
                                        const float *scale, float *loss_rows, void *dlogits, int dtype, void *stream) {
-  LGS_REQUIRE(logits && labels && scale && loss_rows && dlogits, "lgs_ce_forward_backward: null argument");
+  LGS_REQUIRE(logits && labels && scale && (loss_rows || dlogits), "lgs_ce_forward_backward: null argument");
   const int W = dtype == LGS_BF16 ? 8 : 4;
   LGS_REQUIRE(c % W == 0 && c / W <= 32 * kMaxChunks, "lgs_ce_forward_backward: class count unsupported");
   if (n == 0) return 0;

@@ -15,16 +15,21 @@ from .me.core import get_backend
 
 
 class _FusedCE(torch.autograd.Function):
+    """forward: loss only; backward: the same kernel again writes d(logits) already scaled by the upstream gradient
+    (one read of the logits instead of a write + read-modify-write of an [N,200] gradient tensor)."""
+
     @staticmethod
     def forward(ctx, logits, labels, ignore_index):
-        loss, dlogits = get_backend().cross_entropy(logits, labels, ignore_index)
-        ctx.save_for_backward(dlogits)
+        loss, _ = get_backend().cross_entropy(logits, labels, ignore_index, want_grad=False)
+        ctx.save_for_backward(logits, labels)
+        ctx.ignore_index = ignore_index
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        (dlogits,) = ctx.saved_tensors
-        return dlogits.mul_(g.to(dlogits.dtype)), None, None
+        logits, labels = ctx.saved_tensors
+        _, dlogits = get_backend().cross_entropy(logits, labels, ctx.ignore_index, grad_scale=g)
+        return dlogits, None, None
 
 
 def fused_cross_entropy(logits, labels, ignore_index=-1):

@@ -297,7 +297,9 @@ class HipBackend:
         return sim, inv[:n]
 
     # ---- fused softmax cross-entropy: lgs_ce_forward_backward
-    def cross_entropy(self, logits, labels, ignore_index):
+    def cross_entropy(self, logits, labels, ignore_index, want_grad=True, grad_scale=None):
+        """mean CE over the non-ignored rows.  want_grad=False: loss only; grad_scale (device scalar): gradient only,
+        already multiplied by it (the two halves of one kernel, so the upstream gradient never needs its own pass)."""
         _require_dev(logits, "logits")
         L = engine.lib()
         logits = logits.contiguous()
@@ -307,8 +309,11 @@ class HipBackend:
         with torch.cuda.device(logits.device):
             valid = (labels != ignore_index).sum().to(torch.float32).clamp_min(1.0)
             scale = valid.reciprocal()
-            loss_rows = torch.empty(max(n, 1), dtype=torch.float32, device=logits.device)
-            dlogits = torch.empty_like(logits)
+            if grad_scale is not None:
+                scale = scale * grad_scale.to(torch.float32).reshape(())
+            loss_rows = torch.empty(max(n, 1), dtype=torch.float32, device=logits.device) if grad_scale is None else None
+            dlogits = torch.empty_like(logits) if (want_grad or grad_scale is not None) else None
             engine.check(L.lgs_ce_forward_backward(_ptr(logits), n, c, _ptr(labels), int(ignore_index), _ptr(scale),
                                                    _ptr(loss_rows), _ptr(dlogits), dt, _stream()))
-        return loss_rows[:n].sum() * scale, dlogits
+        loss = loss_rows[:n].sum() * scale if loss_rows is not None else None
+        return loss, dlogits

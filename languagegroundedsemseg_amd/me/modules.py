@@ -78,7 +78,7 @@ class MinkowskiConvolutionFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gin = ctx.kmap.conv_dgrad(gout, kernel, ctx.transposed)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gout.float().sum(0, keepdim=True)
+            gb = gout.sum(0, keepdim=True, dtype=torch.float32)   # fp32 accumulation without an fp32 copy of gout
         return gin, gw, gb, None, None
 
 
