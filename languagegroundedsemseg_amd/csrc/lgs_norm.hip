@@ -140,26 +140,30 @@ __global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, cons
 }
 
 // fold the per-block partials (fixed order, deterministic) and finish: forward -> mean / invstd / running stats,
-// backward -> dbeta = sum dy', dgamma = sum dy' xhat.  Block = 64 channels x 4 partial-slices; each thread sums
-// every 4th partial (coalesced across channels), slices are combined through LDS.
+// backward -> dbeta = sum dy', dgamma = sum dy' xhat.  Block = 16 channels x 16 partial-slices: a thread sums every
+// 16th partial with eight independent loads in flight (the fold is a pure latency chain: 4 slices of 128 dependent
+// steps took 13 us per BatchNorm, twice per layer), slices are combined through LDS in slice order.
+constexpr int kFoldCh = 16, kFoldSl = 16;
 __device__ inline void fold_sums(const float *__restrict__ scratch, int nblocks, int c, int ch, int part, double &s, double &ss,
-                                 double (*red)[2][64]) {
+                                 double (*red)[2][kFoldCh]) {
   s = 0.0; ss = 0.0;
-  if (ch < c)
-    for (int b = part; b < nblocks; b += 4) { s += scratch[(int64_t)b * 2 * c + ch]; ss += scratch[(int64_t)b * 2 * c + c + ch]; }
-  red[part][0][threadIdx.x & 63] = s;
-  red[part][1][threadIdx.x & 63] = ss;
+  if (ch < c) {
+#pragma unroll 8
+    for (int b = part; b < nblocks; b += kFoldSl) { s += scratch[(int64_t)b * 2 * c + ch]; ss += scratch[(int64_t)b * 2 * c + c + ch]; }
+  }
+  red[part][0][threadIdx.x % kFoldCh] = s;
+  red[part][1][threadIdx.x % kFoldCh] = ss;
   __syncthreads();
   if (part == 0) {
-    for (int q = 1; q < 4; ++q) { s += red[q][0][threadIdx.x & 63]; ss += red[q][1][threadIdx.x & 63]; }
+    for (int q = 1; q < kFoldSl; ++q) { s += red[q][0][threadIdx.x % kFoldCh]; ss += red[q][1][threadIdx.x % kFoldCh]; }
   }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_fold_fwd(const float *__restrict__ scratch, const T *__restrict__ x, int nblocks, int c,
                                                   int64_t n, float eps, float momentum, float *__restrict__ running_mean,
                                                   float *__restrict__ running_var, float *__restrict__ stats) {
-  __shared__ double red[4][2][64];
-  const int ch = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  __shared__ double red[kFoldSl][2][kFoldCh];
+  const int ch = blockIdx.x * kFoldCh + (threadIdx.x % kFoldCh), part = threadIdx.x / kFoldCh;
   double s, ss;
   fold_sums(scratch, nblocks, c, ch, part, s, ss, red);
   if (part != 0 || ch >= c) return;
@@ -180,8 +184,8 @@ __global__ __launch_bounds__(256) void k_fold_fwd(const float *__restrict__ scra
 template <typename T>
 __global__ __launch_bounds__(256) void k_fold_stats(const float *__restrict__ scratch, const T *__restrict__ x, int nblocks, int c,
                                                     int64_t n, float *__restrict__ mean_m2) {
-  __shared__ double red[4][2][64];
-  const int ch = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  __shared__ double red[kFoldSl][2][kFoldCh];
+  const int ch = blockIdx.x * kFoldCh + (threadIdx.x % kFoldCh), part = threadIdx.x / kFoldCh;
   double s, ss;
   fold_sums(scratch, nblocks, c, ch, part, s, ss, red);
   if (part != 0 || ch >= c) return;
@@ -195,8 +199,8 @@ __global__ __launch_bounds__(256) void k_fold_stats(const float *__restrict__ sc
 
 __global__ __launch_bounds__(256) void k_fold_bwd(const float *__restrict__ scratch, int nblocks, int c, float *__restrict__ dgamma,
                                                   float *__restrict__ dbeta, float *__restrict__ sums) {
-  __shared__ double red[4][2][64];
-  const int ch = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  __shared__ double red[kFoldSl][2][kFoldCh];
+  const int ch = blockIdx.x * kFoldCh + (threadIdx.x % kFoldCh), part = threadIdx.x / kFoldCh;
   double s, ss;
   fold_sums(scratch, nblocks, c, ch, part, s, ss, red);
   if (part != 0 || ch >= c) return;
@@ -319,7 +323,7 @@ int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const flo
   const T *x = reinterpret_cast<const T *>(xv);
   hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, n, c, 0,
                      rpb, scratch);
-  hipLaunchKernelGGL((k_fold_fwd<T>), (c + 63) / 64, 256, 0, s, scratch, x, nb, c, n, eps, momentum, rm, rv, stats);
+  hipLaunchKernelGGL((k_fold_fwd<T>), (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, x, nb, c, n, eps, momentum, rm, rv, stats);
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
@@ -342,7 +346,7 @@ int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, in
   float *sums = scratch + (size_t)2 * c * nb;
   const T *x = reinterpret_cast<const T *>(xv), *y = reinterpret_cast<const T *>(yv), *dy = reinterpret_cast<const T *>(dyv);
   hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, x, y, dy, stats, gamma, beta, n, c, relu, rpb, scratch);
-  hipLaunchKernelGGL(k_fold_bwd, (c + 63) / 64, 256, 0, s, scratch, nb, c, dgamma, dbeta, sums);
+  hipLaunchKernelGGL(k_fold_bwd, (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, nb, c, dgamma, dbeta, sums);
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
@@ -363,7 +367,7 @@ int bn_stats_t(const void *xv, int64_t n, int c, float *mean_m2, void *workspace
   const T *x = reinterpret_cast<const T *>(xv);
   hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, n, c, 0,
                      rpb, scratch);
-  hipLaunchKernelGGL((k_fold_stats<T>), (c + 63) / 64, 256, 0, s, scratch, x, nb, c, n, mean_m2);
+  hipLaunchKernelGGL((k_fold_stats<T>), (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, x, nb, c, n, mean_m2);
   LGS_HIP(hipGetLastError());
   return 0;
 }
@@ -392,7 +396,7 @@ int bn_bwd_reduce_t(const void *xv, const void *yv, const void *dyv, int64_t n, 
   float *tmp = scratch + (size_t)2 * c * nb;  // dgamma/dbeta duplicates (unused by the caller)
   hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
                      reinterpret_cast<const T *>(dyv), stats, gamma, beta, n, c, relu, rpb, scratch);
-  hipLaunchKernelGGL(k_fold_bwd, (c + 63) / 64, 256, 0, s, scratch, nb, c, tmp + c, tmp, sums);
+  hipLaunchKernelGGL(k_fold_bwd, (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, nb, c, tmp + c, tmp, sums);
   LGS_HIP(hipGetLastError());
   return 0;
 }
