@@ -120,12 +120,13 @@ int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const 
  *   /root/reference/models/modules/common.py:17-19, models/modules/resnet_block.py:41-57
  * Training-mode batch statistics over all n rows.  stats = float32 [2*C] workspace:
  * on return mean[C], invstd[C].  running_mean/var (float32 [C]) updated with `momentum`
- * (unbiased variance), may be NULL.  residual may be NULL.  y may alias x.
+ * (unbiased variance), may be NULL; num_batches_tracked (device int64 scalar, nn.BatchNorm1d's buffer) is
+ * incremented by the same kernel, may be NULL.  residual may be NULL.  y may alias x.
  * workspace: lgs_bn_workspace_bytes(n, c) bytes of caller-owned device scratch (no allocation inside). */
 int64_t lgs_bn_workspace_bytes(int64_t n, int c);
 int lgs_bn_forward(const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps,
-                   float momentum, float *running_mean, float *running_var, const void *residual, int relu,
-                   void *y, float *stats, int dtype, void *workspace, void *stream);
+                   float momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                   const void *residual, int relu, void *y, float *stats, int dtype, void *workspace, void *stream);
 /* Backward of the fused op.  x = forward input, stats = the forward's mean/invstd.
  * relu: 0 = none; 1 = ReLU mask taken from the forward OUTPUT y (required when a residual was added);
  *       2 = mask recomputed from x as (xhat*gamma + beta > 0), y may be NULL (one tensor read fewer).

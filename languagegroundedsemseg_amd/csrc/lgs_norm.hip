@@ -161,11 +161,13 @@ __device__ inline void fold_sums(const float *__restrict__ scratch, int nblocks,
 template <typename T>
 __global__ __launch_bounds__(256) void k_fold_fwd(const float *__restrict__ scratch, const T *__restrict__ x, int nblocks, int c,
                                                   int64_t n, float eps, float momentum, float *__restrict__ running_mean,
-                                                  float *__restrict__ running_var, float *__restrict__ stats) {
+                                                  float *__restrict__ running_var, long long *__restrict__ nbt,
+                                                  float *__restrict__ stats) {
   __shared__ double red[kFoldSl][2][kFoldCh];
   const int ch = blockIdx.x * kFoldCh + (threadIdx.x % kFoldCh), part = threadIdx.x / kFoldCh;
   double s, ss;
   fold_sums(scratch, nblocks, c, ch, part, s, ss, red);
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;   // nn.BatchNorm1d.num_batches_tracked
   if (part != 0 || ch >= c) return;
   const double pivot = n > 0 ? (double)ld_elem(x + ch) : 0.0;
   double dm = n > 0 ? s / (double)n : 0.0;
@@ -314,7 +316,8 @@ inline int reduce_blocks(int64_t n, int64_t *rows_per_block) {
 
 template <typename T>
 int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const float *beta, float eps, float momentum,
-                 float *rm, float *rv, const void *res, int relu, void *yv, float *stats, void *workspace, hipStream_t s) {
+                 float *rm, float *rv, long long *nbt, const void *res, int relu, void *yv, float *stats, void *workspace,
+                 hipStream_t s) {
   constexpr int W = Vec<T>::W;
   LGS_REQUIRE(c % W == 0 && c / W <= kNT && c <= 2048, "lgs_bn_forward: channel count unsupported");
   int64_t rpb;
@@ -323,7 +326,7 @@ int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const flo
   const T *x = reinterpret_cast<const T *>(xv);
   hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, n, c, 0,
                      rpb, scratch);
-  hipLaunchKernelGGL((k_fold_fwd<T>), (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, x, nb, c, n, eps, momentum, rm, rv, stats);
+  hipLaunchKernelGGL((k_fold_fwd<T>), (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, x, nb, c, n, eps, momentum, rm, rv, nbt, stats);
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
@@ -463,12 +466,12 @@ int64_t lgs_bn_workspace_bytes(int64_t n, int c) {
 }
 
 int lgs_bn_forward(const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps, float momentum,
-                   float *running_mean, float *running_var, const void *residual, int relu, void *y, float *stats,
-                   int dtype, void *workspace, void *stream) {
+                   float *running_mean, float *running_var, int64_t *num_batches_tracked, const void *residual, int relu,
+                   void *y, float *stats, int dtype, void *workspace, void *stream) {
   LGS_REQUIRE(x && y && gamma && beta && stats && workspace, "lgs_bn_forward: null argument");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == LGS_F32) return bn_forward_t<float>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, y, stats, workspace, s);
-  if (dtype == LGS_BF16) return bn_forward_t<bf16_t>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, y, stats, workspace, s);
+  if (dtype == LGS_F32) return bn_forward_t<float>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), residual, relu, y, stats, workspace, s);
+  if (dtype == LGS_BF16) return bn_forward_t<bf16_t>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), residual, relu, y, stats, workspace, s);
   LGS_REQUIRE(false, "lgs_bn_forward: unknown dtype");
 }
 

@@ -190,6 +190,7 @@ class HipManager:
 
 class HipBackend:
     name = "hip"
+    bn_counts_batches = True    # lgs_bn_forward increments num_batches_tracked itself
 
     def __init__(self):
         self._side = {}
@@ -205,7 +206,7 @@ class HipBackend:
         return self._side[key]
 
     # ---- fused BN(+residual)(+ReLU): lgs_bn_forward / lgs_bn_backward
-    def bn_forward(self, x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu):
+    def bn_forward(self, x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, num_batches_tracked=None):
         _require_dev(x, "features")
         L = engine.lib()
         x = x.contiguous()
@@ -217,7 +218,7 @@ class HipBackend:
             res = residual.contiguous() if residual is not None else None
             ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
             engine.check(L.lgs_bn_forward(_ptr(x), n, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
-                                          _ptr(running_mean), _ptr(running_var), _ptr(res), int(relu), _ptr(y),
+                                          _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(res), int(relu), _ptr(y),
                                           _ptr(stats), dt, _ptr(ws), _stream()))
         return y, stats
 

@@ -173,10 +173,13 @@ class FusedBatchNormFunction(torch.autograd.Function):
     """y = relu?(BN(x) (+ residual)) with batch statistics, one engine call each way."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, backend):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, backend, nbt=None):
         ctx.gparam = gamma if isinstance(gamma, torch.nn.Parameter) else None
         ctx.bparam = beta if isinstance(beta, torch.nn.Parameter) else None
-        y, stats = backend.bn_forward(x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu)
+        if nbt is not None:
+            y, stats = backend.bn_forward(x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, nbt)
+        else:
+            y, stats = backend.bn_forward(x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu)
         # ReLU mask in the backward: recomputed from x when there is no residual (mode 2, y is not kept alive),
         # taken from the saved output otherwise (mode 1)
         ctx.backend, ctx.has_res = backend, residual is not None
@@ -199,8 +202,8 @@ class FusedBatchNormFunction(torch.autograd.Function):
         dx, dres, dgamma, dbeta = ctx.backend.bn_backward(x, y, dy, gamma, beta, stats, ctx.relu_mode,
                                                           ctx.has_res and ctx.needs_input_grad[3], gview, bview)
         if gview is not None:
-            return dx, gview, bview, dres, None, None, None, None, None, None
-        return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), dres, None, None, None, None, None, None
+            return dx, gview, bview, dres, None, None, None, None, None, None, None
+        return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), dres, None, None, None, None, None, None, None
 
 
 class MinkowskiBatchNorm(nn.Module):
@@ -220,11 +223,13 @@ class MinkowskiBatchNorm(nn.Module):
         res = residual.F if isinstance(residual, SparseTensor) else residual
         fused = hasattr(backend, "bn_forward") and bn.affine and (bn.training or not bn.track_running_stats)
         if fused:
-            if bn.track_running_stats and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
             rm = bn.running_mean if bn.track_running_stats else None
             rv = bn.running_var if bn.track_running_stats else None
-            y = FusedBatchNormFunction.apply(x, bn.weight, bn.bias, res, rm, rv, bn.eps, bn.momentum, relu, backend)
+            nbt = bn.num_batches_tracked if bn.track_running_stats else None
+            if nbt is not None and not getattr(backend, "bn_counts_batches", False):
+                nbt += 1
+                nbt = None                                 # (the HIP engine increments it inside the fold kernel)
+            y = FusedBatchNormFunction.apply(x, bn.weight, bn.bias, res, rm, rv, bn.eps, bn.momentum, relu, backend, nbt)
         else:
             y = bn(x.float()).to(x.dtype) if x.dtype != torch.float32 else bn(x)
             if res is not None:

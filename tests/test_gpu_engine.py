@@ -233,6 +233,7 @@ def test_fused_bn_matches_torch(dtype, tol, relu, res):
     assert rel_err(bn_h.bn.bias.grad.cpu().numpy(), bn_t.bias.grad.numpy()) < tol * 5
     assert rel_err(bn_h.bn.running_mean.cpu().numpy(), bn_t.running_mean.numpy()) < max(tol, 1e-4)
     assert rel_err(bn_h.bn.running_var.cpu().numpy(), bn_t.running_var.numpy()) < max(tol, 1e-4)
+    assert int(bn_h.bn.num_batches_tracked) == int(bn_t.num_batches_tracked) == 1   # counted inside the fold kernel
 
 
 # ------------------------------------------------------------------------------------------- CLIP
