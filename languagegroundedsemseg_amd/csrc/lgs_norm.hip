@@ -87,31 +87,15 @@ __global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, cons
   const int64_t r1 = min(r0 + rows_per_block, n);
   if (active) {
     int64_t r = r0 + rl;
-    if (MODE == 0) {
-      // forward statistics: two independent row loads in flight per thread
-      for (; r + RL < r1; r += 2 * RL) {
-        float xa[W], xb[W];
-        Vec<T>::load(x + r * c + cg * W, xa);
-        Vec<T>::load(x + (r + RL) * c + cg * W, xb);
-#pragma unroll
-        for (int i = 0; i < W; ++i) {
-          const float da = xa[i] - mean[i], db = xb[i] - mean[i];
-          s0[i] += da + db; s1[i] += da * da + db * db;
-        }
-      }
-    }
-    for (; r < r1; r += RL) {
-      float xv[W];
-      Vec<T>::load(x + r * c + cg * W, xv);
+    // U rows per thread are in flight before the first is consumed (a streaming reduction needs ~50 KB of loads in
+    // flight per CU to cover the HBM latency); sums are then taken in row order, i.e. exactly as a 1-row loop would
+    constexpr int U = MODE == 0 ? 4 : 2;
+    auto accumulate = [&](const float (&xv)[W], float (&gv)[W], const float (&yv)[W]) __attribute__((always_inline)) {
       if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < W; ++i) { const float d = xv[i] - mean[i]; s0[i] += d; s1[i] += d * d; }
       } else {
-        float gv[W];
-        Vec<T>::load(dy + r * c + cg * W, gv);
         if (relu == 1) {
-          float yv[W];
-          Vec<T>::load(y + r * c + cg * W, yv);
 #pragma unroll
           for (int i = 0; i < W; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
         } else if (relu == 2) {
@@ -121,6 +105,30 @@ __global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, cons
 #pragma unroll
         for (int i = 0; i < W; ++i) { s0[i] += gv[i]; s1[i] += gv[i] * (xv[i] - mean[i]) * istd[i]; }
       }
+    };
+    for (; r + (U - 1) * RL < r1; r += U * RL) {
+      float xv[U][W], gv[U][W], yv[U][W];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t o = (r + u * RL) * c + cg * W;
+        Vec<T>::load(x + o, xv[u]);
+        if (MODE == 1) {
+          Vec<T>::load(dy + o, gv[u]);
+          if (relu == 1) Vec<T>::load(y + o, yv[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) accumulate(xv[u], gv[u], yv[u]);
+    }
+    for (; r < r1; r += RL) {
+      float xv[W], gv[W], yv[W];
+      const int64_t o = r * c + cg * W;
+      Vec<T>::load(x + o, xv);
+      if (MODE == 1) {
+        Vec<T>::load(dy + o, gv);
+        if (relu == 1) Vec<T>::load(y + o, yv);
+      }
+      accumulate(xv, gv, yv);
     }
   }
   // block reduction over rl through LDS
