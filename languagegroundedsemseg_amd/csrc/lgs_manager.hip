@@ -572,6 +572,10 @@ int lgs_manager_map_size(lgs_manager *m, int key, int64_t *n, int *tensor_stride
 int lgs_manager_get_coords(lgs_manager *m, int key, int32_t *dst, void *stream) {
   LGS_REQUIRE(m && key >= 0 && key < (int)m->maps.size(), "lgs_manager_get_coords: bad key");
   const CoordMap &cm = m->maps[key];
+  // `dst` was allocated on the caller's stream: a caching allocator may have handed out a block that kernels still
+  // queued on that stream are using (e.g. a conv workspace released a moment ago), so the copy must be ordered after
+  // the caller's pending work -- writing it early from the map stream corrupted a running conv's packed weights
+  if (begin_from_caller(m, (hipStream_t)stream)) return 1;
   if (cm.n > 0)
     LGS_HIP(hipMemcpyAsync(dst, cm.coords, sizeof(int32_t) * 4 * (size_t)cm.n, hipMemcpyDeviceToDevice, m->ms));
   return publish(m, (hipStream_t)stream, true);

@@ -80,13 +80,13 @@ def test_out_of_range_coordinates_fail_loudly():
 
 
 # ------------------------------------------------------------------------------------------- conv
-def run_both(build, coords, feats, dtype=torch.float32, grad_seed=0):
+def run_both(build, coords, feats, dtype=torch.float32, grad_seed=0, oracle_impl="c"):
     """run the same module graph on the HIP engine and on the oracle; return canonicalised outputs + grads"""
     res = []
     for backend in ("hip", "oracle"):
         prev = ME.get_backend()
         if backend == "oracle":
-            ME.set_backend(OracleBackend("c"))
+            ME.set_backend(OracleBackend(oracle_impl))
         try:
             torch.manual_seed(1)
             mods = build()
@@ -265,6 +265,23 @@ def test_bf16_mfma_paths_all_tile_shapes(cin, cout, ks, st):
         dtype=torch.bfloat16)
     assert rel_err(h_out, o_out) < 2e-2
     for n, a, b in zip(["dgrad", "wgrad", "bgrad"], h_g, o_g):
+        assert rel_err(a, b) < 2e-2, n
+
+
+@pytest.mark.parametrize("cin,cout", [(96, 96), (128, 96), (32, 32), (32, 64)])
+def test_bf16_conv_on_a_large_map(cin, cout):
+    """maps of >= 65536 positions take the 'big' tile configurations of k_conv_gather and the one-offset-per-wave
+    schedule of k_wgrad_bf16; reading y.C while kernels are still queued must not disturb them (the coordinate export
+    once wrote into a just-released conv workspace from the map stream)"""
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    coords, _, _ = make_batch([3], voxel=0.02, n_target=80000)
+    assert coords.shape[0] >= 66000
+    feats = torch.from_numpy(np.random.default_rng(5).standard_normal((coords.shape[0], cin)).astype(np.float32)).bfloat16().float().numpy()
+    (h_out, h_g), (o_out, o_g) = run_both(
+        lambda: [ME.MinkowskiConvolution(cin, cout, kernel_size=3, stride=1, dimension=3)], coords, feats, dtype=torch.bfloat16,
+        oracle_impl="torch")
+    assert rel_err(h_out, o_out) < 2e-2
+    for n, a, b in zip(["dgrad", "wgrad"], h_g, o_g):
         assert rel_err(a, b) < 2e-2, n
 
 
