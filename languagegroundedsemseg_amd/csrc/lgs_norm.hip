@@ -314,7 +314,9 @@ __global__ __launch_bounds__(kNT) void k_bn_bwd_apply(const T *__restrict__ x, c
 }
 
 inline int reduce_blocks(int64_t n, int64_t *rows_per_block) {
-  int64_t nb = (n + 1023) / 1024;
+  // >= 128 rows per block, <= 512 blocks: coarse levels (a few thousand rows) still get tens of blocks -- with 1024
+  // rows per block their reductions were 5-block, 13 us latency chains
+  int64_t nb = (n + 127) / 128;
   if (nb > 512) nb = 512;
   if (nb < 1) nb = 1;
   *rows_per_block = (n + nb - 1) / nb;
