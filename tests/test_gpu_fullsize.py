@@ -1,0 +1,139 @@
+"""Full-size checks (BASELINE configs[1]: 8 scenes, ~1.2 M voxels @2cm) through SIZE-INDEPENDENT properties -- the
+oracle would need minutes here, so the HIP path is held against identities any correct sparse convolution satisfies:
+
+* coordinate maps against numpy set arithmetic (dedup, stride-2 coarsening = unique(floor(c / 2) * 2));
+* kernel-map pair counts: offset k and its mirror 26-k have the same number of pairs, the centre has N;
+* conv with a one-hot weight (single offset, identity matrix) copies exactly the neighbour row a numpy hash lookup finds;
+* adjointness <conv(x), g> = <x, dgrad(g)> = <W, wgrad(x, g)>: ties forward, dgrad and wgrad kernels together;
+* linearity conv(a x + b y) = a conv(x) + b conv(y);
+* bf16 and fp32 paths agree to bf16 precision on the same map.
+"""
+import numpy as np
+import pytest
+import torch
+
+import MinkowskiEngine as ME
+from languagegroundedsemseg_amd.synthetic import make_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def batch():
+    coords, feats, labels = make_batch(list(range(8)), voxel=0.02, n_target=150000)
+    return coords
+
+
+def _key(c):
+    c = c.astype(np.int64)
+    return ((c[:, 0] << 48) | ((c[:, 1] + (1 << 15)) << 32) | ((c[:, 2] + (1 << 15)) << 16) | (c[:, 3] + (1 << 15)))
+
+
+def test_fullsize_maps_against_numpy_sets(batch):
+    coords = batch
+    n = coords.shape[0]
+    assert n > 1_000_000
+    x = ME.SparseTensor(torch.zeros(n, 1, device=DEV), torch.from_numpy(coords).to(DEV))
+    assert np.array_equal(np.sort(_key(x.C.cpu().numpy())), np.sort(_key(coords)))      # no voxel lost or invented
+    mgr = x.coordinate_manager
+    key = x.coordinate_map_key
+    ref = coords
+    for lvl in range(1, 5):
+        key = mgr.stride(key, 2)
+        ts = 2 ** lvl
+        ref = np.concatenate([ref[:, :1], (ref[:, 1:] // ts) * ts], 1)
+        want = np.unique(_key(ref))
+        got = np.sort(_key(mgr.get_coordinates(key).cpu().numpy()))
+        assert np.array_equal(got, want), "stride-%d map differs from numpy unique(floor(c/%d)*%d)" % (ts, ts, ts)
+
+
+def test_fullsize_kernel_map_counts_are_mirror_symmetric(batch):
+    coords = batch
+    n = coords.shape[0]
+    x = ME.SparseTensor(torch.zeros(n, 1, device=DEV), torch.from_numpy(coords).to(DEV))
+    km = x.coordinate_manager.kernel_map_handle(x.coordinate_map_key, x.coordinate_map_key, 3)
+    k, i, o = km.export()
+    k = k.cpu().numpy()
+    cnt = np.bincount(k, minlength=27)
+    assert cnt[13] == n
+    for kk in range(13):
+        assert cnt[kk] == cnt[26 - kk], (kk, cnt[kk], cnt[26 - kk])
+    # every pair is a real neighbour: c_in - c_out == offset_k
+    ii, oo = i.cpu().numpy().astype(np.int64), o.cpu().numpy().astype(np.int64)
+    C = x.C.cpu().numpy().astype(np.int64)
+    d = C[ii, 1:] - C[oo, 1:]
+    off = np.stack([k % 3 - 1, (k // 3) % 3 - 1, k // 9 - 1], 1)
+    assert np.array_equal(d, off) and np.array_equal(C[ii, 0], C[oo, 0])
+
+
+@pytest.mark.parametrize("k_sel", [0, 4, 13, 22])
+def test_fullsize_one_hot_conv_copies_the_neighbour_row(batch, k_sel):
+    coords = batch
+    n, c = coords.shape[0], 32
+    f = torch.randn(n, c, device=DEV)
+    x = ME.SparseTensor(f, torch.from_numpy(coords).to(DEV))
+    conv = ME.MinkowskiConvolution(c, c, kernel_size=3, dimension=3).to(DEV)
+    with torch.no_grad():
+        conv.kernel.zero_()
+        conv.kernel[k_sel] = torch.eye(c, device=DEV)
+    y = conv(x).F
+    # numpy hash lookup of the neighbour at offset k_sel (first spatial axis fastest, ME's convention)
+    off = np.array([k_sel % 3 - 1, (k_sel // 3) % 3 - 1, k_sel // 9 - 1], np.int64)
+    C = x.C.cpu().numpy().astype(np.int64)
+    keys = _key(C)
+    order = np.argsort(keys)
+    nb = C.copy()
+    nb[:, 1:] += off
+    q = _key(nb)
+    pos = np.searchsorted(keys[order], q)
+    pos = np.clip(pos, 0, n - 1)
+    hit = keys[order][pos] == q
+    src = order[pos]
+    want = torch.zeros_like(f)
+    hit_t = torch.from_numpy(hit).to(DEV)
+    want[hit_t] = f[torch.from_numpy(src[hit]).to(DEV)]
+    assert torch.equal(y, want)                               # fp32 MFMA with an identity weight is exact
+
+
+def test_fullsize_adjoint_identity_ties_forward_dgrad_wgrad(batch):
+    coords = batch
+    n, cin, cout = coords.shape[0], 32, 64
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x0 = torch.randn(n, cin, device=DEV, generator=g)
+    go = torch.randn(n, cout, device=DEV, generator=g)
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 6e-3)):
+        conv = ME.MinkowskiConvolution(cin, cout, kernel_size=3, dimension=3).to(DEV)
+        xf = x0.detach().clone().to(dtype).requires_grad_(True)
+        x = ME.SparseTensor(xf, torch.from_numpy(coords).to(DEV))
+        y = conv(x).F
+        gy = go.to(dtype)
+        y.backward(gy)
+        a = (y.double() * gy.double()).sum().item()
+        b = (xf.detach().double() * xf.grad.double()).sum().item()
+        c = (conv.kernel.detach().double() * conv.kernel.grad.double()).sum().item()
+        scale = (y.double().norm() * gy.double().norm()).item()
+        assert abs(a - b) / scale < tol, (dtype, a, b)
+        assert abs(a - c) / scale < tol, (dtype, a, c)
+
+
+def test_fullsize_linearity_and_bf16_vs_fp32(batch):
+    coords = batch
+    n, cin, cout = coords.shape[0], 96, 96
+    g = torch.Generator(device=DEV).manual_seed(1)
+    xa = torch.randn(n, cin, device=DEV, generator=g)
+    xb = torch.randn(n, cin, device=DEV, generator=g)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=3, dimension=3).to(DEV)
+    c = torch.from_numpy(coords).to(DEV)
+    with torch.no_grad():
+        sa = ME.SparseTensor(xa, c)
+        mk = dict(coordinate_map_key=sa.coordinate_map_key, coordinate_manager=sa.coordinate_manager)
+        ya = conv(sa).F
+        yb = conv(ME.SparseTensor(xb, **mk)).F
+        yc = conv(ME.SparseTensor(0.5 * xa - 2.0 * xb, **mk)).F
+        ref = 0.5 * ya - 2.0 * yb
+        assert (yc - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
+        y16 = conv(ME.SparseTensor(xa.bfloat16(), **mk)).F.float()
+        ya_r = conv(ME.SparseTensor(xa.bfloat16().float(), **mk)).F      # same rounded inputs, fp32 path
+        err = (y16 - ya_r).norm().item() / ya_r.norm().item()
+        assert err < 6e-3, err                                            # bf16 weights + bf16 output rounding
