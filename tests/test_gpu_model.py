@@ -159,3 +159,19 @@ def test_clip_pretrain_step_matches_oracle():
     assert abs(h[0] - o[0]) < 1e-4
     assert np.abs(h[1] - o[1]).max() < 1e-3
     assert np.linalg.norm(h[2] - o[2]) / np.linalg.norm(o[2]) < 2e-3
+
+
+def test_bf16_training_step_is_bitwise_reproducible():
+    """no atomics on floating-point data anywhere (fixed-order partial sums in wgrad / BN / slot-split conv, weight
+    gradients written by exactly one wave): the same step run twice gives bit-identical logits and gradients"""
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    coords, feats, _ = make_batch([1, 2], voxel=0.02, n_target=60000)
+    labels = np.random.default_rng(0).integers(-1, 20, coords.shape[0]).astype(np.int64)
+    runs = []
+    for _ in range(2):
+        logits, loss, grads, _ = run_model("Res16UNet14A", coords, feats, labels, DEV, dtype=torch.bfloat16)
+        runs.append((logits, loss, grads))
+    assert np.array_equal(runs[0][0], runs[1][0])
+    assert runs[0][1] == runs[1][1]
+    for k in runs[0][2]:
+        assert np.array_equal(runs[0][2][k], runs[1][2][k]), k
