@@ -387,17 +387,42 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_bf16(View v, const bf16_t *_
     }
 }
 
-__global__ void k_wgrad_reduce(const float *__restrict__ partial, int S, int K, int cin_pad, int cout_pad, int cin,
-                               int cout, float *__restrict__ gw) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t total = (int64_t)K * cin * cout;
+// gw[k][ci][co] = sum over the S partial slabs, fixed order.  One thread = 4 consecutive output channels (16-byte
+// loads, the padded slab rows are 128-byte aligned), four slabs in flight: the reduce reads S x K x Cin x Cout floats
+// (295 MB at level 0) and used to run as one dependent 4-byte load per slab and thread.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, int S, int K, int cin_pad, int cout_pad,
+                                                      int cin, int cout, float *__restrict__ gw) {
+  const int cq = (cout + 3) / 4;                       // channel quads per row
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)K * cin * cq;
   if (idx >= total) return;
-  int co = (int)(idx % cout);
-  int ci = (int)((idx / cout) % cin);
-  int k = (int)(idx / ((int64_t)cout * cin));
-  float s = 0.f;
-  for (int x = 0; x < S; ++x) s += partial[(((int64_t)x * K + k) * cin_pad + ci) * cout_pad + co];
-  gw[idx] = s;
+  const int q = (int)(idx % cq);
+  const int ci = (int)((idx / cq) % cin);
+  const int k = (int)(idx / ((int64_t)cq * cin));
+  const int64_t slab = (int64_t)K * cin_pad * cout_pad;
+  const float *src = partial + ((int64_t)k * cin_pad + ci) * cout_pad + 4 * q;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  int x = 0;
+  for (; x + 4 <= S; x += 4) {
+    const float4 v0 = *reinterpret_cast<const float4 *>(src + (int64_t)(x + 0) * slab);
+    const float4 v1 = *reinterpret_cast<const float4 *>(src + (int64_t)(x + 1) * slab);
+    const float4 v2 = *reinterpret_cast<const float4 *>(src + (int64_t)(x + 2) * slab);
+    const float4 v3 = *reinterpret_cast<const float4 *>(src + (int64_t)(x + 3) * slab);
+    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+    a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+    a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+  }
+  for (; x < S; ++x) {
+    const float4 v0 = *reinterpret_cast<const float4 *>(src + (int64_t)x * slab);
+    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+  }
+  const float r[4] = {(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                      (a0.w + a1.w) + (a2.w + a3.w)};
+  float *dst = gw + ((int64_t)k * cin + ci) * cout + 4 * q;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (4 * q + j < cout) dst[j] = r[j];
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -544,7 +569,7 @@ int conv_wgrad_bf16(const View &v, const void *in_v, int cin, const void *gout_v
   LGS_WG(4, 1) LGS_WG(4, 2) LGS_WG(4, 3)
   { LGS_REQUIRE(false, "bf16 wgrad: no kernel instance for this tile"); }
 #undef LGS_WG
-  int64_t total = (int64_t)v.K * cin_real * cout;
+  int64_t total = (int64_t)v.K * cin_real * ((cout + 3) / 4);
   hipLaunchKernelGGL(k_wgrad_reduce, (unsigned)((total + 255) / 256), 256, 0, s, partial, p.S, v.K, p.cin_pad, p.cout_pad, cin_real,
                      cout, gw);
   LGS_HIP(hipGetLastError());
@@ -567,7 +592,7 @@ int conv_wgrad_f32path(const View &v, const void *in_v, int cin, const void *gou
     case 2: hipLaunchKernelGGL((k_wgrad_f32<T, 2>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
     default: hipLaunchKernelGGL((k_wgrad_f32<T, 1>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
   }
-  int64_t total = (int64_t)v.K * cin * cout;
+  int64_t total = (int64_t)v.K * cin * ((cout + 3) / 4);
   hipLaunchKernelGGL(k_wgrad_reduce, (unsigned)((total + 255) / 256), 256, 0, s, partial, p.S, v.K, p.cin_pad, p.cout_pad, cin,
                      cout, gw);
   LGS_HIP(hipGetLastError());
