@@ -52,8 +52,8 @@ template <> __device__ inline void mma16<float>(f32x16 &acc, const u32x4 &w, con
 }
 
 // Missing neighbours / padded channels are not branched around (hipcc would fence every such load with
-// s_waitcnt vmcnt(0) and serialise the whole gather pipeline): their lane simply points at a zero page.
-constexpr int kZeroPage = 4096;  // bytes, at the start of every conv workspace
+// s_waitcnt vmcnt(0) and serialise the whole gather pipeline): their lane gets an out-of-range buffer offset, for
+// which the hardware returns zeros.
 
 // ------------------------------------------------------------------------------------ weight packing
 // dst[kd][c][nb][t][lane] (16 B each): element e of lane (j = lane&31, h = lane>>5) is
@@ -65,10 +65,9 @@ constexpr int kZeroPage = 4096;  // bytes, at the start of every conv workspace
 template <typename T>
 __global__ void k_pack_weights(const float *__restrict__ w, int K, int cin_w, int cout_w, int transposed, int mirror,
                                int g_real, int o_real, int nc /*padded chunks*/, int nb_total /*padded blocks*/,
-                               uint4 *__restrict__ dst, uint4 *__restrict__ zero_page) {
+                               uint4 *__restrict__ dst) {
   constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < kZeroPage / 16) zero_page[idx] = make_uint4(0, 0, 0, 0);  // the page missing neighbours are read from
   int64_t total = (int64_t)K * nc * nb_total * LD * 64;
   if (idx >= total) return;
   int lane = (int)(idx & 63);
@@ -470,11 +469,10 @@ inline int64_t split_partial_bytes(int K, int64_t n_out, int o_real) {
 }
 
 template <typename T>
-int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real, int nc, const uint4 *wp, const uint4 *zpage,
+int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real, int nc, const uint4 *wp,
                   int nb_total, int ncp, int nbp, int K, T *out, int cout_real, const float *bias, hipStream_t s,
                   float *out_f32 = nullptr, const float *row_scale = nullptr, float *zpartial = nullptr) {
   if (v.n_pad == 0) return 0;
-  (void)zpage;
   constexpr int LDc = Tr<T>::LD;
   const uint64_t in_bytes64 = (uint64_t)v.n_in * (uint64_t)cin_real * sizeof(T);
   const uint64_t w_bytes64 = (uint64_t)K * ncp * nbp * LDc * 64 * 16;
@@ -529,11 +527,10 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
   constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
   const int g_pad = pad32(g_real), nc = g_pad / 32, nb_total = pad32(o_real) / 32;
   char *ws = reinterpret_cast<char *>(workspace);
-  uint4 *zpage = reinterpret_cast<uint4 *>(ws);
-  uint4 *wp = reinterpret_cast<uint4 *>(ws + kZeroPage);
+  uint4 *wp = reinterpret_cast<uint4 *>(ws);
   const GatherCfg cfg = gather_cfg<T>(v, nb_total);
   const int ncp = (nc + cfg.sc - 1) / cfg.sc * cfg.sc, nbp = (nb_total + cfg.wb - 1) / cfg.wb * cfg.wb;
-  int64_t wbytes = kZeroPage + align256((int64_t)K * (nc + 3) * (nb_total + 3) * LD * 64 * 16);
+  int64_t wbytes = align256((int64_t)K * (nc + 3) * (nb_total + 3) * LD * 64 * 16);
   if (o_real % 4 != 0) {
     // rows are written in 4-channel groups: route odd widths (e.g. the 3-channel input gradient of a
     // test) through a 4-aligned scratch image placed after the packed weights and the padded input
@@ -562,13 +559,13 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
   }
   int64_t total = (int64_t)K * ncp * nbp * LD * 64;
   hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, weight, K, cin_w, cout_w, transposed_w,
-                     v.mirror, g_real, w_o_real, ncp, nbp, wp, zpage);
+                     v.mirror, g_real, w_o_real, ncp, nbp, wp);
   LGS_HIP(hipGetLastError());
   // fp32 partial images of the slot split live behind the packed weights and the padded input
   float *zpartial = nullptr;
   if (w_o_real == o_real && split_partial_bytes(K, v.n_out, o_real) > 0)
     zpartial = reinterpret_cast<float *>(ws + wbytes + ((g_real % EPL != 0) ? align256(v.n_in * (int64_t)g_pad * (int64_t)sizeof(T)) : 0));
-  return launch_gather<T>(v, cfg, in, g_stride, nc, wp, zpage, nb_total, ncp, nbp, K, reinterpret_cast<T *>(out_v), o_real, bias, s,
+  return launch_gather<T>(v, cfg, in, g_stride, nc, wp, nb_total, ncp, nbp, K, reinterpret_cast<T *>(out_v), o_real, bias, s,
                           nullptr, nullptr, zpartial);
 }
 
@@ -609,9 +606,8 @@ int clip_similarity_t(const void *feat, int64_t n, int c, const float *anchors, 
   if (n == 0) return 0;
   const int nc = pad32(c) / 32, nb_total = pad32(na) / 32;
   char *ws = reinterpret_cast<char *>(workspace);
-  uint4 *zpage = reinterpret_cast<uint4 *>(ws);
-  float *tn = reinterpret_cast<float *>(ws + kZeroPage);
-  int64_t off = kZeroPage + align256((int64_t)na * c * 4);
+  float *tn = reinterpret_cast<float *>(ws);
+  int64_t off = align256((int64_t)na * c * 4);
   uint4 *wp = reinterpret_cast<uint4 *>(ws + off);
   off += align256((int64_t)(nc + 3) * (nb_total + 3) * LD * 64 * 16);
   float *inv = inv_norm_f ? inv_norm_f : reinterpret_cast<float *>(ws + off);
@@ -623,10 +619,10 @@ int clip_similarity_t(const void *feat, int64_t n, int c, const float *anchors, 
   const int ncp = (nc + cfg.sc - 1) / cfg.sc * cfg.sc, nbp = (nb_total + cfg.wb - 1) / cfg.wb * cfg.wb;
   int64_t total = (int64_t)ncp * nbp * LD * 64;
   // T^[a][c] read as w[o = a][g = c]  ("transposed" form of the packer with cin_w = na, cout_w = c)
-  hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, tn, 1, na, c, 1, 0, c, na, ncp, nbp, wp, zpage);
+  hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, tn, 1, na, c, 1, 0, c, na, ncp, nbp, wp);
   hipLaunchKernelGGL((k_row_invnorm<T>), (unsigned)((n * 64 + 255) / 256), 256, 0, s, f, n, c, inv);
   LGS_HIP(hipGetLastError());
-  return launch_gather<T>(v, cfg, f, c, nc, wp, zpage, nb_total, ncp, nbp, 1, (T *)nullptr, na, nullptr, s, sim, inv);
+  return launch_gather<T>(v, cfg, f, c, nc, wp, nb_total, ncp, nbp, 1, (T *)nullptr, na, nullptr, s, sim, inv);
 }
 
 }  // namespace lgs
@@ -640,7 +636,7 @@ int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtyp
   const int e = esize(dtype);
   if (op == 2) return lgs::wgrad_workspace_bytes(km, cin, cout, dtype);
   int g = op == 0 ? cin : cout, o = op == 0 ? cout : cin;
-  int64_t bytes = kZeroPage + align256((int64_t)km->K * (pad32(g) + 96) * (pad32(o) + 96) * e);
+  int64_t bytes = align256((int64_t)km->K * (pad32(g) + 96) * (pad32(o) + 96) * e);
   int64_t nmax = km->fwd.n_in > km->bwd.n_in ? km->fwd.n_in : km->bwd.n_in;
   if (g % epl(dtype) != 0) bytes += align256(nmax * pad32(g) * e);
   if (o % 4 != 0) bytes += align256(nmax * (int64_t)((o + 3) / 4 * 4) * e);
@@ -680,7 +676,7 @@ int lgs_conv_dgrad(lgs_kmap *km, int transposed, const void *grad_out, int cout,
 extern "C" {
 
 int64_t lgs_clip_workspace_bytes(int c, int n_anchor, int dtype) {
-  int64_t b = kZeroPage + align256((int64_t)n_anchor * c * 4) + align256((int64_t)(pad32(c) + 96) * (pad32(n_anchor) + 96) * esize(dtype));
+  int64_t b = align256((int64_t)n_anchor * c * 4) + align256((int64_t)(pad32(c) + 96) * (pad32(n_anchor) + 96) * esize(dtype));
   return b + 256;
 }
 

@@ -127,7 +127,6 @@ __global__ __launch_bounds__(256) void k_wgrad_f32(View v, const T *__restrict__
 
 // ------------------------------------------------------------------------------------ bf16 MFMA path
 constexpr int kQ = 1024;       // positions compacted per wave chunk
-constexpr int kWgZero = 4096;  // zero page at the start of the wgrad workspace (missing rows point here: branch-free loads)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // row stride (bytes) of a [16 pairs][C channels] bf16 tile, = 64 (mod 256) -> conflict-free tr reads
@@ -506,7 +505,7 @@ inline WgradPlan wgrad_plan(const View &v, int cin, int cout, int dtype) {
 int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype) {
   WgradPlan a = wgrad_plan(km->fwd, cin, cout, dtype), b = wgrad_plan(km->bwd, cin, cout, dtype);
   int64_t per = (int64_t)km->K * pad32(cin) * pad32(cout) * 4;
-  int64_t bytes = kWgZero + align256((int64_t)(a.S > b.S ? a.S : b.S) * per) + 256;
+  int64_t bytes = align256((int64_t)(a.S > b.S ? a.S : b.S) * per) + 256;
   if (dtype == LGS_BF16 && cin % 8 != 0) {
     int64_t nmax = km->fwd.n_in > km->bwd.n_in ? km->fwd.n_in : km->bwd.n_in;
     bytes += align256(nmax * (int64_t)((cin + 7) / 8 * 8) * 2);
@@ -550,12 +549,12 @@ int conv_wgrad_bf16(const View &v, const void *in_v, int cin, const void *gout_v
   LGS_REQUIRE(cout % 8 == 0, "bf16 wgrad: output channel count must be a multiple of 8 (16-byte rows)");
   WgradPlan p = wgrad_plan(v, cin, cout, LGS_BF16);
   char *wsb = reinterpret_cast<char *>(workspace);
-  float *partial = reinterpret_cast<float *>(wsb + kWgZero);
+  float *partial = reinterpret_cast<float *>(wsb);
   const bf16_t *in = reinterpret_cast<const bf16_t *>(in_v), *go = reinterpret_cast<const bf16_t *>(gout_v);
   const int cin_real = cin;
   if (cin % 8 != 0) {  // e.g. the 3-channel colour input of conv0p1s1: zero-pad rows to 8 channels behind the partials
     const int c8 = (cin + 7) / 8 * 8;
-    bf16_t *padded = reinterpret_cast<bf16_t *>(wsb + kWgZero + align256((int64_t)p.S * v.K * p.cin_pad * p.cout_pad * 4));
+    bf16_t *padded = reinterpret_cast<bf16_t *>(wsb + align256((int64_t)p.S * v.K * p.cin_pad * p.cout_pad * 4));
     int64_t tot = v.n_in * (int64_t)c8;
     if (tot > 0) hipLaunchKernelGGL(k_pad_rows_bf16, (unsigned)((tot + 255) / 256), 256, 0, s, in, v.n_in, cin, c8, padded);
     in = padded;
