@@ -551,11 +551,14 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
   const T *in = reinterpret_cast<const T *>(in_v);
   int g_stride = g_real;
   if (g_real % EPL != 0) {  // e.g. the 3-channel colour input of conv0p1s1
+    // rows are padded to ONE 16-byte piece multiple (3 -> 8 bf16 / 4 fp32 channels), not to the 32-channel chunk: the
+    // pieces beyond the row are masked by the gather's channel-tail test, so neighbours cost 16 instead of 64 bytes
     T *padded = reinterpret_cast<T *>(ws + wbytes);
-    int64_t tot = v.n_in * g_pad;
-    if (tot > 0) hipLaunchKernelGGL((k_pad_rows<T>), (unsigned)((tot + 255) / 256), 256, 0, s, in, v.n_in, g_real, g_pad, padded);
+    const int g_al = (g_real + EPL - 1) / EPL * EPL;
+    int64_t tot = v.n_in * g_al;
+    if (tot > 0) hipLaunchKernelGGL((k_pad_rows<T>), (unsigned)((tot + 255) / 256), 256, 0, s, in, v.n_in, g_real, g_al, padded);
     in = padded;
-    g_stride = g_pad;
+    g_stride = g_al;
   }
   int64_t total = (int64_t)K * ncp * nbp * LD * 64;
   hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, weight, K, cin_w, cout_w, transposed_w,
