@@ -130,10 +130,12 @@ int lgs_bn_forward(const void *x, int64_t n, int c, const float *gamma, const fl
 /* Backward of the fused op.  x = forward input, stats = the forward's mean/invstd.
  * relu: 0 = none; 1 = ReLU mask taken from the forward OUTPUT y (required when a residual was added);
  *       2 = mask recomputed from x as (xhat*gamma + beta > 0), y may be NULL (one tensor read fewer).
- * Writes dx, dgamma[C], dbeta[C]; if dresidual != NULL also the gradient flowing to the residual (= masked dy). */
-int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
-                    const float *beta, const float *stats, int relu, void *dx, void *dresidual, float *dgamma,
-                    float *dbeta, int dtype, void *workspace, void *stream);
+ * Writes dx, dgamma[C], dbeta[C]; if dresidual != NULL also the gradient flowing to the residual (= masked dy).
+ * dy_row_stride (elements, 0 = C): dy may be a column slice of a wider row-major tensor -- the gradient of one input
+ * of ME.cat (res16unet.py:233-262) is exactly that, and reading it in place saves a copy of the whole slice. */
+int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t dy_row_stride, int64_t n, int c,
+                    const float *gamma, const float *beta, const float *stats, int relu, void *dx, void *dresidual,
+                    float *dgamma, float *dbeta, int dtype, void *workspace, void *stream);
 
 /* The same op in two halves per direction, so that data-parallel training can exchange the statistics between
  * ranks in the middle (ME.MinkowskiSyncBatchNorm, /root/reference/main.py:122-123):

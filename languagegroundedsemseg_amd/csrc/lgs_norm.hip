@@ -62,7 +62,7 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy,
                                                    const float *__restrict__ stats, const float *__restrict__ gamma,
                                                    const float *__restrict__ beta, int64_t n, int c, int relu,
-                                                   int64_t rows_per_block, float *__restrict__ scratch) {
+                                                   int64_t rows_per_block, float *__restrict__ scratch, int64_t dy_ld) {
   constexpr int W = Vec<T>::W;
   const int G = c / W;              // channel groups per row
   const int RL = kNT / G;           // rows in flight per block iteration (G <= 256)
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, cons
         const int64_t o = (r + u * RL) * c + cg * W;
         Vec<T>::load(x + o, xv[u]);
         if (MODE == 1) {
-          Vec<T>::load(dy + o, gv[u]);
+          Vec<T>::load(dy + (r + u * RL) * dy_ld + cg * W, gv[u]);
           if (relu == 1) Vec<T>::load(y + o, yv[u]);
         }
       }
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, cons
       const int64_t o = r * c + cg * W;
       Vec<T>::load(x + o, xv);
       if (MODE == 1) {
-        Vec<T>::load(dy + o, gv);
+        Vec<T>::load(dy + r * dy_ld + cg * W, gv);
         if (relu == 1) Vec<T>::load(y + o, yv);
       }
       accumulate(xv, gv, yv);
@@ -273,7 +273,8 @@ __global__ __launch_bounds__(kNT) void k_bn_bwd_apply(const T *__restrict__ x, c
                                                       int64_t n, int c, const float *__restrict__ gamma,
                                                       const float *__restrict__ beta,
                                                       const float *__restrict__ stats, const float *__restrict__ sums,
-                                                      float inv_n, int relu, T *__restrict__ dx, T *__restrict__ dres) {
+                                                      float inv_n, int relu, T *__restrict__ dx, T *__restrict__ dres,
+                                                      int64_t dy_ld) {
   constexpr int W = Vec<T>::W;
   const int G = c / W, RL = kNT / G;
   const int cg = threadIdx.x % G, rl = threadIdx.x / G;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(kNT) void k_bn_bwd_apply(const T *__restrict__ x, c
     const int64_t o = r * c + cg * W;
     float xv[W], gv[W];
     Vec<T>::load(x + o, xv);
-    Vec<T>::load(dy + o, gv);
+    Vec<T>::load(dy + r * dy_ld + cg * W, gv);
     if (relu == 1) {
       float yv[W];
       Vec<T>::load(y + o, yv);
@@ -335,7 +336,7 @@ int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const flo
   float *scratch = reinterpret_cast<float *>(workspace);  // caller-owned: no allocator call (and no implicit sync) here
   const T *x = reinterpret_cast<const T *>(xv);
   hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, n, c, 0,
-                     rpb, scratch);
+                     rpb, scratch, (int64_t)c);
   hipLaunchKernelGGL((k_fold_fwd<T>), (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, x, nb, c, n, eps, momentum, rm, rv, nbt, stats);
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
@@ -350,7 +351,7 @@ int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const flo
 template <typename T>
 int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *gamma, const float *beta,
                   const float *stats, int relu, void *dxv, void *dresv, float *dgamma, float *dbeta, void *workspace,
-                  hipStream_t s) {
+                  hipStream_t s, int64_t dy_ld) {
   constexpr int W = Vec<T>::W;
   LGS_REQUIRE(c % W == 0 && c / W <= kNT && c <= 2048, "lgs_bn_backward: channel count unsupported");
   int64_t rpb;
@@ -358,13 +359,13 @@ int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, in
   float *scratch = reinterpret_cast<float *>(workspace);
   float *sums = scratch + (size_t)2 * c * nb;
   const T *x = reinterpret_cast<const T *>(xv), *y = reinterpret_cast<const T *>(yv), *dy = reinterpret_cast<const T *>(dyv);
-  hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, x, y, dy, stats, gamma, beta, n, c, relu, rpb, scratch);
+  hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, x, y, dy, stats, gamma, beta, n, c, relu, rpb, scratch, dy_ld);
   hipLaunchKernelGGL(k_fold_bwd, (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, nb, c, dgamma, dbeta, sums);
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
     hipLaunchKernelGGL((k_bn_bwd_apply<T>), grid, kNT, 0, s, x, y, dy, n, c, gamma, beta, stats, sums, n > 0 ? 1.f / (float)n : 0.f, relu, reinterpret_cast<T *>(dxv),
-                       reinterpret_cast<T *>(dresv));
+                       reinterpret_cast<T *>(dresv), dy_ld);
   }
   LGS_HIP(hipGetLastError());
   return 0;
@@ -379,7 +380,7 @@ int bn_stats_t(const void *xv, int64_t n, int c, float *mean_m2, void *workspace
   float *scratch = reinterpret_cast<float *>(workspace);
   const T *x = reinterpret_cast<const T *>(xv);
   hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, n, c, 0,
-                     rpb, scratch);
+                     rpb, scratch, (int64_t)c);
   hipLaunchKernelGGL((k_fold_stats<T>), (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, x, nb, c, n, mean_m2);
   LGS_HIP(hipGetLastError());
   return 0;
@@ -408,7 +409,7 @@ int bn_bwd_reduce_t(const void *xv, const void *yv, const void *dyv, int64_t n, 
   float *scratch = reinterpret_cast<float *>(workspace);
   float *tmp = scratch + (size_t)2 * c * nb;  // dgamma/dbeta duplicates (unused by the caller)
   hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
-                     reinterpret_cast<const T *>(dyv), stats, gamma, beta, n, c, relu, rpb, scratch);
+                     reinterpret_cast<const T *>(dyv), stats, gamma, beta, n, c, relu, rpb, scratch, (int64_t)c);
   hipLaunchKernelGGL(k_fold_bwd, (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, nb, c, tmp + c, tmp, sums);
   LGS_HIP(hipGetLastError());
   return 0;
@@ -423,7 +424,7 @@ int bn_bwd_apply_t(const void *xv, const void *yv, const void *dyv, int64_t n, i
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
     hipLaunchKernelGGL((k_bn_bwd_apply<T>), grid, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
                        reinterpret_cast<const T *>(dyv), n, c, gamma, beta, stats, sums, inv_n_total, relu, reinterpret_cast<T *>(dxv),
-                       reinterpret_cast<T *>(dresv));
+                       reinterpret_cast<T *>(dresv), (int64_t)c);
   }
   LGS_HIP(hipGetLastError());
   return 0;
@@ -485,15 +486,19 @@ int lgs_bn_forward(const void *x, int64_t n, int c, const float *gamma, const fl
   LGS_REQUIRE(false, "lgs_bn_forward: unknown dtype");
 }
 
-int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma, const float *beta,
-                    const float *stats, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta, int dtype,
-                    void *workspace, void *stream) {
+int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t dy_row_stride, int64_t n, int c, const float *gamma,
+                    const float *beta, const float *stats, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta,
+                    int dtype, void *workspace, void *stream) {
   LGS_REQUIRE(x && dy && dx && gamma && stats && dgamma && dbeta && workspace, "lgs_bn_backward: null argument");
+  const int64_t dy_ld = dy_row_stride > 0 ? dy_row_stride : c;
+  LGS_REQUIRE(dy_ld >= c && dy_ld % (dtype == LGS_BF16 ? 8 : 4) == 0 &&
+                  (reinterpret_cast<uintptr_t>(dy) & 15u) == 0,
+              "lgs_bn_backward: dy rows must start 16-byte aligned (row stride a multiple of 16 bytes)");
   LGS_REQUIRE(relu != 1 || y, "lgs_bn_backward: relu mode 1 needs the forward output");
   LGS_REQUIRE(relu != 2 || beta, "lgs_bn_backward: relu mode 2 needs beta");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == LGS_F32) return bn_backward_t<float>(x, y, dy, n, c, gamma, beta, stats, relu, dx, dresidual, dgamma, dbeta, workspace, s);
-  if (dtype == LGS_BF16) return bn_backward_t<bf16_t>(x, y, dy, n, c, gamma, beta, stats, relu, dx, dresidual, dgamma, dbeta, workspace, s);
+  if (dtype == LGS_F32) return bn_backward_t<float>(x, y, dy, n, c, gamma, beta, stats, relu, dx, dresidual, dgamma, dbeta, workspace, s, dy_ld);
+  if (dtype == LGS_BF16) return bn_backward_t<bf16_t>(x, y, dy, n, c, gamma, beta, stats, relu, dx, dresidual, dgamma, dbeta, workspace, s, dy_ld);
   LGS_REQUIRE(false, "lgs_bn_backward: unknown dtype");
 }
 

@@ -63,7 +63,7 @@ def lib():
         "lgs_conv_dgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp],
         "lgs_conv_wgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp],
         "lgs_bn_forward": [vp, i64, ci, vp, vp, cf, cf, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp],
-        "lgs_bn_backward": [vp, vp, vp, i64, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp],
+        "lgs_bn_backward": [vp, vp, vp, i64, i64, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp],
         "lgs_bn_stats": [vp, i64, ci, vp, ci, vp, vp],
         "lgs_bn_apply": [vp, i64, ci, vp, vp, vp, vp, ci, vp, ci, vp],
         "lgs_bn_backward_reduce": [vp, vp, vp, i64, ci, vp, vp, vp, ci, vp, ci, vp, vp],

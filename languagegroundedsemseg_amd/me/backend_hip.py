@@ -225,16 +225,23 @@ class HipBackend:
     def bn_backward(self, x, y, dy, gamma, beta, stats, relu, want_residual, dgamma_out=None, dbeta_out=None):
         """relu: 0 none, 1 mask from y, 2 mask recomputed from x (y may be None)"""
         L = engine.lib()
-        dy = dy.contiguous()
         n, c = x.shape
         dt = _dtype_code(x)
+        # a column slice of a wider row-major tensor (the gradient of one ME.cat input) is read in place
+        esz = dy.element_size()
+        if (dy.dim() == 2 and dy.stride(1) == 1 and dy.stride(0) >= c and (dy.stride(0) * esz) % 16 == 0
+                and dy.data_ptr() % 16 == 0 and dy.dtype == x.dtype):
+            dy_ld = dy.stride(0)
+        else:
+            dy = dy.contiguous()
+            dy_ld = c
         with torch.cuda.device(x.device):
             dx = torch.empty_like(x)
             dres = torch.empty_like(x) if want_residual else None
             dgamma = dgamma_out if dgamma_out is not None else torch.empty(c, dtype=torch.float32, device=x.device)
             dbeta = dbeta_out if dbeta_out is not None else torch.empty(c, dtype=torch.float32, device=x.device)
             ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
-            engine.check(L.lgs_bn_backward(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), int(relu), _ptr(dx),
+            engine.check(L.lgs_bn_backward(_ptr(x), _ptr(y), _ptr(dy), int(dy_ld), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), int(relu), _ptr(dx),
                                            _ptr(dres), _ptr(dgamma), _ptr(dbeta), dt, _ptr(ws), _stream()))
         return dx, dres, dgamma, dbeta
 

@@ -329,3 +329,22 @@ def test_contrastive_loss_on_mfma_matches_reference_golden():
         assert abs(float(loss) - float(g("total"))) < 1e-5
         loss.backward()
         assert torch.isfinite(F.grad).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_backward_reads_a_column_slice_in_place(dtype):
+    """the gradient of one ME.cat input is a column slice of a wider tensor: lgs_bn_backward(dy_row_stride) must give
+    bit-identical results to the contiguous copy"""
+    be = ME.get_backend()
+    torch.manual_seed(3)
+    n, c, wide = 4097, 96, 128
+    x = torch.randn(n, c, device=DEV).to(dtype)
+    g1, b1 = torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV) * 0.1
+    y, st = be.bn_forward(x, g1, b1, 1e-5, 0.1, None, None, None, 1)
+    big = torch.randn(n, wide, device=DEV).to(dtype)
+    for off in (0, 32):
+        dy = big[:, off:off + c]
+        assert not dy.is_contiguous()
+        a = be.bn_backward(x, None, dy, g1, b1, st, 2, False)
+        b = be.bn_backward(x, None, dy.contiguous(), g1, b1, st, 2, False)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
