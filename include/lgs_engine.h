@@ -137,21 +137,30 @@ int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t dy_row
                     const float *gamma, const float *beta, const float *stats, int relu, void *dx, void *dresidual,
                     float *dgamma, float *dbeta, int dtype, void *workspace, void *stream);
 
-/* The same op in two halves per direction, so that data-parallel training can exchange the statistics between
- * ranks in the middle (ME.MinkowskiSyncBatchNorm, /root/reference/main.py:122-123):
- *   lgs_bn_stats           -> mean_m2[2C] = local mean, local M2 (sum of squared deviations from the local mean)
- *   lgs_bn_apply           <- stats[2C] = (global) mean, invstd
- *   lgs_bn_backward_reduce -> sums[2C] = local sum dy', local sum dy' * xhat   (dy' = dy masked by ReLU)
- *   lgs_bn_backward_apply  <- sums[2C] (all-reduced), inv_n_total = 1 / global row count */
-int lgs_bn_stats(const void *x, int64_t n, int c, float *mean_m2, int dtype, void *workspace, void *stream);
+/* The same op in halves, so that data-parallel training can exchange the statistics between ranks in the middle
+ * (ME.MinkowskiSyncBatchNorm, /root/reference/main.py:122-123) with one small collective per direction and NO host-side
+ * tensor arithmetic in between:
+ *   lgs_bn_stats           -> rec[2C+1] = local mean[C], local M2[C] (sum of squared deviations from it), row count
+ *   (all-gather of the records of all ranks: all_stats[world][2C+1])
+ *   lgs_bn_sync_combine    -> stats[2C] = global mean, invstd (Chan's parallel formula, double); updates running_mean /
+ *                             running_var / num_batches_tracked (each may be NULL); *inv_n_total = 1 / global rows
+ *   lgs_bn_apply           <- stats[2C]
+ *   lgs_bn_backward_reduce -> sums[2C] = local sum dy', local sum dy' * xhat (dy' = dy masked by ReLU); the same two
+ *                             vectors also go to dgamma / dbeta (may be NULL): parameter gradients stay local
+ *   (all-reduce of sums)
+ *   lgs_bn_backward_apply  <- sums[2C] (all-reduced), 1/N either by value (inv_n_total) or, if inv_n_device != NULL,
+ *                             read from the device scalar lgs_bn_sync_combine wrote (no host sync) */
+int lgs_bn_stats(const void *x, int64_t n, int c, float *rec /* [2C+1] */, int dtype, void *workspace, void *stream);
+int lgs_bn_sync_combine(const float *all_stats, int world, int c, float eps, float momentum, float *running_mean,
+                        float *running_var, int64_t *num_batches_tracked, float *stats, float *inv_n_total, void *stream);
 int lgs_bn_apply(const void *x, int64_t n, int c, const float *gamma, const float *beta, const float *stats,
                  const void *residual, int relu, void *y, int dtype, void *stream);
 int lgs_bn_backward_reduce(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
-                           const float *beta, const float *stats, int relu, float *sums, int dtype, void *workspace,
-                           void *stream);
+                           const float *beta, const float *stats, int relu, float *sums, float *dgamma, float *dbeta,
+                           int dtype, void *workspace, void *stream);
 int lgs_bn_backward_apply(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
-                          const float *beta, const float *stats, const float *sums, float inv_n_total, int relu, void *dx,
-                          void *dresidual, int dtype, void *stream);
+                          const float *beta, const float *stats, const float *sums, float inv_n_total,
+                          const float *inv_n_device, int relu, void *dx, void *dresidual, int dtype, void *stream);
 
 /* ---- CLIP text-anchor contraction (MFMA) ----------------------------------------------------
  * replaces ContrastiveLanguageLoss.feat_dist (cos) + feature_sim

@@ -205,6 +205,7 @@ __global__ __launch_bounds__(256) void k_fold_stats(const float *__restrict__ sc
   if (m2 < 0.0) m2 = 0.0;
   mean_m2[ch] = (float)(pivot + dm);
   mean_m2[c + ch] = (float)m2;
+  if (ch == 0) mean_m2[2 * c] = (float)n;   // [mean | M2 | count]: one packed all-gather per layer
 }
 
 __global__ __launch_bounds__(256) void k_fold_bwd(const float *__restrict__ scratch, int nblocks, int c, float *__restrict__ dgamma,
@@ -218,6 +219,38 @@ __global__ __launch_bounds__(256) void k_fold_bwd(const float *__restrict__ scra
   dgamma[ch] = (float)ss;
   sums[ch] = (float)s;
   sums[c + ch] = (float)ss;
+}
+
+// SyncBN: combine the per-rank [mean | M2 | count] records (Chan's parallel formula, double) into the global
+// mean / invstd, update the running statistics and num_batches_tracked, and leave 1/N for the backward pass
+__global__ void k_sync_combine(const float *__restrict__ all_stats, int world, int c, float eps, float momentum,
+                               float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ nbt,
+                               float *__restrict__ stats, float *__restrict__ inv_n_out) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  const int rec = 2 * c + 1;
+  double n = 0.0;
+  for (int r = 0; r < world; ++r) n += (double)all_stats[(int64_t)r * rec + 2 * c];
+  if (ch == 0) {
+    if (inv_n_out) *inv_n_out = n > 0.0 ? (float)(1.0 / n) : 0.f;
+    if (nbt) *nbt += 1;
+  }
+  if (ch >= c) return;
+  double mean = 0.0;
+  for (int r = 0; r < world; ++r) mean += (double)all_stats[(int64_t)r * rec + 2 * c] * (double)all_stats[(int64_t)r * rec + ch];
+  mean = n > 0.0 ? mean / n : 0.0;
+  double m2 = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const double d = (double)all_stats[(int64_t)r * rec + ch] - mean;
+    m2 += (double)all_stats[(int64_t)r * rec + c + ch] + (double)all_stats[(int64_t)r * rec + 2 * c] * d * d;
+  }
+  const double var = n > 0.0 ? m2 / n : 0.0;
+  stats[ch] = (float)mean;
+  stats[c + ch] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unb = n > 1.0 ? m2 / (n - 1.0) : var;
+    running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+    running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+  }
 }
 
 // y = relu?( (x - mean) * invstd * gamma + beta (+ residual) )
@@ -274,12 +307,13 @@ __global__ __launch_bounds__(kNT) void k_bn_bwd_apply(const T *__restrict__ x, c
                                                       const float *__restrict__ beta,
                                                       const float *__restrict__ stats, const float *__restrict__ sums,
                                                       float inv_n, int relu, T *__restrict__ dx, T *__restrict__ dres,
-                                                      int64_t dy_ld) {
+                                                      int64_t dy_ld, const float *__restrict__ inv_n_dev) {
   constexpr int W = Vec<T>::W;
   const int G = c / W, RL = kNT / G;
   const int cg = threadIdx.x % G, rl = threadIdx.x / G;
   if (rl >= RL) return;
   float mean[W], istd[W], sc[W], bt[W], gi[W], m1[W], m2[W];
+  if (inv_n_dev) inv_n = *inv_n_dev;   // SyncBN: 1 / global row count lives on the device (no host sync)
 #pragma unroll
   for (int k = 0; k < W; ++k) {
     const int ch = cg * W + k;
@@ -365,7 +399,7 @@ int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, in
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
     hipLaunchKernelGGL((k_bn_bwd_apply<T>), grid, kNT, 0, s, x, y, dy, n, c, gamma, beta, stats, sums, n > 0 ? 1.f / (float)n : 0.f, relu, reinterpret_cast<T *>(dxv),
-                       reinterpret_cast<T *>(dresv), dy_ld);
+                       reinterpret_cast<T *>(dresv), dy_ld, (const float *)nullptr);
   }
   LGS_HIP(hipGetLastError());
   return 0;
@@ -401,22 +435,23 @@ int bn_apply_t(const void *xv, int64_t n, int c, const float *gamma, const float
 }
 template <typename T>
 int bn_bwd_reduce_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *gamma, const float *beta,
-                    const float *stats, int relu, float *sums, void *workspace, hipStream_t s) {
+                    const float *stats, int relu, float *sums, float *dgamma, float *dbeta, void *workspace, hipStream_t s) {
   constexpr int W = Vec<T>::W;
   LGS_REQUIRE(c % W == 0 && c / W <= kNT && c <= 2048, "lgs_bn_backward_reduce: channel count unsupported");
   int64_t rpb;
   int nb = reduce_blocks(n, &rpb);
   float *scratch = reinterpret_cast<float *>(workspace);
-  float *tmp = scratch + (size_t)2 * c * nb;  // dgamma/dbeta duplicates (unused by the caller)
+  float *tmp = scratch + (size_t)2 * c * nb;  // dgamma/dbeta land here when the caller does not want them
   hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
                      reinterpret_cast<const T *>(dyv), stats, gamma, beta, n, c, relu, rpb, scratch, (int64_t)c);
-  hipLaunchKernelGGL(k_fold_bwd, (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, nb, c, tmp + c, tmp, sums);
+  hipLaunchKernelGGL(k_fold_bwd, (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, nb, c, dgamma ? dgamma : tmp + c, dbeta ? dbeta : tmp, sums);
   LGS_HIP(hipGetLastError());
   return 0;
 }
 template <typename T>
 int bn_bwd_apply_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *gamma, const float *beta,
-                   const float *stats, const float *sums, float inv_n_total, int relu, void *dxv, void *dresv, hipStream_t s) {
+                   const float *stats, const float *sums, float inv_n_total, const float *inv_n_dev, int relu, void *dxv, void *dresv,
+                   hipStream_t s) {
   constexpr int W = Vec<T>::W;
   LGS_REQUIRE(c % W == 0 && c / W <= kNT, "lgs_bn_backward_apply: channel count unsupported");
   int64_t total = n * (int64_t)(c / W);
@@ -424,7 +459,7 @@ int bn_bwd_apply_t(const void *xv, const void *yv, const void *dyv, int64_t n, i
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
     hipLaunchKernelGGL((k_bn_bwd_apply<T>), grid, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
                        reinterpret_cast<const T *>(dyv), n, c, gamma, beta, stats, sums, inv_n_total, relu, reinterpret_cast<T *>(dxv),
-                       reinterpret_cast<T *>(dresv), (int64_t)c);
+                       reinterpret_cast<T *>(dresv), (int64_t)c, inv_n_dev);
   }
   LGS_HIP(hipGetLastError());
   return 0;
@@ -449,24 +484,32 @@ int lgs_bn_apply(const void *x, int64_t n, int c, const float *gamma, const floa
   if (dtype == LGS_BF16) return bn_apply_t<bf16_t>(x, n, c, gamma, beta, stats, residual, relu, y, (hipStream_t)stream);
   LGS_REQUIRE(false, "lgs_bn_apply: unknown dtype");
 }
+int lgs_bn_sync_combine(const float *all_stats, int world, int c, float eps, float momentum, float *running_mean,
+                        float *running_var, int64_t *num_batches_tracked, float *stats, float *inv_n_total, void *stream) {
+  LGS_REQUIRE(all_stats && stats && world > 0 && c > 0, "lgs_bn_sync_combine: bad argument");
+  hipLaunchKernelGGL(k_sync_combine, (unsigned)((c + 127) / 128), 128, 0, (hipStream_t)stream, all_stats, world, c, eps, momentum,
+                     running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), stats, inv_n_total);
+  LGS_HIP(hipGetLastError());
+  return 0;
+}
 int lgs_bn_backward_reduce(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
-                           const float *beta, const float *stats, int relu, float *sums, int dtype, void *workspace,
-                           void *stream) {
+                           const float *beta, const float *stats, int relu, float *sums, float *dgamma, float *dbeta, int dtype,
+                           void *workspace, void *stream) {
   LGS_REQUIRE(x && dy && stats && sums && workspace, "lgs_bn_backward_reduce: null argument");
   LGS_REQUIRE(relu != 1 || y, "lgs_bn_backward_reduce: relu mode 1 needs the forward output");
   LGS_REQUIRE(relu != 2 || (gamma && beta), "lgs_bn_backward_reduce: relu mode 2 needs gamma and beta");
-  if (dtype == LGS_F32) return bn_bwd_reduce_t<float>(x, y, dy, n, c, gamma, beta, stats, relu, sums, workspace, (hipStream_t)stream);
-  if (dtype == LGS_BF16) return bn_bwd_reduce_t<bf16_t>(x, y, dy, n, c, gamma, beta, stats, relu, sums, workspace, (hipStream_t)stream);
+  if (dtype == LGS_F32) return bn_bwd_reduce_t<float>(x, y, dy, n, c, gamma, beta, stats, relu, sums, dgamma, dbeta, workspace, (hipStream_t)stream);
+  if (dtype == LGS_BF16) return bn_bwd_reduce_t<bf16_t>(x, y, dy, n, c, gamma, beta, stats, relu, sums, dgamma, dbeta, workspace, (hipStream_t)stream);
   LGS_REQUIRE(false, "lgs_bn_backward_reduce: unknown dtype");
 }
 int lgs_bn_backward_apply(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
-                          const float *beta, const float *stats, const float *sums, float inv_n_total, int relu, void *dx,
-                          void *dresidual, int dtype, void *stream) {
+                          const float *beta, const float *stats, const float *sums, float inv_n_total,
+                          const float *inv_n_device, int relu, void *dx, void *dresidual, int dtype, void *stream) {
   LGS_REQUIRE(x && dy && dx && gamma && stats && sums, "lgs_bn_backward_apply: null argument");
   LGS_REQUIRE(relu != 1 || y, "lgs_bn_backward_apply: relu mode 1 needs the forward output");
   LGS_REQUIRE(relu != 2 || beta, "lgs_bn_backward_apply: relu mode 2 needs beta");
-  if (dtype == LGS_F32) return bn_bwd_apply_t<float>(x, y, dy, n, c, gamma, beta, stats, sums, inv_n_total, relu, dx, dresidual, (hipStream_t)stream);
-  if (dtype == LGS_BF16) return bn_bwd_apply_t<bf16_t>(x, y, dy, n, c, gamma, beta, stats, sums, inv_n_total, relu, dx, dresidual, (hipStream_t)stream);
+  if (dtype == LGS_F32) return bn_bwd_apply_t<float>(x, y, dy, n, c, gamma, beta, stats, sums, inv_n_total, inv_n_device, relu, dx, dresidual, (hipStream_t)stream);
+  if (dtype == LGS_BF16) return bn_bwd_apply_t<bf16_t>(x, y, dy, n, c, gamma, beta, stats, sums, inv_n_total, inv_n_device, relu, dx, dresidual, (hipStream_t)stream);
   LGS_REQUIRE(false, "lgs_bn_backward_apply: unknown dtype");
 }
 

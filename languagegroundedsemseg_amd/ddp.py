@@ -214,48 +214,49 @@ class _SyncBNFused(torch.autograd.Function):
     combination -> fused normalise(+residual)(+ReLU); backward: local sums -> ONE all_reduce of 2C floats."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, eps, momentum, relu, group, backend):
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, nbt, eps, momentum, relu, group, backend):
         c = x.shape[1]
         world = dist.get_world_size(group)
-        local = torch.empty(2 * c + 1, dtype=torch.float32, device=x.device)
-        local[:2 * c] = backend.bn_stats(x)
-        local[2 * c] = float(x.shape[0])
+        local = backend.bn_stats(x)                                    # [mean | M2 | count], 2 kernels
         allst = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=x.device)
         if dist.get_backend(group) == "nccl":
             dist.all_gather_into_tensor(allst, local, group=group)
         else:  # gloo (single-GPU dry runs / CPU tests) has no flat all-gather
             dist.all_gather(list(allst.unbind(0)), local, group=group)
-        cnt = allst[:, 2 * c].double()
-        n = cnt.sum()
-        means = allst[:, :c].double()
-        mean = (means * cnt[:, None]).sum(0) / n
-        m2 = allst[:, c:2 * c].double().sum(0) + (cnt[:, None] * (means - mean) ** 2).sum(0)
-        var = m2 / n
-        stats = torch.cat([mean, torch.rsqrt(var + eps)]).float()
-        if running_mean is not None:
-            with torch.no_grad():
-                running_mean.mul_(1 - momentum).add_(mean.float() * momentum)
-                running_var.mul_(1 - momentum).add_((m2 / (n - 1).clamp_min(1)).float() * momentum)
+        # one kernel: Chan's combination, running statistics, num_batches_tracked, 1/N (device scalar)
+        stats, inv_n = backend.bn_sync_combine(allst, c, eps, momentum, running_mean, running_var, nbt)
         y = backend.bn_apply(x, weight, bias, stats, residual, relu)
         ctx.backend, ctx.group, ctx.has_res = backend, group, residual is not None
         ctx.relu_mode = 0 if not relu else (1 if residual is not None else 2)
-        ctx.save_for_backward(x, weight, bias, stats, y if ctx.relu_mode == 1 else x.new_empty(0), (1.0 / n).float())
+        ctx.gparam = weight if isinstance(weight, torch.nn.Parameter) else None
+        ctx.bparam = bias if isinstance(bias, torch.nn.Parameter) else None
+        ctx.save_for_backward(x, weight, bias, stats, y if ctx.relu_mode == 1 else x.new_empty(0), inv_n)
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        from .me.modules import grad_slot_view
         x, weight, bias, stats, y, inv_n = ctx.saved_tensors
         dy = dy.contiguous()
         yy = y if ctx.relu_mode == 1 else None
-        sums = ctx.backend.bn_backward_reduce(x, yy, dy, weight, bias, stats, ctx.relu_mode)
         c = x.shape[1]
-        dbeta, dgamma = sums[:c].clone(), sums[c:].clone()      # parameter grads stay local; DDP averages them
+        # parameter gradients stay local (DDP averages them): written by the reduce kernel, straight into the gradient
+        # bucket slots when the parameters have them
+        gview = grad_slot_view(ctx.gparam) if ctx.gparam is not None else None
+        bview = grad_slot_view(ctx.bparam) if ctx.bparam is not None else None
+        if gview is None or bview is None:
+            gview = bview = None
+            dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+            dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+        else:
+            dgamma, dbeta = gview, bview
+        sums = ctx.backend.bn_backward_reduce(x, yy, dy, weight, bias, stats, ctx.relu_mode, dgamma, dbeta)
         dist.all_reduce(sums, group=ctx.group)
-        # fold 1/N into the sums so the kernel's scalar stays 1.0 (no host sync for the global row count)
-        sums = sums * inv_n
-        dx, dres = ctx.backend.bn_backward_apply(x, yy, dy, weight, bias, stats, sums, 1.0, ctx.relu_mode,
+        dx, dres = ctx.backend.bn_backward_apply(x, yy, dy, weight, bias, stats, sums, inv_n, ctx.relu_mode,
                                                  ctx.has_res and ctx.needs_input_grad[3])
-        return dx, dgamma.to(weight.dtype), dbeta.to(weight.dtype), dres, None, None, None, None, None, None, None
+        if gview is not None:
+            return dx, gview, bview, dres, None, None, None, None, None, None, None, None
+        return dx, dgamma.to(weight.dtype), dbeta.to(weight.dtype), dres, None, None, None, None, None, None, None, None
 
 
 def sync_batch_norm(x, bn, group=None, residual=None, relu=False):
@@ -263,11 +264,12 @@ def sync_batch_norm(x, bn, group=None, residual=None, relu=False):
     torch formulation below is only reachable with CPU tensors (the gloo host-logic tests)."""
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    nbt = bn.num_batches_tracked if bn.track_running_stats else None
     if x.is_cuda:
         from .me.core import get_backend
-        return _SyncBNFused.apply(x, bn.weight, bn.bias, residual, rm, rv, bn.eps, bn.momentum, relu, group, get_backend())
+        return _SyncBNFused.apply(x, bn.weight, bn.bias, residual, rm, rv, nbt, bn.eps, bn.momentum, relu, group, get_backend())
+    if nbt is not None:
+        nbt += 1
     y = _SyncBNFunction.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, group)
     if residual is not None:
         y = y + residual

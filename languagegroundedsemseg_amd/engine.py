@@ -21,7 +21,7 @@ EXPORTS = [
     "lgs_kmap_export",
     "lgs_conv_workspace_bytes", "lgs_conv_forward", "lgs_conv_dgrad", "lgs_conv_wgrad",
     "lgs_bn_workspace_bytes", "lgs_bn_forward", "lgs_bn_backward",
-    "lgs_bn_stats", "lgs_bn_apply", "lgs_bn_backward_reduce", "lgs_bn_backward_apply",
+    "lgs_bn_stats", "lgs_bn_sync_combine", "lgs_bn_apply", "lgs_bn_backward_reduce", "lgs_bn_backward_apply",
     "lgs_clip_similarity", "lgs_clip_workspace_bytes",
     "lgs_ce_forward_backward",
 ]
@@ -66,8 +66,9 @@ def lib():
         "lgs_bn_backward": [vp, vp, vp, i64, i64, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp],
         "lgs_bn_stats": [vp, i64, ci, vp, ci, vp, vp],
         "lgs_bn_apply": [vp, i64, ci, vp, vp, vp, vp, ci, vp, ci, vp],
-        "lgs_bn_backward_reduce": [vp, vp, vp, i64, ci, vp, vp, vp, ci, vp, ci, vp, vp],
-        "lgs_bn_backward_apply": [vp, vp, vp, i64, ci, vp, vp, vp, vp, cf, ci, vp, vp, ci, vp],
+        "lgs_bn_backward_reduce": [vp, vp, vp, i64, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp],
+        "lgs_bn_sync_combine": [vp, ci, ci, cf, cf, vp, vp, vp, vp, vp, vp],
+        "lgs_bn_backward_apply": [vp, vp, vp, i64, ci, vp, vp, vp, vp, cf, vp, ci, vp, vp, ci, vp],
         "lgs_clip_similarity": [vp, i64, ci, vp, ci, vp, vp, ci, vp, vp],
         "lgs_ce_forward_backward": [vp, i64, ci, vp, i64, vp, vp, vp, ci, vp],
     }

@@ -247,14 +247,26 @@ class HipBackend:
 
     # ---- the same op in halves (SyncBN: statistics are exchanged between ranks in the middle)
     def bn_stats(self, x):
+        """-> float32 [2C+1]: local mean, local M2, row count (the record one rank contributes to SyncBN's all-gather)"""
         L = engine.lib()
         x = x.contiguous()
         n, c = x.shape
         with torch.cuda.device(x.device):
-            out = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+            out = torch.empty(2 * c + 1, dtype=torch.float32, device=x.device)
             ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
             engine.check(L.lgs_bn_stats(_ptr(x), n, c, _ptr(out), _dtype_code(x), _ptr(ws), _stream()))
         return out
+
+    def bn_sync_combine(self, all_stats, c, eps, momentum, running_mean, running_var, num_batches_tracked):
+        """all_stats [world, 2C+1] -> (stats [2C] = global mean | invstd, inv_n [1] = 1 / global rows); one kernel"""
+        L = engine.lib()
+        world = all_stats.shape[0]
+        with torch.cuda.device(all_stats.device):
+            stats = torch.empty(2 * c, dtype=torch.float32, device=all_stats.device)
+            inv_n = torch.empty(1, dtype=torch.float32, device=all_stats.device)
+            engine.check(L.lgs_bn_sync_combine(_ptr(all_stats), int(world), int(c), float(eps), float(momentum), _ptr(running_mean),
+                                               _ptr(running_var), _ptr(num_batches_tracked), _ptr(stats), _ptr(inv_n), _stream()))
+        return stats, inv_n
 
     def bn_apply(self, x, gamma, beta, stats, residual, relu):
         L = engine.lib()
@@ -267,24 +279,28 @@ class HipBackend:
                                         _dtype_code(x), _stream()))
         return y
 
-    def bn_backward_reduce(self, x, y, dy, gamma, beta, stats, relu):
+    def bn_backward_reduce(self, x, y, dy, gamma, beta, stats, relu, dgamma_out=None, dbeta_out=None):
+        """-> sums [2C] (local sum dy', sum dy' xhat); the same vectors are also written to dgamma_out / dbeta_out"""
         L = engine.lib()
         n, c = x.shape
         with torch.cuda.device(x.device):
             sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
             ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
             engine.check(L.lgs_bn_backward_reduce(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), int(relu), _ptr(sums),
-                                                  _dtype_code(x), _ptr(ws), _stream()))
+                                                  _ptr(dgamma_out), _ptr(dbeta_out), _dtype_code(x), _ptr(ws), _stream()))
         return sums
 
     def bn_backward_apply(self, x, y, dy, gamma, beta, stats, sums, inv_n_total, relu, want_residual):
+        """inv_n_total: python float, or a device scalar tensor (1 / global row count, no host sync)"""
         L = engine.lib()
         n, c = x.shape
+        dev_inv = inv_n_total if torch.is_tensor(inv_n_total) else None
         with torch.cuda.device(x.device):
             dx = torch.empty_like(x)
             dres = torch.empty_like(x) if want_residual else None
             engine.check(L.lgs_bn_backward_apply(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(sums),
-                                                 float(inv_n_total), int(relu), _ptr(dx), _ptr(dres), _dtype_code(x), _stream()))
+                                                 0.0 if dev_inv is not None else float(inv_n_total), _ptr(dev_inv), int(relu), _ptr(dx),
+                                                 _ptr(dres), _dtype_code(x), _stream()))
         return dx, dres
 
     # ---- CLIP contraction: lgs_clip_similarity

@@ -1,0 +1,71 @@
+"""SyncBN on the engine's split kernels (lgs_bn_stats -> all-gather -> lgs_bn_sync_combine -> lgs_bn_apply;
+lgs_bn_backward_reduce -> all-reduce -> lgs_bn_backward_apply with the device-side 1/N), run by two gloo ranks that share
+the one GPU of the box, against single-process full-batch BatchNorm (main.py:122-123)."""
+import pytest
+import torch
+import torch.nn as nn
+
+from test_ddp_cpu import run_distributed
+
+pytestmark = pytest.mark.gpu
+N, C = 5000, 96
+
+
+def _data(dtype):
+    torch.manual_seed(11)
+    full = (torch.randn(N, C) * 2 + 0.5).to(dtype).float()
+    res = torch.randn(N, C).to(dtype).float()
+    g = torch.randn(N, C).to(dtype).float()
+    return full, res, g
+
+
+def _job(rank, world, dtype_name, relu, use_res):
+    import MinkowskiEngine as ME
+    from languagegroundedsemseg_amd.ddp import sync_batch_norm
+    dtype = getattr(torch, dtype_name)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    full, res, g = _data(dtype)
+    sl = slice(0, 1800) if rank == 0 else slice(1800, N)          # ragged shards
+    x = full[sl].to(dev).to(dtype).requires_grad_(True)
+    r = res[sl].to(dev).to(dtype).requires_grad_(True)
+    mod = ME.MinkowskiSyncBatchNorm(C, momentum=0.02).to(dev)
+    with torch.no_grad():
+        mod.bn.weight.copy_(torch.linspace(0.5, 1.5, C)); mod.bn.bias.copy_(torch.linspace(-0.2, 0.2, C))
+    y = sync_batch_norm(x, mod.bn, residual=r if use_res else None, relu=relu)
+    y.backward(g[sl].to(dev).to(dtype))
+    torch.cuda.synchronize()
+    return (y.detach().float().cpu(), x.grad.float().cpu(), r.grad.float().cpu() if use_res else None,
+            mod.bn.running_mean.cpu(), mod.bn.running_var.cpu(), mod.bn.weight.grad.cpu(), mod.bn.bias.grad.cpu(),
+            int(mod.bn.num_batches_tracked))
+
+
+@pytest.mark.parametrize("dtype_name,tol", [("float32", 2e-5), ("bfloat16", 2e-2)])
+@pytest.mark.parametrize("relu,use_res", [(False, False), (True, False), (True, True)])
+def test_fused_sync_bn_two_ranks_match_full_batch(dtype_name, tol, relu, use_res):
+    import functools
+    r0, r1 = run_distributed(functools.partial(_job, dtype_name=dtype_name, relu=relu, use_res=use_res))
+    dtype = getattr(torch, dtype_name)
+    full, res, g = _data(dtype)
+    xf = full.clone().requires_grad_(True)
+    rf = res.clone().requires_grad_(True)
+    bn = nn.BatchNorm1d(C, momentum=0.02)
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.2, 0.2, C))
+    y = bn(xf)
+    if use_res:
+        y = y + rf
+    if relu:
+        y = torch.relu(y)
+    y.backward(g)
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+    assert rel(torch.cat([r0[0], r1[0]]), y.detach()) < tol
+    assert rel(torch.cat([r0[1], r1[1]]), xf.grad) < 5 * tol
+    if use_res:
+        assert rel(torch.cat([r0[2], r1[2]]), rf.grad) < tol
+    assert rel(r0[3], bn.running_mean) < max(tol, 1e-4) and rel(r1[4], bn.running_var) < max(tol, 1e-4)
+    assert rel(r0[5] + r1[5], bn.weight.grad) < 5 * tol          # parameter grads stay local: their sum is the full one
+    assert rel(r0[6] + r1[6], bn.bias.grad) < 5 * tol
+    assert r0[7] == 1 and r1[7] == 1
