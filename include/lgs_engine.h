@@ -172,6 +172,19 @@ int lgs_clip_similarity(const void *feat, int64_t n, int c, const float *anchors
                         float *inv_norm_f, int dtype, void *workspace, void *stream);
 int64_t lgs_clip_workspace_bytes(int c, int n_anchor, int dtype);
 
+/* ---- voxelisation on the device (the step in front of the hot path) ----------------
+ * lgs_voxelize: points[n,3] float32 -> coords[n,4] int32 = (batch, floor(A * (x,y,z,1))), A = 3x4 row-major affine
+ *   given as 12 HOST doubles (voxel scale / rotation / translation), evaluated in double like numpy's:
+ *   /root/reference/lib/voxelizer.py:136-139 (homo_coords @ rigid_transformation.T[:, :3] -> np.floor) plus the batch
+ *   column of ME.utils.sparse_collate (lib/transforms.py:421).
+ * lgs_label_vote: label rule of ME.utils.sparse_quantize(..., labels, ignore_label) (lib/voxelizer.py:284): a voxel
+ *   keeps its first point's label unless another of its points disagrees -> ignore_label.  unique_index / inverse are
+ *   the outputs of lgs_manager_insert (device int64), labels / labels_out device int64.
+ * Dedup (first occurrence wins, surviving indices ascending) is lgs_manager_insert itself. */
+int lgs_voxelize(const float *points, int64_t n, const double *affine, int batch, int32_t *coords, void *stream);
+int lgs_label_vote(const int64_t *labels, int64_t n, const int64_t *unique_index, const int64_t *inverse,
+                   int64_t n_unique, int64_t ignore_label, int64_t *labels_out, void *stream);
+
 /* ---- fused softmax cross-entropy ----------------------------------------------------------------
  * replaces nn.CrossEntropyLoss(ignore_index=-1) on the [N,200] logits of the fine-tune step
  *   /root/reference/lib/train_test/pl_BaselineTrainer.py:94-99,350

@@ -145,3 +145,31 @@ def canonical_order(coords):
     """Row permutation that sorts coords lexicographically by (b,x,y,z) -- for set-equality checks."""
     c = np.asarray(coords)
     return np.lexsort((c[:, 3], c[:, 2], c[:, 1], c[:, 0]))
+
+
+def quantize(points, affine=None, labels=None, ignore_label=-100, batch_index=0):
+    """CPU restatement of the reference's voxelisation (test oracle for lgs_voxelize / lgs_label_vote):
+         coords_aug = np.floor(hstack(coords, 1) @ rigid_transformation.T[:, :3])     lib/voxelizer.py:136-139
+         _, unique_map = ME.utils.sparse_quantize(coords_aug, return_index=True)        lib/voxelizer.py:142
+         sparse_quantize(coords, feats, labels, ignore_label=...)                      lib/voxelizer.py:284
+    (dedup: first occurrence wins, indices ascending; a voxel whose points disagree on the label gets ignore_label).
+    The affine product is evaluated elementwise in float64 in the fixed order ((x*a0 + y*a1) + z*a2) + a3.
+    -> coords int32 [N,4] (batch column first), unique_index, inverse, voxel labels (or None)."""
+    p = np.asarray(points, dtype=np.float32).astype(np.float64)
+    a = np.eye(4, dtype=np.float64)
+    if affine is not None:
+        m = np.asarray(affine, dtype=np.float64)
+        a[:m.shape[0], :m.shape[1]] = m
+    cols = []
+    for r in range(3):
+        v = ((p[:, 0] * a[r, 0] + p[:, 1] * a[r, 1]) + p[:, 2] * a[r, 2]) + a[r, 3]
+        cols.append(np.floor(v).astype(np.int32))
+    coords = np.stack([np.full(p.shape[0], batch_index, np.int32)] + cols, 1)
+    ui, inv = unique_coords(coords)
+    lab = None
+    if labels is not None:
+        ln = np.asarray(labels).astype(np.int64)
+        lab = ln[ui].copy()
+        mism = ln != lab[inv]
+        lab[np.unique(inv[mism])] = ignore_label
+    return coords, ui, inv, lab

@@ -101,6 +101,29 @@ def clip():
                 n, c, str(dtype).split(".")[1], ms, flop / ms / 1e9, byts / ms / 1e9))
 
 
+def quantize():
+    """raw points -> voxel coordinates on the device (voxelize + dedup + label vote)"""
+    import numpy as np
+    coords, feats, labels = make_batch(list(range(8)), n_target=150000, shift_seed=0)
+    rng = np.random.default_rng(0)
+    rep = np.repeat(coords, 2, 0)                                   # ~2 points per voxel, like a 2 cm voxelisation of ScanNet
+    pts = (rep[:, 1:].astype(np.float64) + rng.uniform(0.05, 0.95, (rep.shape[0], 3))) * 0.02
+    p = torch.from_numpy(pts.astype(np.float32)).to(DEV)
+    lab = torch.from_numpy(np.repeat(labels, 2)).to(DEV)
+    n = p.shape[0]
+    tv = timeit(lambda: ME.utils.voxelize(p, quantization_size=0.02))
+    tq = timeit(lambda: ME.utils.sparse_quantize(p, None, lab, ignore_label=-1, quantization_size=0.02, return_index=True))
+    print("voxelize %d points: %.3f ms (%.2f TB/s of 28 B/point)" % (n, tv, n * 28 / tv / 1e9))
+    print("sparse_quantize (voxelize + dedup + label vote) %d points -> voxels: %.3f ms (%.1f M points/s)" % (n, tq, n / tq / 1e3))
+    import time
+    m = 300000                                                      # bounded CPU sample of the same workload (host path = numpy)
+    ph, lh = p[:m].cpu(), lab[:m].cpu()
+    t0 = time.perf_counter()
+    ME.utils.sparse_quantize(ph, None, lh, ignore_label=-1, quantization_size=0.02, return_index=True)
+    tc = time.perf_counter() - t0
+    print("host path (numpy, 1 core) on the first %d points: %.1f ms (%.2f M points/s)" % (m, tc * 1e3, m / tc / 1e6))
+
+
 def coarse():
     """coarse-level layer shapes (L2..L4 of an 8-scene batch)"""
     coords, feats, labels = make_batch(list(range(8)), n_target=150000, shift_seed=0)
@@ -127,6 +150,9 @@ def coarse():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "coarse":
         coarse()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "quantize":
+        quantize()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "clip":
         clip()
