@@ -80,16 +80,36 @@ class ContrastiveLanguageLoss(nn.Module):
     Negatives are sampled on the device (no host loop / joblib pool / np.random), or passed explicitly."""
 
     def __init__(self, num_labels=200, num_negative_samples=3, pos_thresh=0.0, neg_thresh=0.6, neg_weight=1.0,
-                 ignore_label=-1, reduction="mean"):
+                 ignore_label=-1, reduction="mean", uniform_sampling=True):
         super().__init__()
         self.num_labels, self.K = num_labels, num_negative_samples
         self.pos_thresh, self.neg_thresh, self.neg_weight = pos_thresh, neg_thresh, neg_weight
         self.ignore_label, self.reduction = ignore_label, reduction
+        self.uniform_sampling = uniform_sampling      # config.clip_uniform_sampling (ContrastiveLanguageLoss.py:138-141)
 
     def sample_negatives(self, labels, generator=None):
+        """K negative classes per voxel, on the device, no host sync.
+        uniform_sampling=True : uniform over all other classes (clip_candidates minus own, :139)
+        uniform_sampling=False: uniform over the OTHER classes present in this batch (unique_targets minus own, :141)"""
         n = labels.shape[0]
-        r = torch.randint(0, self.num_labels - 1, (n, self.K), device=labels.device, generator=generator)
-        return r + (r >= labels.clamp_min(0)[:, None]).long()     # uniform over the other num_labels-1 classes
+        lab = labels.clamp_min(0)
+        if self.uniform_sampling:
+            r = torch.randint(0, self.num_labels - 1, (n, self.K), device=labels.device, generator=generator)
+            return r + (r >= lab[:, None]).long()
+        L = self.num_labels
+        valid = labels != self.ignore_label
+        present = torch.zeros(L + 1, dtype=torch.bool, device=labels.device)
+        present[torch.where(valid, lab, torch.full_like(lab, L))] = True
+        present = present[:L]
+        rank = torch.cumsum(present.long(), 0) - 1                          # rank of a present class among the present ones
+        n_present = present.sum()                                           # device scalar: never read on the host
+        cls_of_rank = torch.zeros(L + 1, dtype=torch.long, device=labels.device)
+        cls_of_rank[torch.where(present, rank, torch.full_like(rank, L))] = torch.arange(L, device=labels.device)
+        u = torch.rand((n, self.K), device=labels.device, generator=generator)
+        r = torch.minimum((u * (n_present - 1).clamp_min(1)).long(), (n_present - 2).clamp_min(0))
+        own = rank[lab][:, None]
+        idx = torch.minimum(r + (r >= own).long(), (n_present - 1).clamp_min(0))   # a single-class batch has no negatives: own class
+        return cls_of_rank[idx]
 
     def forward(self, features, labels, anchor_feats, neg_indices=None, return_similarity=False):
         if features.dim() != 2:
@@ -116,6 +136,40 @@ class ContrastiveLanguageLoss(nn.Module):
         if return_similarity:
             return loss, pos_loss, neg_loss, sim
         return loss, pos_loss, neg_loss
+
+
+def sample_categories_for_balancing(loss, targets, frequency_organized_cats, head_ratio, common_ratio, ignore_label=-1,
+                                    generator=None):
+    """lib/losses/utils.py:13-77 on the device, no host loop / np.random.choice / sync: per-point `loss` [N] is masked so
+    that every HEAD class keeps round(head_ratio * count) of its points, every COMMON class round(common_ratio * count)
+    (drawn without replacement), TAIL classes keep all; ratio <= 0 keeps everything (:41,:54).
+    frequency_organized_cats: bool [num_labels, 3] (head, common, tail), lib/datasets/scannet.py:131-141.
+    -> (masked loss mean over ALL points, (head, common, tail per-point losses, detached), loss_items [N_valid, 3])."""
+    dev = loss.device
+    foc = frequency_organized_cats.to(dev).bool()
+    valid = targets != ignore_label
+    lab = targets.clamp_min(0).long()
+    L = foc.shape[0]
+    group = torch.where(foc[:, 0], 0, torch.where(foc[:, 1], 1, 2)).to(dev)     # anything not head/common is kept like tail (:58-62)
+    ratio_of_group = torch.tensor([head_ratio if head_ratio > 0 else 1.0, common_ratio if common_ratio > 0 else 1.0, 1.0],
+                                  device=dev, dtype=torch.float64)
+    pg = group[lab]
+    counts = torch.zeros(L, dtype=torch.long, device=dev).index_add_(0, lab, valid.long())
+    keep_n = torch.round(ratio_of_group[group] * counts.double()).long()         # python round == torch.round: half to even
+    # rank of every point inside its class by a random key = a uniform draw without replacement
+    u = torch.rand(loss.shape[0], device=dev, generator=generator)
+    key = lab.double() + u.double()
+    key = torch.where(valid, key, torch.full_like(key, float(L + 1)))
+    order = torch.argsort(key)
+    start = torch.cumsum(counts, 0) - counts                                     # first sorted position of every class
+    pos = torch.empty_like(order)
+    pos[order] = torch.arange(order.shape[0], device=dev)
+    rank_in_class = pos - start[lab]
+    point_mask = valid & (rank_in_class < keep_n[lab])
+    loss_items = torch.stack([valid & (pg == 0), valid & (pg == 1), valid & (pg == 2)], 1)
+    head, common, tail = (loss[loss_items[:, i]].detach() for i in range(3))
+    masked = loss * point_mask.to(loss.dtype)
+    return masked.mean(), (head, common, tail), loss_items[valid]
 
 
 def feature_sim_argmax(sim):
