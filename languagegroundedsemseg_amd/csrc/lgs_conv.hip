@@ -534,12 +534,18 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
   if (o_real % 4 != 0) {
     // rows are written in 4-channel groups: route odd widths (e.g. the 3-channel input gradient of a
     // test) through a 4-aligned scratch image placed after the packed weights and the padded input
-    LGS_REQUIRE(bias == nullptr, "sparse conv: bias needs an output channel count that is a multiple of 4");
     const int o4 = (o_real + 3) / 4 * 4;
     int64_t off = wbytes + ((g_real % EPL != 0) ? align256(v.n_in * (int64_t)g_pad * (int64_t)sizeof(T)) : 0);
     T *tmp = reinterpret_cast<T *>(ws + off);
     if (v.n_out > 0) LGS_HIP(hipMemsetAsync(tmp, 0, (size_t)v.n_out * o4 * sizeof(T), s));
-    int rc = conv_gather_op<T>(v, in_v, g_real, weight, K, cin_w, cout_w, transposed_w, o4, nullptr, tmp, workspace, s, o_real);
+    const float *bias4 = nullptr;
+    if (bias) {   // e.g. the 3-channel offset head of the instance-segmentation model: bias padded to the scratch width
+      float *bp = reinterpret_cast<float *>(ws + off + align256(v.n_out * (int64_t)o4 * (int64_t)sizeof(T)));
+      LGS_HIP(hipMemsetAsync(bp, 0, sizeof(float) * o4, s));
+      LGS_HIP(hipMemcpyAsync(bp, bias, sizeof(float) * o_real, hipMemcpyDeviceToDevice, s));
+      bias4 = bp;
+    }
+    int rc = conv_gather_op<T>(v, in_v, g_real, weight, K, cin_w, cout_w, transposed_w, o4, bias4, tmp, workspace, s, o_real);
     if (rc) return rc;
     int64_t tot = v.n_out * (int64_t)o_real;
     if (tot > 0)
@@ -642,7 +648,7 @@ int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtyp
   int64_t bytes = align256((int64_t)km->K * (pad32(g) + 96) * (pad32(o) + 96) * e);
   int64_t nmax = km->fwd.n_in > km->bwd.n_in ? km->fwd.n_in : km->bwd.n_in;
   if (g % epl(dtype) != 0) bytes += align256(nmax * pad32(g) * e);
-  if (o % 4 != 0) bytes += align256(nmax * (int64_t)((o + 3) / 4 * 4) * e);
+  if (o % 4 != 0) bytes += align256(nmax * (int64_t)((o + 3) / 4 * 4) * e) + 256;   // scratch image + padded bias
   int64_t omax = km->fwd.n_out > km->bwd.n_out ? km->fwd.n_out : km->bwd.n_out;
   bytes += lgs::split_partial_bytes(km->K, omax, o) + lgs::split_partial_bytes(km->K, omax, (o + 3) / 4 * 4);
   return bytes + 256;

@@ -172,6 +172,22 @@ def sample_categories_for_balancing(loss, targets, frequency_organized_cats, hea
     return masked.mean(), (head, common, tail), loss_items[valid]
 
 
+def instance_offset_losses(pt_offsets, coords_xyz, centers, instance_ids, voxel_size):
+    """downstream/insseg/lib/pl_Trainer.py:271-299 (PointGroup offset losses): L1 norm loss and direction loss of the
+    predicted per-voxel offset to its instance centre, averaged over voxels with an instance (id != -1).
+    pt_offsets [N,3] (any float dtype), coords_xyz [N,3] voxel coordinates, centers [N,3] in voxel units.
+    -> (offset_norm_loss, offset_dir_loss)"""
+    po = pt_offsets.float()
+    gt = (centers.float() - coords_xyz.float()) * voxel_size
+    valid = (instance_ids != -1).float()
+    denom = valid.sum() + 1e-6
+    norm_loss = ((po - gt).abs().sum(-1) * valid).sum() / denom
+    gt_n = gt / (gt.norm(p=2, dim=1, keepdim=True) + 1e-8)
+    po_n = po / (po.norm(p=2, dim=1, keepdim=True) + 1e-8)
+    dir_loss = (-(gt_n * po_n).sum(-1) * valid).sum() / denom
+    return norm_loss, dir_loss
+
+
 def feature_sim_argmax(sim):
     """lib/losses/utils.py:80-103 (cosine branch) + argmax for the metrics: reuse the similarity matrix."""
     return sim.argmax(1)

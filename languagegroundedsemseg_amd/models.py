@@ -172,7 +172,37 @@ class Res16UNet34D(Res16UNet34CR):
     PLANES = (32, 64, 128, 256, 256, 256, 256, 512)
 
 
-MODELS = {c.__name__: c for c in [Res16UNet14, Res16UNet18, Res16UNet34, Res16UNet14A, Res16UNet18A, Res16UNet34A,
+class _InsSegHead:
+    """downstream/insseg head on the same trunk (insseg_models/insseg_res16unet.py:197-199,260-265):
+    offsets = 1x1(C->3, bias)(ReLU(BN(1x1(C->C, bias)(block8 features)))); forward -> (offsets, logits, features)."""
+
+    def _add_head(self, D):
+        c = self.PLANES[7]
+        bn_m = self.bn0.bn.momentum
+        self.offsets_pre = _conv(c, c, 1, bias=True, D=D)
+        self.bntr_offset = ME.MinkowskiBatchNorm(c, momentum=bn_m)
+        self.offsets = _conv(c, 3, 1, bias=True, D=D)
+
+    def forward(self, x, detach=False):
+        out = self.trunk(x)
+        off = self.offsets(self.bntr_offset(self.offsets_pre(out), relu=True))
+        return off, self.final(out), out
+
+
+class InsSegRes16UNet14A(_InsSegHead, Res16UNet14A):
+    def __init__(self, in_channels, out_channels, config=None, D=3, **kwargs):
+        Res16UNet14A.__init__(self, in_channels, out_channels, config, D, **kwargs)
+        self._add_head(D)
+
+
+class InsSegRes16UNet34C(_InsSegHead, Res16UNet34C):
+    def __init__(self, in_channels, out_channels, config=None, D=3, **kwargs):
+        Res16UNet34C.__init__(self, in_channels, out_channels, config, D, **kwargs)
+        self._add_head(D)
+
+
+MODELS = {c.__name__: c for c in [InsSegRes16UNet14A, InsSegRes16UNet34C,
+                                  Res16UNet14, Res16UNet18, Res16UNet34, Res16UNet14A, Res16UNet18A, Res16UNet34A,
                                   Res16UNet34B, Res16UNet34C, Res16UNet34CR, Res16UNet34CR_Proj, Res16UNet34D]}
 
 

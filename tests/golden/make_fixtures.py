@@ -102,7 +102,63 @@ def forward_fixture(name, seed, n):
         ME.set_backend(prev)
 
 
+def insseg_fixture(seed=11, n=1400):
+    """downstream/insseg: the reference's instance-seg model (insseg_models/insseg_res16unet.py) through the alias
+    package on the oracle backend -> state-dict manifest + (offsets, logits) on a small scene + the offset losses of
+    lib/pl_Trainer.py:271-299 restated with the reference's own expressions."""
+    sys.path.insert(0, "/root/reference/downstream/insseg")
+    from insseg_models import insseg_res16unet as M
+    cfg = types.SimpleNamespace(optimizer=types.SimpleNamespace(bn_momentum=0.02), net=types.SimpleNamespace(conv1_kernel_size=3))
+    man = {}
+    for name in ("Res16UNet14A", "Res16UNet34C"):
+        m = getattr(M, name)(3, 20, cfg)
+        man[name] = {"num_parameters": int(sum(p.numel() for p in m.parameters())),
+                     "state_dict": [[k, list(v.shape)] for k, v in m.state_dict().items()]}
+    prev = ME.set_backend(OracleBackend("c"))
+    try:
+        torch.manual_seed(0)
+        m = deterministic_init(M.Res16UNet14A(3, 20, cfg), 42)
+        m.train()
+        coords = small_scene(seed, n=n)
+        rng = np.random.default_rng(seed)
+        feats = rng.uniform(-0.5, 0.5, (coords.shape[0], 3)).astype(np.float32)
+        x = ME.SparseTensor(torch.from_numpy(feats), torch.from_numpy(coords))
+        pt_offsets, soutput, out_feats = m(x)
+        # losses exactly as pl_Trainer.py:283-299 writes them
+        inst = rng.integers(-1, 6, coords.shape[0])
+        centers = np.zeros((coords.shape[0], 3), np.float32)
+        for i in range(6):
+            sel = inst == i
+            if sel.any():
+                centers[sel] = coords[sel, 1:].mean(0)
+        VOXEL = 0.02
+        gt_offsets = torch.from_numpy(centers) - torch.from_numpy(coords[:, 1:]).float()
+        gt_offsets *= VOXEL
+        pt_diff = pt_offsets.F - gt_offsets
+        pt_dist = torch.sum(torch.abs(pt_diff), dim=-1)
+        valid = (torch.from_numpy(inst) != -1).float()
+        offset_norm_loss = torch.sum(pt_dist * valid) / (torch.sum(valid) + 1e-6)
+        gt_offsets_norm = torch.norm(gt_offsets, p=2, dim=1)
+        gt_offsets_ = gt_offsets / (gt_offsets_norm.unsqueeze(-1) + 1e-8)
+        pt_offsets_norm = torch.norm(pt_offsets.F, p=2, dim=1)
+        pt_offsets_ = pt_offsets.F / (pt_offsets_norm.unsqueeze(-1) + 1e-8)
+        direction_diff = - (gt_offsets_ * pt_offsets_).sum(-1)
+        offset_dir_loss = torch.sum(direction_diff * valid) / (torch.sum(valid) + 1e-6)
+        np.savez_compressed(os.path.join(HERE, "insseg_res16unet14a_forward.npz"), coords=coords, feats=feats,
+                            offsets=pt_offsets.F.detach().numpy(), logits=soutput.F.detach().numpy(), inst=inst, centers=centers,
+                            voxel=np.float32(VOXEL), norm_loss=np.float32(offset_norm_loss.item()),
+                            dir_loss=np.float32(offset_dir_loss.item()))
+        print("insseg fixture:", coords.shape, pt_offsets.F.shape, float(offset_norm_loss), float(offset_dir_loss))
+    finally:
+        ME.set_backend(prev)
+    with open(os.path.join(HERE, "insseg_manifest.json"), "w") as f:
+        json.dump(man, f)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "insseg":
+        insseg_fixture()
+        sys.exit(0)
     manifest()
     contrastive()
     forward_fixture("Res16UNet14A", 3, 1500)

@@ -175,3 +175,21 @@ def test_bf16_training_step_is_bitwise_reproducible():
     assert runs[0][1] == runs[1][1]
     for k in runs[0][2]:
         assert np.array_equal(runs[0][2][k], runs[1][2][k]), k
+
+
+def test_insseg_head_matches_reference_fixture_on_the_engine():
+    """downstream/insseg: offsets + logits of the HIP engine vs the fixture the reference's insseg model
+    produced on the oracle backend; backward through the 3-channel 1x1 head runs"""
+    from languagegroundedsemseg_amd.losses import instance_offset_losses
+    fx = np.load(os.path.join(G, "insseg_res16unet14a_forward.npz"))
+    m = deterministic_init(load_model("InsSegRes16UNet14A")(3, 20, Cfg()), 42).to(DEV).train()
+    x = ME.SparseTensor(torch.from_numpy(fx["feats"]).to(DEV), torch.from_numpy(fx["coords"]).to(DEV))
+    off, logits, feats = m(x)
+    assert np.abs(off.F.detach().cpu().numpy() - fx["offsets"]).max() < 1e-3
+    assert np.abs(logits.F.detach().cpu().numpy() - fx["logits"]).max() < 1e-3
+    nl, dl = instance_offset_losses(off.F, torch.from_numpy(fx["coords"][:, 1:]).to(DEV), torch.from_numpy(fx["centers"]).to(DEV),
+                                    torch.from_numpy(fx["inst"]).to(DEV), float(fx["voxel"]))
+    assert abs(float(nl) - float(fx["norm_loss"])) < 1e-3 and abs(float(dl) - float(fx["dir_loss"])) < 1e-3
+    (nl + dl + logits.F.float().square().mean()).backward()
+    assert m.offsets.kernel.grad is not None and torch.isfinite(m.offsets.kernel.grad).all()
+    assert torch.isfinite(m.conv0p1s1.kernel.grad).all()

@@ -124,6 +124,35 @@ def quantize():
     print("host path (numpy, 1 core) on the first %d points: %.1f ms (%.2f M points/s)" % (m, tc * 1e3, m / tc / 1e6))
 
 
+def insseg():
+    """instance-seg model (trunk + offset head), CE + offset losses, forward + backward, bf16"""
+    import numpy as np
+    from languagegroundedsemseg_amd import models
+    from languagegroundedsemseg_amd.losses import fused_cross_entropy, instance_offset_losses
+    coords, feats, labels = make_batch(list(range(8)), n_target=150000, shift_seed=0)
+    c = torch.from_numpy(coords).to(DEV)
+    f = torch.from_numpy(feats).to(DEV).bfloat16()
+    lab = torch.from_numpy(labels).to(DEV)
+    rng = np.random.default_rng(0)
+    inst = torch.from_numpy(rng.integers(-1, 30, coords.shape[0])).to(DEV)
+    centers = (c[:, 1:].float() + torch.randn(coords.shape[0], 3, device=DEV) * 20)
+
+    class Cfg:
+        bn_momentum, conv1_kernel_size = 0.02, 3
+    m = models.load_model("InsSegRes16UNet34C")(3, 200, Cfg()).to(DEV).train()
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        x = ME.SparseTensor(f, c)
+        off, logits, _ = m(x)
+        nl, dl = instance_offset_losses(off.F, c[:, 1:], centers, inst, 0.02)
+        (fused_cross_entropy(logits.F, lab, ignore_index=-1) + nl + dl).backward()
+    t = timeit(step)
+    print("InsSegRes16UNet34C fwd+bwd (CE + offset losses, incl. map build) %d voxels: %.2f ms = %.1f M voxels/s" % (
+        coords.shape[0], t, coords.shape[0] / t / 1e3))
+
+
 def coarse():
     """coarse-level layer shapes (L2..L4 of an 8-scene batch)"""
     coords, feats, labels = make_batch(list(range(8)), n_target=150000, shift_seed=0)
@@ -150,6 +179,9 @@ def coarse():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "coarse":
         coarse()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "insseg":
+        insseg()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "quantize":
         quantize()
