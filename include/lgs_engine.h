@@ -185,6 +185,20 @@ int lgs_voxelize(const float *points, int64_t n, const double *affine, int batch
 int lgs_label_vote(const int64_t *labels, int64_t n, const int64_t *unique_index, const int64_t *inverse,
                    int64_t n_unique, int64_t ignore_label, int64_t *labels_out, void *stream);
 
+/* ---- PointGroup clustering (validation-time only) --------------------------------
+ * replaces PG_OP.ballquery_batch_p + PG_OP.bfs_cluster
+ *   /root/reference/downstream/insseg/lib/bfs/ops/src/bfs_cluster_kernel.cu:16-61, bfs_cluster.cpp:54-125,
+ *   as called by downstream/insseg/lib/bfs/bfs.py:124-150.
+ * Connected components of {(i,j): |p_i - p_j|^2 < radius^2 (float32, reference operation order), same batch, same
+ * semantic label} through a radius-sized cell grid + lock-free union-find; component[i] = smallest point index of i's
+ * component (= the point the reference's BFS starts it from, so clusters sorted by it come in the reference's order)
+ * or -1 if the component has fewer than `threshold` points; *n_clusters (host) = kept components.  The reference's
+ * per-point cap of 1000 neighbours / meanActive buffer is not reproduced (no neighbour lists are materialised).
+ * Synchronises `stream` once.  batch_idx may be NULL (single scene). */
+int64_t lgs_cluster_workspace_bytes(int64_t n);
+int lgs_cluster(const float *xyz, const int32_t *batch_idx, const int32_t *semantic_label, int64_t n, float radius,
+                int threshold, int32_t *component, int32_t *n_clusters, void *workspace, void *stream);
+
 /* ---- fused softmax cross-entropy ----------------------------------------------------------------
  * replaces nn.CrossEntropyLoss(ignore_index=-1) on the [N,200] logits of the fine-tune step
  *   /root/reference/lib/train_test/pl_BaselineTrainer.py:94-99,350

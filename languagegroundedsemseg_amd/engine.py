@@ -24,7 +24,7 @@ EXPORTS = [
     "lgs_bn_stats", "lgs_bn_sync_combine", "lgs_bn_apply", "lgs_bn_backward_reduce", "lgs_bn_backward_apply",
     "lgs_clip_similarity", "lgs_clip_workspace_bytes",
     "lgs_ce_forward_backward",
-    "lgs_voxelize", "lgs_label_vote",
+    "lgs_voxelize", "lgs_label_vote", "lgs_cluster_workspace_bytes", "lgs_cluster",
 ]
 
 
@@ -62,6 +62,7 @@ def lib():
         "lgs_kmap_export": [vp, vp, vp, vp, vp, pi64],
         "lgs_conv_forward": [vp, ci, vp, ci, vp, ci, vp, vp, ci, vp, vp],
         "lgs_conv_dgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp],
+        "lgs_cluster": [vp, vp, vp, i64, cf, ci, vp, ctypes.POINTER(ctypes.c_int32), vp, vp],
         "lgs_voxelize": [vp, i64, ctypes.POINTER(ctypes.c_double), ci, vp, vp],
         "lgs_label_vote": [vp, i64, vp, vp, i64, i64, vp, vp],
         "lgs_conv_wgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp],
@@ -79,6 +80,8 @@ def lib():
         f = getattr(L, name)
         f.restype = ci
         f.argtypes = args
+    L.lgs_cluster_workspace_bytes.restype = i64
+    L.lgs_cluster_workspace_bytes.argtypes = [i64]
     L.lgs_conv_workspace_bytes.restype = i64
     L.lgs_conv_workspace_bytes.argtypes = [vp, ci, ci, ci, ci]
     L.lgs_bn_workspace_bytes.restype = i64

@@ -173,3 +173,47 @@ def quantize(points, affine=None, labels=None, ignore_label=-100, batch_index=0)
         mism = ln != lab[inv]
         lab[np.unique(inv[mism])] = ignore_label
     return coords, ui, inv, lab
+
+
+def pointgroup_clusters(xyz, semantic_label, radius, threshold, batch_idx=None):
+    """CPU restatement of PG_OP.ballquery_batch_p + PG_OP.bfs_cluster (test oracle for lgs_cluster):
+         /root/reference/downstream/insseg/lib/bfs/ops/src/bfs_cluster_kernel.cu:16-61   d2 < radius^2 inside the batch segment
+         /root/reference/downstream/insseg/lib/bfs/ops/src/bfs_cluster.cpp:54-101       BFS over same-label neighbours,
+                                                                                         components visited by ascending start index,
+                                                                                         kept if size >= threshold
+    d2 = (ox-x)^2 + (oy-y)^2 + (oz-z)^2 in float32, left to right (numpy elementwise ops, no FMA).  Candidate pairs come
+    from a KD-tree with a slightly larger radius and are then filtered with that exact float32 test.
+    -> list of clusters, each a list of point indices in BFS order (cluster order = the reference's)."""
+    from collections import deque
+    from scipy.spatial import cKDTree
+    p = np.asarray(xyz, dtype=np.float32)
+    n = p.shape[0]
+    sem = np.asarray(semantic_label)
+    b = np.zeros(n, np.int64) if batch_idx is None else np.asarray(batch_idx)
+    r2 = np.float32(radius) * np.float32(radius)
+    pairs = cKDTree(p.astype(np.float64)).query_pairs(float(radius) * 1.001, output_type="ndarray")
+    d = p[pairs[:, 0]] - p[pairs[:, 1]]
+    d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    ok = (d2 < r2) & (b[pairs[:, 0]] == b[pairs[:, 1]])
+    pairs = pairs[ok]
+    nbrs = [[] for _ in range(n)]
+    for a, c in pairs:
+        nbrs[a].append(c); nbrs[c].append(a)
+    for l in nbrs:
+        l.sort()                      # the ball query lists neighbours by ascending index (k = start..end)
+    visited = np.zeros(n, bool)
+    clusters = []
+    for i in range(n):
+        if visited[i]:
+            continue
+        cc = [i]; visited[i] = True
+        q = deque([i])
+        while q:
+            cur = q.popleft()
+            for j in nbrs[cur]:
+                if sem[j] != sem[cur] or visited[j]:
+                    continue
+                cc.append(j); visited[j] = True; q.append(j)
+        if len(cc) >= threshold:
+            clusters.append(cc)
+    return clusters

@@ -153,6 +153,28 @@ def insseg():
         coords.shape[0], t, coords.shape[0] / t / 1e3))
 
 
+def cluster():
+    """PointGroup proposal clustering of one scene (ball query radius 3 cm + same-label components)"""
+    import time
+    import numpy as np
+    from languagegroundedsemseg_amd.pointgroup import cluster_points
+    from oracle import oracle as orc
+    coords, feats, labels = make_batch([0], n_target=150000, shift_seed=0)
+    rng = np.random.default_rng(0)
+    xyz = (coords[:, 1:].astype(np.float32) + rng.uniform(0.2, 0.8, (coords.shape[0], 3)).astype(np.float32)) * np.float32(0.02)
+    blk = np.floor(xyz / np.float32(0.4)).astype(np.int64)
+    sem = ((blk[:, 0] * 3 + blk[:, 1] * 5 + blk[:, 2] * 7) % 7).astype(np.int32)
+    x, s = torch.from_numpy(xyz).to(DEV), torch.from_numpy(sem).to(DEV)
+    t = timeit(lambda: cluster_points(x, s, 0.03, 50))
+    idx, off = cluster_points(x, s, 0.03, 50)
+    print("cluster_points %d points -> %d clusters: %.3f ms (%.1f M points/s)" % (xyz.shape[0], off.shape[0] - 1, t, xyz.shape[0] / t / 1e3))
+    m = 30000
+    t0 = time.perf_counter()
+    orc.pointgroup_clusters(xyz[:m], sem[:m], 0.03, 50)
+    tc = time.perf_counter() - t0
+    print("oracle (KD-tree + python BFS, 1 core) on the first %d points: %.0f ms (%.3f M points/s)" % (m, tc * 1e3, m / tc / 1e6))
+
+
 def coarse():
     """coarse-level layer shapes (L2..L4 of an 8-scene batch)"""
     coords, feats, labels = make_batch(list(range(8)), n_target=150000, shift_seed=0)
@@ -179,6 +201,9 @@ def coarse():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "coarse":
         coarse()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cluster":
+        cluster()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "insseg":
         insseg()
