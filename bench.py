@@ -129,6 +129,7 @@ def build(device, dtype, n_classes=200, model_name="Res16UNet34C"):
 
 
 _DATA_STREAM = {}
+_CLIP = None   # set by main() for --workload clip
 
 
 def train_step(model, ddp, opt, coords, feats, labels, dtype, step_idx, shift=True):
@@ -153,8 +154,12 @@ def train_step(model, ddp, opt, coords, feats, labels, dtype, step_idx, shift=Tr
     for t in (c, f, sinput.F):
         t.record_stream(main)
     ddp.zero_grad()
-    logits, _ = model(sinput)
-    loss = fused_cross_entropy(logits.F, labels, ignore_index=-1)
+    if _CLIP is not None:   # --workload clip (BASELINE configs[2]): representation model + CLIP text-anchor loss
+        out = model(sinput)
+        loss, _, _ = _CLIP["crit"](out.F, labels, _CLIP["anchors"])
+    else:
+        logits, _ = model(sinput)
+        loss = fused_cross_entropy(logits.F, labels, ignore_index=-1)
     loss.backward()
     ddp.finalize()
     opt.step()
@@ -232,7 +237,10 @@ def main():
     ap.add_argument("--scenes", type=int, default=8, help="synthetic scenes per GPU per step")
     ap.add_argument("--voxels", type=int, default=150000, help="target voxels per scene (@2cm)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--model", default="Res16UNet34C")
+    ap.add_argument("--model", default=None, help="default: Res16UNet34C (ce) / Res16UNet34D (clip)")
+    ap.add_argument("--workload", default="ce", choices=["ce", "clip"],
+                    help="ce = BASELINE configs[1] (the headline metric); clip = configs[2], CLIP-contrastive pretrain step "
+                         "(scripts/text_representation_train.sh: Res16UNet34D, 512-d text anchors)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--sync-bn", type=int, default=1, help="convert to MinkowskiSyncBatchNorm when gpus > 1 (main.py:122)")
@@ -242,6 +250,8 @@ def main():
                                                        "N>1 code path with several ranks on ONE GPU)")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (single-GPU dry run of the N>1 path)")
     args = ap.parse_args()
+    if args.model is None:
+        args.model = "Res16UNet34C" if args.workload == "ce" else "Res16UNet34D"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -270,6 +280,13 @@ def main():
     log("data resident: %d voxels in %d scenes" % (n_vox, args.scenes))
 
     model = build(device, dtype, model_name=args.model)
+    if args.workload == "clip":
+        global _CLIP
+        from languagegroundedsemseg_amd.losses import ContrastiveLanguageLoss
+        from languagegroundedsemseg_amd.synthetic import text_anchors
+        model.representation_only(True)
+        _CLIP = {"crit": ContrastiveLanguageLoss(num_labels=200, num_negative_samples=3),
+                 "anchors": torch.from_numpy(text_anchors(200, model.PLANES[7])).to(device)}
     if world > 1 and args.sync_bn:
         model = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)
     ddp = BucketedDDP(model, bucket_mb=32.0)
@@ -317,8 +334,11 @@ def main():
         "metric": "voxels/sec fwd+bwd Res16UNet34C @2cm ScanNet200", "value": value, "unit": "voxels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "%s 2cm ScanNet200-shaped synthetic scenes, cross-entropy fine-tune step "
-                               "(configs[1]): SparseTensor build + fwd + CE(200) + bwd + grad all-reduce + SGD" % args.model,
+        "config": {"workload": ("%s 2cm ScanNet200-shaped synthetic scenes, cross-entropy fine-tune step "
+                                "(configs[1]): SparseTensor build + fwd + CE(200) + bwd + grad all-reduce + SGD" % args.model)
+                               if args.workload == "ce" else
+                               ("%s 2cm synthetic scenes, CLIP-contrastive pretrain step (configs[2]): SparseTensor build + fwd + "
+                                "text-anchor contrastive loss (200 anchors, MFMA contraction) + bwd + grad all-reduce + SGD" % args.model),
                    "scenes_per_gpu": args.scenes, "voxels_per_gpu": n_vox, "global_voxels": int(total_vox),
                    "parallelism": "dp%d" % world, "sync_bn": bool(world > 1 and args.sync_bn),
                    "storage": "bf16 features / fp32 master weights, fp32 accumulate + BN statistics" if args.dtype == "bf16"
