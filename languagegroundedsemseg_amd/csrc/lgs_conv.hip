@@ -427,6 +427,9 @@ GatherCfg gather_cfg(const View &v, int nb_total) {
     if (nb_total == 1) return {0, kF32 ? 2 : 4, 1};
     if (nb_total == 2) return {1, kF32 ? 2 : 4, 2};
     if (nb_total == 3 || (nb_total % 3 == 0 && nb_total % 4 != 0)) return {2, kF32 ? 2 : 4, 3};
+    // wide outputs (>= 256 channels, e.g. the 512-d CLIP representation model): 256 positions x 256 channels per
+    // 8-wave workgroup -- every staged weight fragment serves two row blocks and the rows are gathered half as often
+    if (!kF32 && nb_total % 8 == 0) return {15, 2, 8};
     if (!kF32) return {7, 2, 4};   // bf16: 128-position tiles, 4 column blocks per wave at 3 waves/SIMD
     return {3, kF32 ? 1 : 2, 4};
   }
@@ -504,6 +507,7 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
     case 4: LGS_LAUNCH(1, 1, 2, 1, (kF32 ? 2 : 4), (kF32 ? 4 : 8)); break;
     case 6: LGS_LAUNCH(1, 7, 4, 1, (kF32 ? 1 : 2), (kF32 ? 3 : 4)); break;
     case 7: LGS_LAUNCH(1, 4, 4, 1, 2, 4); break;
+    case 15: LGS_LAUNCH(2, 4, 4, 2, 2, 2); break;
     case 8: LGS_LAUNCH(1, 2, 4, 1, 4, 6); break;
     case 9: LGS_LAUNCH(1, 2, 2, 2, 4, 6); break;
     case 10: LGS_LAUNCH(1, 2, 2, 1, 4, 6); break;

@@ -268,7 +268,7 @@ def test_bf16_mfma_paths_all_tile_shapes(cin, cout, ks, st):
         assert rel_err(a, b) < 2e-2, n
 
 
-@pytest.mark.parametrize("cin,cout", [(96, 96), (128, 96), (32, 32), (32, 64)])
+@pytest.mark.parametrize("cin,cout", [(96, 96), (128, 96), (32, 32), (32, 64), (64, 256)])
 def test_bf16_conv_on_a_large_map(cin, cout):
     """maps of >= 65536 positions take the 'big' tile configurations of k_conv_gather and the one-offset-per-wave
     schedule of k_wgrad_bf16; reading y.C while kernels are still queued must not disturb them (the coordinate export
