@@ -172,6 +172,13 @@ int lgs_clip_similarity(const void *feat, int64_t n, int c, const float *anchors
                         float *inv_norm_f, int dtype, void *workspace, void *stream);
 int64_t lgs_clip_workspace_bytes(int c, int n_anchor, int dtype);
 
+/* ---- fused SGD step on a flat parameter / gradient bucket -----------------------------------------
+ * torch.optim.SGD's update rule as the reference configures it (/root/reference/lib/solvers.py: momentum 0.9,
+ * dampening 0.1, weight_decay 1e-4) in ONE pass:  d = g + wd*p;  buf = first_step ? d : m*buf + (1-damp)*d;
+ * p -= lr * mask * buf.   mask (may be NULL) zeroes the update of parameters that received no gradient this step. */
+int lgs_sgd_step(float *params, const float *grads, float *momentum_buf, const float *mask, int64_t n, float lr,
+                 float momentum, float dampening, float weight_decay, int first_step, void *stream);
+
 /* ---- voxelisation on the device (the step in front of the hot path) ----------------
  * lgs_voxelize: points[n,3] float32 -> coords[n,4] int32 = (batch, floor(A * (x,y,z,1))), A = 3x4 row-major affine
  *   given as 12 HOST doubles (voxel scale / rotation / translation), evaluated in double like numpy's:

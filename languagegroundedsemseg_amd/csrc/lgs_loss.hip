@@ -117,3 +117,50 @@ extern "C" int lgs_ce_forward_backward(const void *logits, int64_t n, int c, con
   LGS_HIP(hipGetLastError());
   return 0;
 }
+
+// ---- fused SGD step on a flat bucket (torch.optim.SGD's rule, /root/reference/lib/solvers.py: momentum 0.9,
+// dampening 0.1, weight decay 1e-4): d = g + wd * p;  buf = first ? d : m * buf + (1 - damp) * d;  p -= lr * mask * buf
+// one pass over the bucket instead of four elementwise kernels
+namespace lgs {
+__global__ void k_sgd_step(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ buf,
+                           const float *__restrict__ mask, int64_t n, float lr, float momentum, float dampening, float wd,
+                           int first) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {
+    float4 pv = *reinterpret_cast<float4 *>(p + i);
+    const float4 gv = *reinterpret_cast<const float4 *>(g + i);
+    float4 bv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4 *>(buf + i);
+    float4 mv = mask ? *reinterpret_cast<const float4 *>(mask + i) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float d;
+#define LGS_SGD1(c)                                                                  \
+    d = gv.c + wd * pv.c;                                                             \
+    bv.c = momentum != 0.f ? (first ? d : momentum * bv.c + (1.f - dampening) * d) : d; \
+    pv.c -= lr * mv.c * bv.c;
+    LGS_SGD1(x) LGS_SGD1(y) LGS_SGD1(z) LGS_SGD1(w)
+#undef LGS_SGD1
+    if (momentum != 0.f) *reinterpret_cast<float4 *>(buf + i) = bv;
+    *reinterpret_cast<float4 *>(p + i) = pv;
+  } else {
+    for (int64_t j = i; j < n; ++j) {
+      const float d = g[j] + wd * p[j];
+      float b = momentum != 0.f ? (first ? d : momentum * buf[j] + (1.f - dampening) * d) : d;
+      if (momentum != 0.f) buf[j] = b;
+      p[j] -= lr * (mask ? mask[j] : 1.f) * b;
+    }
+  }
+}
+}  // namespace lgs
+
+extern "C" int lgs_sgd_step(float *params, const float *grads, float *momentum_buf, const float *mask, int64_t n, float lr,
+                            float momentum, float dampening, float weight_decay, int first_step, void *stream) {
+  LGS_REQUIRE(n >= 0 && (n == 0 || (params && grads && (momentum == 0.f || momentum_buf))), "lgs_sgd_step: bad argument");
+  LGS_REQUIRE(((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(momentum_buf) |
+                reinterpret_cast<uintptr_t>(mask)) & 15u) == 0, "lgs_sgd_step: buffers must be 16-byte aligned");
+  if (n == 0) return 0;
+  const int64_t threads = (n + 3) / 4;
+  hipLaunchKernelGGL(lgs::k_sgd_step, (unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream, params, grads, momentum_buf,
+                     mask, n, lr, momentum, dampening, weight_decay, first_step);
+  LGS_HIP(hipGetLastError());
+  return 0;
+}

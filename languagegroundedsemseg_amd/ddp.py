@@ -146,6 +146,7 @@ class FlatSGD:
 
     @torch.no_grad()
     def step(self):
+        fused = self.state and self.state[0]["p"].is_cuda
         for b, st in zip(self.ddp.buckets, self.state):
             g = b["flat"]
             # parameters without a gradient this step (grad is None) must not move, not even by weight decay / momentum
@@ -154,6 +155,19 @@ class FlatSGD:
                 st["mask"].fill_(1.0)
                 for p, off in unused:
                     st["mask"][off:off + p.numel()] = 0.0
+            if fused:   # one kernel per bucket (lgs_sgd_step) instead of four elementwise passes
+                import ctypes
+                from . import engine
+                first = st["buf"] is None
+                if first and self.momentum != 0:
+                    st["buf"] = torch.empty_like(g)
+                vp = ctypes.c_void_p
+                with torch.cuda.device(g.device):
+                    engine.check(engine.lib().lgs_sgd_step(
+                        vp(st["p"].data_ptr()), vp(g.data_ptr()), vp(st["buf"].data_ptr()) if st["buf"] is not None else vp(None),
+                        vp(st["mask"].data_ptr()) if unused else vp(None), int(g.numel()), float(self.lr), float(self.momentum),
+                        float(self.dampening), float(self.weight_decay), int(first), vp(torch.cuda.current_stream(g.device).cuda_stream)))
+                continue
             d = g.add(st["p"], alpha=self.weight_decay) if self.weight_decay != 0 else g.clone()
             if self.momentum != 0:
                 if st["buf"] is None:

@@ -24,7 +24,7 @@ EXPORTS = [
     "lgs_bn_stats", "lgs_bn_sync_combine", "lgs_bn_apply", "lgs_bn_backward_reduce", "lgs_bn_backward_apply",
     "lgs_clip_similarity", "lgs_clip_workspace_bytes",
     "lgs_ce_forward_backward",
-    "lgs_voxelize", "lgs_label_vote", "lgs_cluster_workspace_bytes", "lgs_cluster",
+    "lgs_voxelize", "lgs_label_vote", "lgs_cluster_workspace_bytes", "lgs_cluster", "lgs_sgd_step",
 ]
 
 
@@ -62,6 +62,7 @@ def lib():
         "lgs_kmap_export": [vp, vp, vp, vp, vp, pi64],
         "lgs_conv_forward": [vp, ci, vp, ci, vp, ci, vp, vp, ci, vp, vp],
         "lgs_conv_dgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp],
+        "lgs_sgd_step": [vp, vp, vp, vp, i64, cf, cf, cf, cf, ci, vp],
         "lgs_cluster": [vp, vp, vp, i64, cf, ci, vp, ctypes.POINTER(ctypes.c_int32), vp, vp],
         "lgs_voxelize": [vp, i64, ctypes.POINTER(ctypes.c_double), ci, vp, vp],
         "lgs_label_vote": [vp, i64, vp, vp, i64, i64, vp, vp],

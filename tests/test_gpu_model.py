@@ -193,3 +193,36 @@ def test_insseg_head_matches_reference_fixture_on_the_engine():
     (nl + dl + logits.F.float().square().mean()).backward()
     assert m.offsets.kernel.grad is not None and torch.isfinite(m.offsets.kernel.grad).all()
     assert torch.isfinite(m.conv0p1s1.kernel.grad).all()
+
+
+def test_fused_flat_sgd_on_device_equals_torch_sgd():
+    """FlatSGD's one-kernel bucket update (lgs_sgd_step) == torch.optim.SGD(momentum, dampening, weight_decay) of
+    lib/solvers.py over several steps, including a parameter that never receives a gradient"""
+    import torch.nn as nn
+    from languagegroundedsemseg_amd.ddp import BucketedDDP, FlatSGD
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b, self.unused = nn.Linear(8, 16), nn.Linear(16, 5), nn.Linear(3, 3)
+
+        def forward(self, x):
+            return self.b(torch.relu(self.a(x)))
+    torch.manual_seed(0)
+    a, b = Net().to(DEV), Net().to(DEV)
+    b.load_state_dict(a.state_dict())
+    ddp = BucketedDDP(a, bucket_mb=0.0005)
+    fo = FlatSGD(ddp, lr=0.05, momentum=0.9, dampening=0.1, weight_decay=1e-2)
+    to = torch.optim.SGD(b.parameters(), lr=0.05, momentum=0.9, dampening=0.1, weight_decay=1e-2)
+    x, y = torch.randn(16, 8, device=DEV), torch.randn(16, 5, device=DEV)
+    for step in range(4):
+        ddp.zero_grad()
+        ((a(x) - y) ** 2).mean().backward()
+        ddp.finalize()
+        fo.step()
+        to.zero_grad(set_to_none=True)
+        ((b(x) - y) ** 2).mean().backward()
+        to.step()
+    for (n1, p1), (n2, p2) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.allclose(p1, p2, atol=1e-6), n1
+    assert torch.equal(a.unused.weight, b.unused.weight)
