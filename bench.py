@@ -264,8 +264,12 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL / tensor sharing)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            try:
+                dist.init_process_group("nccl", device_id=device)
+            except TypeError:                                       # older torch: no device_id argument
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group(args.backend)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
