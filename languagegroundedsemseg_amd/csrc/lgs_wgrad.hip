@@ -299,9 +299,12 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_bf16(View v, const bf16_t *_
       if (v.KS > 1) grp_ok = grp_ok && ((v.mask64[bb >> 6] >> slot) & 1u);
       else if (v.tile_k) grp_ok = grp_ok && (v.tile_k[bb >> 6] == k);
       const int64_t p = bb + lane;
-      const int32_t o = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
-      const int32_t i = v.nbr ? v.nbr[(int64_t)slot * v.n_pad + p] : (p < v.n_in ? (int32_t)p : -1);
-      iv[u] = grp_ok ? i : -1;
+      int32_t o = -1, i = -1;
+      if (grp_ok) {   // wave-uniform: groups whose mask lacks this offset (about half of them) cost no index loads
+        o = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
+        i = v.nbr ? v.nbr[(int64_t)slot * v.n_pad + p] : (p < v.n_in ? (int32_t)p : -1);
+      }
+      iv[u] = i;
       ov[u] = o;
     }
 #pragma unroll
