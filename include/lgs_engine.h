@@ -172,6 +172,28 @@ int lgs_clip_similarity(const void *feat, int64_t n, int c, const float *anchors
                         float *inv_norm_f, int dtype, void *workspace, void *stream);
 int64_t lgs_clip_workspace_bytes(int c, int n_anchor, int dtype);
 
+/* ---- fused CLIP text-anchor loss (forward in ONE pass over the features, 4-sparse backward) --------
+ * replaces ContrastiveLanguageLoss.forward's arithmetic (gather [N,1+K,C] + feat_dist bmm) AND feature_sim + argmax
+ *   /root/reference/lib/losses/ContrastiveLanguageLoss.py:73-95 (feat_dist, cos), :185-192 (hinge inputs)
+ *   /root/reference/lib/losses/utils.py:80-103 (feature_sim, cosine branch) + pl_RepresentationTrainer.py:237-238 (argmax)
+ * lgs_clip_loss_forward: per row n (labels[n] == ignore_label, or outside [0, n_anchor): d_pos = d_neg = 0, :94)
+ *   d_pos[n] = 1 - <f^_n, t^_labels[n]>,   d_neg[n] = 1 - mean_j <f^_n, t^_neg[n,j]>,   j < k_neg (1..7)
+ *   pred[n]  = argmax_a <f^_n, t^_a>  (first maximum; may be NULL),   inv_norm_f[n] = 1 / max(|f_n|, 1e-12)
+ *   anchors_n[n_anchor, c] (float32 out) = row-normalised anchors, kept for the backward
+ *   sim[n, n_anchor] (float32) is written only when non-NULL (metrics / visualisation): the loss never needs it.
+ *   n_anchor % 4 == 0, 4 <= n_anchor <= 224 (a wavefront owns all anchor columns of its rows).
+ * lgs_clip_loss_backward: grad_feat[n, c] (dtype) from the upstream g_dpos[n], g_dneg[n] (float32, either may be NULL):
+ *   gf = ( sum_j gs_j t^_j - (sum_j gs_j s_j) f^ ) / |f|  with  gs_pos = -g_dpos, gs_neg_j = -g_dneg / k_neg  (zero rows
+ *   for ignored labels).  d_pos / d_neg / inv_norm_f / anchors_n are the forward's outputs. */
+int64_t lgs_clip_loss_workspace_bytes(int c, int n_anchor, int dtype);
+int lgs_clip_loss_forward(const void *feat, int64_t n, int c, const float *anchors, int n_anchor, const int64_t *labels,
+                          const int64_t *neg, int k_neg, int64_t ignore_label, float *d_pos, float *d_neg, int64_t *pred,
+                          float *inv_norm_f, float *anchors_n, float *sim, int dtype, void *workspace, void *stream);
+int lgs_clip_loss_backward(const void *feat, int64_t n, int c, const float *anchors_n, int n_anchor, const int64_t *labels,
+                           const int64_t *neg, int k_neg, int64_t ignore_label, const float *inv_norm_f, const float *d_pos,
+                           const float *d_neg, const float *g_dpos, const float *g_dneg, void *grad_feat, int dtype,
+                           void *stream);
+
 /* ---- fused SGD step on a flat parameter / gradient bucket -----------------------------------------
  * torch.optim.SGD's update rule as the reference configures it (/root/reference/lib/solvers.py: momentum 0.9,
  * dampening 0.1, weight_decay 1e-4) in ONE pass:  d = g + wd*p;  buf = first_step ? d : m*buf + (1-damp)*d;
@@ -210,7 +232,9 @@ int lgs_cluster(const float *xyz, const int32_t *batch_idx, const int32_t *seman
  * replaces nn.CrossEntropyLoss(ignore_index=-1) on the [N,200] logits of the fine-tune step
  *   /root/reference/lib/train_test/pl_BaselineTrainer.py:94-99,350
  * One pass: loss_rows[n] (float32, 0 for ignored rows) and dlogits[n,c] = (softmax - onehot) * (*scale)
- * (same dtype as logits, zeros for ignored rows).  `scale` is a DEVICE float (e.g. 1 / #valid rows, times
+ * (same dtype as logits, zeros for ignored rows; rows whose label is outside [0, c) are treated as ignored).  Any class
+ * count up to 512 (fp32) / 1024 (bf16) is accepted; counts that are not a multiple of the 16-byte width (20 ScanNet
+ * classes in bf16) take element-wise accesses.  `scale` is a DEVICE float (e.g. 1 / #valid rows, times
  * the upstream gradient), so the mean reduction needs no host sync.  Either output may be NULL: the host
  * wrapper asks for the loss in the forward pass and for the gradient in the backward pass. */
 int lgs_ce_forward_backward(const void *logits, int64_t n, int c, const int64_t *labels, int64_t ignore_index,

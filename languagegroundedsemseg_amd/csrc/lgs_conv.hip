@@ -118,9 +118,42 @@ __global__ void k_unpad_rows(const T *__restrict__ src, int64_t n, int c, int cp
   dst[i] = src[(i / c) * cpad + (i % c)];
 }
 
+// ------------------------------------------------------------------------------------ CLIP-loss epilogue (EPI = 1)
+// The contraction S = normalize(F) . normalize(T)^T of ContrastiveLanguageLoss.feat_dist / feature_sim
+// (/root/reference/lib/losses/ContrastiveLanguageLoss.py:73-95,185-192, lib/losses/utils.py:80-103) never needs its
+// [N, n_anchor] result in memory: the loss reads 1 + K entries per row and the metrics read the arg-max.  With EPI = 1
+// the tile's accumulators are reduced in the epilogue to  d_pos = 1 - s[label],  d_neg = 1 - mean_j s[neg_j],
+// pred = argmax_a s[a]  and  1/|f|  (|f|^2 is accumulated from the operand fragments as they stream through, so the
+// features are read exactly once); the similarity matrix itself is written only when the caller asks for it.
+struct ClipEpi {
+  const int64_t *labels = nullptr;   // [n]
+  const int64_t *neg = nullptr;      // [n, k_neg] negative anchor indices
+  int k_neg = 0;                     // 1..7
+  int n_anchor = 0;
+  int64_t ignore = -1;
+  float *d_pos = nullptr, *d_neg = nullptr, *inv_norm = nullptr;
+  int64_t *pred = nullptr;
+};
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+template <typename T> __device__ inline float sq16(const u32x4 &f, float s);
+template <> __device__ inline float sq16<bf16_t>(const u32x4 &f, float s) {
+  // two bf16 per dword: the high one IS an fp32 with the low half masked off, the low one is a 16-bit shift away
+  const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+    s = fmaf(hi, hi, fmaf(lo, lo, s));
+  }
+  return s;
+}
+template <> __device__ inline float sq16<float>(const u32x4 &f, float s) {
+  const float a = __uint_as_float(f.x), b = __uint_as_float(f.y), c = __uint_as_float(f.z), d = __uint_as_float(f.w);
+  return fmaf(d, d, fmaf(c, c, fmaf(b, b, fmaf(a, a, s))));
+}
+
 // ------------------------------------------------------------------------------------ forward / dgrad
 // Tile: WM x WN waves; each wave owns RB*32 positions x NCB*32 output channels.
-template <typename T, int RB, int NCB, int WM, int WN, int SC, int D>
+template <typename T, int RB, int NCB, int WM, int WN, int SC, int D, int EPI = 0>
 __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__restrict__ in, int cin_real, int nc,
                                                              const u32x4 *__restrict__ wp, int nb_total,
                                                              int ncp, int nbp,
@@ -128,7 +161,9 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
                                                              const float *__restrict__ bias,
                                                              float *__restrict__ out_f32_arg,
                                                              const float *__restrict__ row_scale,
-                                                             unsigned in_bytes, unsigned w_bytes, int64_t zstride) {
+                                                             unsigned in_bytes, unsigned w_bytes, int64_t zstride,
+                                                             ClipEpi ce) {
+  static_assert(EPI == 0 || (RB == 1 && WN == 1), "the CLIP epilogue owns whole rows: one row block, all columns per wave");
   // SC = 32-channel chunks per weight SLAB: the weights of (offset, slab) are staged in LDS once per workgroup
   // and one barrier separates slabs, while the gathered feature fragments stream chunk by chunk through a
   // D-deep register ring (loads issued D-1 chunks = several hundred MFMA cycles ahead of their use) that runs
@@ -265,8 +300,13 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
       if (e < SLAB) lds[buf][e] = wreg[i];
     }
   };
+  float sumsq = 0.f;   // EPI = 1: |f|^2 of this lane's channel half of row vx
   auto compute = [&](int buf, int cc, const u32x4 (&F)[RB][LD], uint32_t act) __attribute__((always_inline)) {
     if (act == 0) return;
+    if constexpr (EPI == 1) {
+#pragma unroll
+      for (int t = 0; t < LD; ++t) sumsq = sq16<T>(F[0][t], sumsq);
+    }
     const u32x4 *wl = &lds[buf][cc * WCH + (wn * NCB) * LD * 64 + lane];
     // all weight fragments of the chunk are requested up front: the LDS latency of step t+1 hides under the
     // MFMAs of step t (the compiler otherwise waits lgkmcnt(0) in front of every MFMA triple)
@@ -374,6 +414,75 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     }
   }
 
+  if constexpr (EPI == 1) {
+    // ---- CLIP-loss epilogue.  The weight LDS is idle now: every wave parks one 32 x 32 block of its similarity tile
+    // there at a time (row stride 36 floats) so that a lane can pick the entries of ITS row's label / negatives with
+    // an indexed ds_read (registers cannot be indexed per lane); the arg-max runs on the registers.
+    __syncthreads();
+    float *tile = reinterpret_cast<float *>(&lds[0][0]) + wave * (32 * 36);
+    sumsq += __shfl_xor(sumsq, 32);
+    const float inv = 1.f / fmaxf(sqrtf(sumsq), 1e-12f);
+    const int64_t p = pos_w + vx;
+    const bool live = p < v.n_out;
+    // half h of row vx handles targets j = h, h + 2, ...  (j = 0: the positive, j >= 1: negative j - 1)
+    int tcol[4];
+    int64_t lab = ce.ignore;
+    if (live) lab = ce.labels[p];
+    const bool valid = live && lab != ce.ignore && lab >= 0 && lab < ce.n_anchor;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = 2 * jj + h;
+      int t = -1;
+      if (valid && j <= ce.k_neg) {
+        const int64_t tt = j == 0 ? lab : ce.neg[p * ce.k_neg + (j - 1)];
+        t = (tt >= 0 && tt < ce.n_anchor) ? (int)tt : -1;
+      }
+      tcol[jj] = t;
+    }
+    float best = -3.0e38f, spos = 0.f, sneg = 0.f;
+    int bi = 0;
+#pragma unroll
+    for (int nb = 0; nb < NCB; ++nb) {
+      if (nb_w + nb >= nb_total) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = (nb_w + nb) * 32 + 8 * q + 4 * h;
+        const float s0 = acc[0][nb][4 * q + 0] * inv, s1 = acc[0][nb][4 * q + 1] * inv, s2 = acc[0][nb][4 * q + 2] * inv,
+                    s3 = acc[0][nb][4 * q + 3] * inv;
+        *reinterpret_cast<float4 *>(tile + vx * 36 + 8 * q + 4 * h) = make_float4(s0, s1, s2, s3);
+        if (c0 + 0 < ce.n_anchor && s0 > best) { best = s0; bi = c0 + 0; }
+        if (c0 + 1 < ce.n_anchor && s1 > best) { best = s1; bi = c0 + 1; }
+        if (c0 + 2 < ce.n_anchor && s2 > best) { best = s2; bi = c0 + 2; }
+        if (c0 + 3 < ce.n_anchor && s3 > best) { best = s3; bi = c0 + 3; }
+        if (out_f32 && live && c0 < cout_real)
+          *reinterpret_cast<float4 *>(out_f32 + p * cout_real + c0) = make_float4(s0, s1, s2, s3);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int t = tcol[jj];
+        if (t >= 0 && (t >> 5) == nb_w + nb) {
+          const float sv = tile[vx * 36 + (t & 31)];
+          if (jj == 0 && h == 0) spos = sv; else sneg += sv;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    {  // the two halves of a row: first maximum (lowest index on ties), sums
+      const float ob = __shfl_xor(best, 32);
+      const int oi = __shfl_xor(bi, 32);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      sneg += __shfl_xor(sneg, 32);
+      spos += __shfl_xor(spos, 32);
+    }
+    if (live && h == 0) {
+      ce.d_pos[p] = valid ? 1.f - spos : 0.f;
+      ce.d_neg[p] = valid ? 1.f - sneg / (float)ce.k_neg : 0.f;
+      if (ce.pred) ce.pred[p] = bi;
+      if (ce.inv_norm) ce.inv_norm[p] = inv;
+    }
+    return;
+  }
   // ---- epilogue: lane (voxel vx, half h) owns channels nb*32 + 8q + 4h + {0..3}
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
@@ -497,7 +606,7 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
     if (did_split) grid.z = 3;                                                                                    \
     hipLaunchKernelGGL((k_conv_gather<T, RB, NCB, WM, WN, SC, D>), grid, dim3(WM *WN * 64), 0, s, v, in, cin_real, nc,    \
                        reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, out, cout_real, did_split ? nullptr : bias, \
-                       did_split ? zpartial : out_f32, row_scale, in_bytes, w_bytes, zstride);                    \
+                       did_split ? zpartial : out_f32, row_scale, in_bytes, w_bytes, zstride, ClipEpi());         \
   } while (0)
   switch (cfg.id) {
     case 0: LGS_LAUNCH(2, 1, 4, 1, (kF32 ? 2 : 4), (kF32 ? 3 : 4)); break;
@@ -638,6 +747,50 @@ int clip_similarity_t(const void *feat, int64_t n, int c, const float *anchors, 
   return launch_gather<T>(v, cfg, f, c, nc, wp, nb_total, ncp, nbp, 1, (T *)nullptr, na, nullptr, s, sim, inv);
 }
 
+// Fused CLIP loss forward: one launch of the EPI = 1 instance.  The wave owns whole rows (all anchor columns), so
+// the anchor count is limited to 7 column blocks (224); the 200 ScanNet200 anchors use the 7-block tile.
+template <typename T>
+int clip_loss_forward_t(const void *feat, int64_t n, int c, const float *anchors, int na, const ClipEpi &ce_in, float *anchors_n,
+                        float *sim, void *workspace, hipStream_t s) {
+  constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
+  constexpr bool kF32 = (sizeof(T) == 4);
+  LGS_REQUIRE(c % EPL == 0, "lgs_clip_loss_forward: feature dim must be a multiple of the 16-byte load width");
+  LGS_REQUIRE(na % 4 == 0 && na >= 4 && na <= 224, "lgs_clip_loss_forward: anchor count must be a multiple of 4 in [4, 224]");
+  LGS_REQUIRE(ce_in.k_neg >= 1 && ce_in.k_neg <= 7, "lgs_clip_loss_forward: 1..7 negatives per row");
+  if (n == 0) return 0;
+  const int nc = pad32(c) / 32, nb_total = pad32(na) / 32;
+  const int ncb = nb_total <= 1 ? 1 : nb_total <= 2 ? 2 : nb_total <= 4 ? 4 : 7;
+  const int sc = ncb == 1 ? (kF32 ? 4 : 8) : ncb == 2 ? (kF32 ? 2 : 4) : ncb == 4 ? (kF32 ? 1 : 2) : (kF32 ? 1 : 2);
+  const int ncp = (nc + sc - 1) / sc * sc, nbp = ncb;
+  char *ws = reinterpret_cast<char *>(workspace);
+  uint4 *wp = reinterpret_cast<uint4 *>(ws);
+  hipLaunchKernelGGL(k_normalize_anchors, na, 64, 0, s, anchors, na, c, anchors_n);
+  int64_t total = (int64_t)ncp * nbp * LD * 64;
+  // T^[a][c] read as w[o = a][g = c]  ("transposed" form of the packer with cin_w = na, cout_w = c)
+  hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, anchors_n, 1, na, c, 1, 0, c, na, ncp, nbp, wp);
+  View v;
+  v.n_pad = pad_rows(n); v.n_out = n; v.n_in = n; v.KS = 1; v.K = 1;
+  const uint64_t in_bytes64 = (uint64_t)n * (uint64_t)c * sizeof(T), w_bytes64 = (uint64_t)total * 16;
+  LGS_REQUIRE(in_bytes64 < 0xfffff000ull, "lgs_clip_loss_forward: feature tensor of 4 GiB or more");
+  ClipEpi ce = ce_in;
+  ce.n_anchor = na;
+  const T *f = reinterpret_cast<const T *>(feat);
+  dim3 grid((unsigned)(v.n_pad / 128), 1);
+#define LGS_CLIP(NCB, SC, D)                                                                                              \
+  hipLaunchKernelGGL((k_conv_gather<T, 1, NCB, 4, 1, SC, D, 1>), grid, dim3(256), 0, s, v, f, c, nc,                      \
+                     reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, (T *)nullptr, na, (const float *)nullptr, sim, \
+                     (const float *)nullptr, (unsigned)in_bytes64, (unsigned)w_bytes64, (int64_t)0, ce)
+  switch (ncb) {
+    case 1: LGS_CLIP(1, (kF32 ? 4 : 8), (kF32 ? 4 : 8)); break;
+    case 2: LGS_CLIP(2, (kF32 ? 2 : 4), (kF32 ? 3 : 4)); break;
+    case 4: LGS_CLIP(4, (kF32 ? 1 : 2), (kF32 ? 3 : 4)); break;
+    default: LGS_CLIP(7, (kF32 ? 1 : 2), (kF32 ? 3 : 4)); break;
+  }
+#undef LGS_CLIP
+  LGS_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace lgs
 
 using namespace lgs;
@@ -652,7 +805,7 @@ int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtyp
   int64_t bytes = align256((int64_t)km->K * (pad32(g) + 96) * (pad32(o) + 96) * e);
   int64_t nmax = km->fwd.n_in > km->bwd.n_in ? km->fwd.n_in : km->bwd.n_in;
   if (g % epl(dtype) != 0) bytes += align256(nmax * pad32(g) * e);
-  if (o % 4 != 0) bytes += align256(nmax * (int64_t)((o + 3) / 4 * 4) * e) + 256;   // scratch image + padded bias
+  if (o % 4 != 0) bytes += align256(nmax * (int64_t)((o + 3) / 4 * 4) * e) + align256(4 * (int64_t)((o + 3) / 4 * 4)) + 256;   // scratch image + padded bias
   int64_t omax = km->fwd.n_out > km->bwd.n_out ? km->fwd.n_out : km->bwd.n_out;
   bytes += lgs::split_partial_bytes(km->K, omax, o) + lgs::split_partial_bytes(km->K, omax, (o + 3) / 4 * 4);
   return bytes + 256;
@@ -691,6 +844,24 @@ extern "C" {
 int64_t lgs_clip_workspace_bytes(int c, int n_anchor, int dtype) {
   int64_t b = align256((int64_t)n_anchor * c * 4) + align256((int64_t)(pad32(c) + 96) * (pad32(n_anchor) + 96) * esize(dtype));
   return b + 256;
+}
+
+int64_t lgs_clip_loss_workspace_bytes(int c, int n_anchor, int dtype) {
+  (void)n_anchor;
+  return align256((int64_t)(pad32(c) + 256) * 256 * esize(dtype)) + 256;   // packed anchors: <= (nc + 7) chunks x 7 blocks
+}
+
+int lgs_clip_loss_forward(const void *feat, int64_t n, int c, const float *anchors, int n_anchor, const int64_t *labels,
+                          const int64_t *neg, int k_neg, int64_t ignore_label, float *d_pos, float *d_neg, int64_t *pred,
+                          float *inv_norm_f, float *anchors_n, float *sim, int dtype, void *workspace, void *stream) {
+  LGS_REQUIRE(feat && anchors && labels && neg && d_pos && d_neg && anchors_n && workspace, "lgs_clip_loss_forward: null argument");
+  ClipEpi ce;
+  ce.labels = labels; ce.neg = neg; ce.k_neg = k_neg; ce.ignore = ignore_label;
+  ce.d_pos = d_pos; ce.d_neg = d_neg; ce.pred = pred; ce.inv_norm = inv_norm_f;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LGS_F32) return clip_loss_forward_t<float>(feat, n, c, anchors, n_anchor, ce, anchors_n, sim, workspace, s);
+  if (dtype == LGS_BF16) return clip_loss_forward_t<bf16_t>(feat, n, c, anchors, n_anchor, ce, anchors_n, sim, workspace, s);
+  LGS_REQUIRE(false, "lgs_clip_loss_forward: unknown dtype");
 }
 
 int lgs_clip_similarity(const void *feat, int64_t n, int c, const float *anchors, int n_anchor, float *sim,

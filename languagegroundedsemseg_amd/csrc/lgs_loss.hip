@@ -33,6 +33,8 @@ template <> struct LVec<bf16_t> {
 };
 
 constexpr int kMaxChunks = 4;  // 16-byte chunks per lane per row: C <= 32 * 4 * W
+__device__ inline void st_elem(float *p, float v) { *p = v; }
+__device__ inline void st_elem(bf16_t *p, float v) { *p = f32_to_bf16(v); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_ce_fwd_bwd(const T *__restrict__ logits, int64_t n, int c, const int64_t *__restrict__ labels,
@@ -42,7 +44,10 @@ __global__ __launch_bounds__(256) void k_ce_fwd_bwd(const T *__restrict__ logits
   const int lane = threadIdx.x & 31;  // half-wave per row
   const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   if (row >= n) return;
-  const int nchunk = c / W;
+  // class counts that are not a multiple of the 16-byte width (e.g. the 20 ScanNet classes in bf16) take
+  // element-wise loads / stores for their rows: kernel-uniform branch, padding lanes hold -inf -> exp = 0
+  const bool vec = (c % W) == 0;
+  const int nchunk = (c + W - 1) / W;
   const int64_t lab = labels[row];
   const bool ignored = (lab == ignore_index) || lab < 0 || lab >= c;
   float v[kMaxChunks][W];
@@ -51,7 +56,12 @@ __global__ __launch_bounds__(256) void k_ce_fwd_bwd(const T *__restrict__ logits
   for (int q = 0; q < kMaxChunks; ++q) {
     const int ch = q * 32 + lane;
     if (ch < nchunk) {
-      LVec<T>::load(logits + row * c + ch * W, v[q]);
+      if (vec) {
+        LVec<T>::load(logits + row * c + ch * W, v[q]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < W; ++i) v[q][i] = ch * W + i < c ? ld_elem(logits + row * c + ch * W + i) : -3.0e38f;
+      }
 #pragma unroll
       for (int i = 0; i < W; ++i) mx = fmaxf(mx, v[q][i]);
     }
@@ -89,7 +99,13 @@ __global__ __launch_bounds__(256) void k_ce_fwd_bwd(const T *__restrict__ logits
         if ((int64_t)(ch * W + i) == lab) g -= scale;
         v[q][i] = g;
       }
-      LVec<T>::store(dlogits + row * c + ch * W, v[q]);
+      if (vec) {
+        LVec<T>::store(dlogits + row * c + ch * W, v[q]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+          if (ch * W + i < c) st_elem(dlogits + row * c + ch * W + i, v[q][i]);
+      }
     }
   }
 }
@@ -102,7 +118,7 @@ extern "C" int lgs_ce_forward_backward(const void *logits, int64_t n, int c, con
                                        const float *scale, float *loss_rows, void *dlogits, int dtype, void *stream) {
   LGS_REQUIRE(logits && labels && scale && (loss_rows || dlogits), "lgs_ce_forward_backward: null argument");
   const int W = dtype == LGS_BF16 ? 8 : 4;
-  LGS_REQUIRE(c % W == 0 && c / W <= 32 * kMaxChunks, "lgs_ce_forward_backward: class count unsupported");
+  LGS_REQUIRE(c >= 1 && (c + W - 1) / W <= 32 * kMaxChunks, "lgs_ce_forward_backward: more classes than one half-wave holds (512 fp32 / 1024 bf16)");
   if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const unsigned blocks = (unsigned)((n * 32 + 255) / 256);
@@ -114,6 +130,84 @@ extern "C" int lgs_ce_forward_backward(const void *logits, int64_t n, int c, con
                        (bf16_t *)dlogits);
   else
     LGS_REQUIRE(false, "lgs_ce_forward_backward: unknown dtype");
+  LGS_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- backward of the fused CLIP text-anchor loss (lgs_clip_loss_forward)
+//   /root/reference/lib/losses/ContrastiveLanguageLoss.py:73-95 (feat_dist, cos branch) through autograd:
+// only 1 + K entries of a row of S = f^ . T^^T carry gradient, so instead of two dense [N, A] x [A, C] products
+//   gf = ( sum_j gs_j t^_j  -  (sum_j gs_j s_j) f^ ) / |f|,      gs_pos = -g_dpos,  gs_neg_j = -g_dneg / K
+// is a pure streaming pass: read f once, gather 1 + K normalised anchor rows (L2-resident table), write gf once.
+// sum_j gs_j s_j needs only s_pos = 1 - d_pos and mean_j s_neg_j = 1 - d_neg, both saved by the forward.
+namespace lgs {
+template <typename T>
+__global__ __launch_bounds__(256) void k_clip_loss_bwd(const T *__restrict__ feat, int64_t n, int c, const float *__restrict__ tn,
+                                                       int n_anchor, const int64_t *__restrict__ labels,
+                                                       const int64_t *__restrict__ neg, int k_neg, int64_t ignore,
+                                                       const float *__restrict__ inv_norm, const float *__restrict__ d_pos,
+                                                       const float *__restrict__ d_neg, const float *__restrict__ g_dpos,
+                                                       const float *__restrict__ g_dneg, T *__restrict__ gf) {
+  constexpr int W = LVec<T>::W;
+  const int G = c / W;                       // 16-byte channel groups per row
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = idx / G;
+  const int g = (int)(idx - row * G);
+  if (row >= n) return;
+  float fv[W], out[W];
+  LVec<T>::load(feat + row * c + g * W, fv);
+  const int64_t lab = labels[row];
+  const bool valid = lab != ignore && lab >= 0 && lab < n_anchor;
+#pragma unroll
+  for (int i = 0; i < W; ++i) out[i] = 0.f;
+  if (valid) {
+    const float inv = inv_norm[row];
+    const float gp = g_dpos ? -g_dpos[row] : 0.f;
+    const float gn = g_dneg ? -g_dneg[row] / (float)k_neg : 0.f;
+    const float sigma = gp * (1.f - d_pos[row]) + gn * (float)k_neg * (1.f - d_neg[row]);
+    const float *tp = tn + lab * c + g * W;
+#pragma unroll
+    for (int i = 0; i < W; i += 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(tp + i);
+      out[i] = gp * t.x; out[i + 1] = gp * t.y; out[i + 2] = gp * t.z; out[i + 3] = gp * t.w;
+    }
+    for (int j = 0; j < k_neg; ++j) {
+      const int64_t a = neg[row * k_neg + j];
+      if (a < 0 || a >= n_anchor) continue;
+      const float *tq = tn + a * c + g * W;
+#pragma unroll
+      for (int i = 0; i < W; i += 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(tq + i);
+        out[i] += gn * t.x; out[i + 1] += gn * t.y; out[i + 2] += gn * t.z; out[i + 3] += gn * t.w;
+      }
+    }
+    const float si = sigma * inv;
+#pragma unroll
+    for (int i = 0; i < W; ++i) out[i] = (out[i] - si * fv[i]) * inv;
+  }
+  LVec<T>::store(gf + row * c + g * W, out);
+}
+}  // namespace lgs
+
+extern "C" int lgs_clip_loss_backward(const void *feat, int64_t n, int c, const float *anchors_n, int n_anchor,
+                                      const int64_t *labels, const int64_t *neg, int k_neg, int64_t ignore_label,
+                                      const float *inv_norm_f, const float *d_pos, const float *d_neg, const float *g_dpos,
+                                      const float *g_dneg, void *grad_feat, int dtype, void *stream) {
+  LGS_REQUIRE(feat && anchors_n && labels && neg && inv_norm_f && d_pos && d_neg && grad_feat, "lgs_clip_loss_backward: null argument");
+  const int W = dtype == LGS_BF16 ? 8 : 4;
+  LGS_REQUIRE(c % W == 0 && k_neg >= 1, "lgs_clip_loss_backward: feature dim must be a multiple of the 16-byte load width");
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t threads = n * (int64_t)(c / W);
+  const unsigned blocks = (unsigned)((threads + 255) / 256);
+  if (dtype == LGS_F32)
+    hipLaunchKernelGGL((k_clip_loss_bwd<float>), blocks, 256, 0, s, (const float *)feat, n, c, anchors_n, n_anchor, labels, neg, k_neg,
+                       ignore_label, inv_norm_f, d_pos, d_neg, g_dpos, g_dneg, (float *)grad_feat);
+  else if (dtype == LGS_BF16)
+    hipLaunchKernelGGL((k_clip_loss_bwd<bf16_t>), blocks, 256, 0, s, (const bf16_t *)feat, n, c, anchors_n, n_anchor, labels, neg,
+                       k_neg, ignore_label, inv_norm_f, d_pos, d_neg, g_dpos, g_dneg, (bf16_t *)grad_feat);
+  else
+    LGS_REQUIRE(false, "lgs_clip_loss_backward: unknown dtype");
   LGS_HIP(hipGetLastError());
   return 0;
 }

@@ -322,6 +322,7 @@ using namespace lgs;
 
 struct lgs_manager {
   int device = 0;
+  hipMemPool_t pool = nullptr;
   // All map construction runs on the manager's OWN stream: the host-side row-count syncs then wait for map work
   // only (never for the compute backlog of the caller's stream), and the maps of step t+1 are built while step t's
   // backward is still running.  Consumers order themselves after `ev_ready` (lgs::kmap_wait).
@@ -337,14 +338,49 @@ struct lgs_manager {
 
 namespace {
 
+// the entry points run on the manager's device and leave the caller's current device as they found it
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+// The maps of step t+1 reuse step t's memory: map arrays come from a PRIVATE stream-ordered pool per device whose
+// release threshold is unlimited (the process-wide default pool is left alone).
+hipMemPool_t g_pool[64] = {nullptr};
+int ensure_pool(int device) {
+  if (g_pool[device]) return 0;
+  hipMemPoolProps props;
+  memset(&props, 0, sizeof(props));
+  props.allocType = hipMemAllocationTypePinned;
+  props.handleTypes = hipMemHandleTypeNone;
+  props.location.type = hipMemLocationTypeDevice;
+  props.location.id = device;
+  hipMemPool_t pool = nullptr;
+  LGS_HIP(hipMemPoolCreate(&pool, &props));
+  uint64_t thr = UINT64_MAX;
+  LGS_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr));
+  g_pool[device] = pool;
+  return 0;
+}
+inline hipError_t pool_alloc(lgs_manager *m, void **q, size_t bytes, hipStream_t s);
+
 template <typename T>
 int dalloc(lgs_manager *m, T **p, int64_t count, hipStream_t s) {
   void *q = nullptr;
   size_t bytes = sizeof(T) * (size_t)(count > 0 ? count : 1);
-  LGS_HIP(hipMallocAsync(&q, bytes, s));
+  LGS_HIP(pool_alloc(m, &q, bytes, s));
   m->allocs.push_back(q);
   *p = reinterpret_cast<T *>(q);
   return 0;
+}
+inline hipError_t pool_alloc(lgs_manager *m, void **q, size_t bytes, hipStream_t s) {
+  return hipMallocFromPoolAsync(q, bytes, m->pool, s);
 }
 int dfree_now(lgs_manager *m, void *q, hipStream_t s) {  // temp buffer: release early
   for (size_t i = 0; i < m->allocs.size(); ++i)
@@ -393,7 +429,7 @@ int scan_incl(lgs_manager *m, const int32_t *in, int32_t *out, int64_t n, hipStr
   size_t tb = 0;
   LGS_HIP(rocprim::inclusive_scan(nullptr, tb, in, out, (size_t)n, rocprim::plus<int32_t>(), s));
   void *tmp = nullptr;
-  LGS_HIP(hipMallocAsync(&tmp, tb ? tb : 16, s));
+  LGS_HIP(pool_alloc(m, &tmp, tb ? tb : 16, s));
   LGS_HIP(rocprim::inclusive_scan(tmp, tb, in, out, (size_t)n, rocprim::plus<int32_t>(), s));
   LGS_HIP(hipFreeAsync(tmp, s));
   return 0;
@@ -417,17 +453,15 @@ const char *lgs_last_error(void) { return g_err.c_str(); }
 
 int lgs_manager_create(int device, lgs_manager **out) {
   LGS_REQUIRE(out != nullptr, "lgs_manager_create: null out");
-  LGS_HIP(hipSetDevice(device));
-  hipMemPool_t pool;
-  LGS_HIP(hipDeviceGetDefaultMemPool(&pool, device));
-  uint64_t thr = UINT64_MAX;  // keep freed blocks cached: the maps of step t+1 reuse step t's memory
-  LGS_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr));
+  LGS_REQUIRE(device >= 0 && device < 64, "lgs_manager_create: device index out of range");
+  DeviceGuard guard(device);
+  if (ensure_pool(device)) return 1;
   lgs_manager *m = new lgs_manager();
   m->device = device;
+  m->pool = g_pool[device];
   // one map stream per device for the whole process (creating / destroying a stream per batch costs host time and
   // can block): managers of consecutive steps simply queue behind each other on it
   static hipStream_t g_map_stream[64] = {nullptr};
-  LGS_REQUIRE(device >= 0 && device < 64, "lgs_manager_create: device index out of range");
   if (!g_map_stream[device]) LGS_HIP(hipStreamCreateWithFlags(&g_map_stream[device], hipStreamNonBlocking));
   m->ms = g_map_stream[device];
   LGS_HIP(hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming));
@@ -438,7 +472,7 @@ int lgs_manager_create(int device, lgs_manager **out) {
 
 int lgs_manager_destroy(lgs_manager *m) {
   if (!m) return 0;
-  (void)hipSetDevice(m->device);
+  DeviceGuard guard(m->device);
   // every stream that read the maps must be done with them before the (stream-ordered) frees
   for (hipStream_t u : m->users) {
     if (hipEventRecord(m->ev_in, u) == hipSuccess) (void)hipStreamWaitEvent(m->ms, m->ev_in, 0);
@@ -458,7 +492,7 @@ int lgs_manager_insert(lgs_manager *m, const int32_t *coords, int64_t n, int64_t
   LGS_REQUIRE(n >= 0 && n < (1ll << 31) - 1024, "lgs_manager_insert: row count out of range");
   hipStream_t caller = (hipStream_t)stream;
   hipStream_t s = m->ms;
-  LGS_HIP(hipSetDevice(m->device));
+  DeviceGuard guard(m->device);
   m->last_stream = caller;
   if (begin_from_caller(m, caller)) return 1;   // `coords` was produced on the caller's stream
   CoordMap cm;
@@ -479,7 +513,7 @@ int lgs_manager_insert(lgs_manager *m, const int32_t *coords, int64_t n, int64_t
     size_t tb = 0;
     LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, skeys, vals, svals, (size_t)n, 0, 64, s));
     void *tmp = nullptr;
-    LGS_HIP(hipMallocAsync(&tmp, tb ? tb : 16, s));
+    LGS_HIP(pool_alloc(m, &tmp, tb ? tb : 16, s));
     LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, keys, skeys, vals, svals, (size_t)n, 0, 64, s));
     LGS_HIP(hipFreeAsync(tmp, s));
   }
@@ -516,7 +550,7 @@ int lgs_manager_stride2(lgs_manager *m, int in_key, void *stream, int *out_key, 
   LGS_REQUIRE(in_key >= 0 && in_key < (int)m->maps.size(), "lgs_manager_stride2: bad key");
   hipStream_t s = m->ms;
   (void)stream;
-  LGS_HIP(hipSetDevice(m->device));
+  DeviceGuard guard(m->device);
   if (m->maps[in_key].coarse_key >= 0) {
     *out_key = m->maps[in_key].coarse_key; *n_out = m->maps[*out_key].n;
     return 0;
@@ -589,7 +623,7 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
     if (k->in_key == in_key && k->out_key == out_key && k->ks == ks) { *out = k; return 0; }
   hipStream_t s = m->ms;
   (void)stream;
-  LGS_HIP(hipSetDevice(m->device));
+  DeviceGuard guard(m->device);
   lgs_kmap *km = new lgs_kmap();
   km->mgr = m; km->in_key = in_key; km->out_key = out_key; km->ks = ks;
   CoordMap &ci = m->maps[in_key];
@@ -616,7 +650,7 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
         size_t tb = 0;
         LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, 64, s));
         void *tmp = nullptr;
-        LGS_HIP(hipMallocAsync(&tmp, tb ? tb : 16, s));
+        LGS_HIP(pool_alloc(m, &tmp, tb ? tb : 16, s));
         LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, 64, s));
         LGS_HIP(hipFreeAsync(tmp, s));
       }
@@ -658,7 +692,7 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
         size_t tb = 0;
         LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, kk, kks, pp, pps, (size_t)n, 0, 3, s));
         void *tmp = nullptr;
-        LGS_HIP(hipMallocAsync(&tmp, tb ? tb : 16, s));
+        LGS_HIP(pool_alloc(m, &tmp, tb ? tb : 16, s));
         LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, kk, kks, pp, pps, (size_t)n, 0, 3, s));
         LGS_HIP(hipFreeAsync(tmp, s));
       }
@@ -689,11 +723,11 @@ int lgs_kmap_export(lgs_kmap *km, int32_t *ek, int32_t *ein, int32_t *eout, void
   lgs_manager *m = km->mgr;
   hipStream_t caller = (hipStream_t)stream;
   hipStream_t s = m->ms;
-  LGS_HIP(hipSetDevice(m->device));
+  DeviceGuard guard(m->device);
   if (begin_from_caller(m, caller)) return 1;   // the output buffers were allocated on the caller's stream
   const View &v = km->fwd;
   int32_t *cnt;
-  LGS_HIP(hipMallocAsync((void **)&cnt, sizeof(int32_t), s));
+  LGS_HIP(pool_alloc(m, (void **)&cnt, sizeof(int32_t), s));
   LGS_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), s));
   if (v.n_pad > 0) {
     if (ek) hipLaunchKernelGGL(k_view_export, nblk(v.n_pad), 256, 0, s, v, cnt, ek, ein, eout);

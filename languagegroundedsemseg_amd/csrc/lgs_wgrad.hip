@@ -18,6 +18,8 @@
 // from HBM in operand order (32 consecutive channels of 2 pairs per instruction) -- exact fp32.
 #include "lgs_common.h"
 
+#include <stdlib.h>
+
 namespace lgs {
 
 // ------------------------------------------------------------------------------------ fp32 (exact) path
@@ -427,6 +429,326 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
     if (4 * q + j < cout) dst[j] = r[j];
 }
 
+// ------------------------------------------------------------------------------------ position-stationary bf16 path
+// k_wgrad_ps (round 2).  The pair-list kernel above reads BOTH rows of every pair (in[i] and gout[o]) from L1/L2 --
+// the gradient row of a voxel ~11 times -- and leaves one fp32 partial slab per (range, offset) workgroup.  Here the
+// positions are stationary: ONE 512-thread workgroup per CU walks chunks of 128 consecutive map positions and keeps the
+// accumulators of ALL K offsets for a 32-channel slice of the gathered operand in the registers of its 8 waves
+// (wave w owns 3-4 offsets, balanced by expected pair density).  Per chunk
+//   * the STATIONARY operand's rows (gout of the 128 positions; `in` for a transposed conv) are staged ONCE in LDS and
+//     serve every offset of every wave: each wave tr-reads them as MFMA B operands once per 16 positions;
+//   * per offset only the gathered 64-byte row pieces move: 16 rows x 64 B = one 1 KB tile per (offset, 16 positions),
+//     read back transposed (ds_read_b64_tr_b16) as the A operand;
+//   * 16-position groups in which an offset has no neighbour at all (wavefront ballot) skip their LDS / MFMA work.
+// All data movement is LDS-DMA (buffer_load ... lds): kernel-map indices two chunks ahead, the wave's 16 rows of the
+// next stationary tile and the gathered tiles land in LDS without passing through registers (the 192 accumulator
+// registers leave no room for a register ring deep enough to cover the gather latency: a 3-deep ring ran at
+// 2.3 TB/s).  The schedule is static -- every wave issues the same number of DMA instructions per step, missing
+// neighbours are out-of-range offsets that return zeros without memory traffic -- so every wait is a compile-time
+// s_waitcnt vmcnt(N).  hipcc would fence each ds_read behind a pending LDS-DMA with vmcnt(0), so the LDS reads of the
+// loop are inline asm and the waits are explicit; the per-chunk barrier is a raw s_barrier.
+// Partial slabs: one per workgroup "lane" (<= 256 / slices), written once, folded by k_wgrad_reduce_ps in fixed order.
+constexpr int kPsChunk = 128;
+// offsets per wave for K = 27 (k = (dx+1) + 3(dy+1) + 9(dz+1)): centre / faces / edges / corners spread so that every
+// wave sees about the same number of pairs; waves 4..6 own four offsets, the others three
+__constant__ int8_t kPsOff27[8][4] = {{13, 0, 2, -1},  {4, 10, 6, -1},  {12, 14, 8, -1},  {16, 22, 18, -1},
+                                      {1, 3, 5, 20},   {7, 9, 11, 24},  {15, 17, 19, 26}, {21, 23, 25, -1}};
+
+struct PsArgs {
+  View v;
+  const bf16_t *G;      // gathered operand  [rows][cg_real]  (rows addressed through v.nbr)
+  const bf16_t *S;      // stationary operand [rows][cs_real] (rows addressed through v.out_row / identity)
+  int cg_real, cs_real, cg_pad, cs_pad, n_cg, n_cs;
+  int n_lanes, chunks_per_lane, n_chunks, xcd_map;
+  float *partial;       // [n_lanes][K][cg_pad][cs_pad]
+  unsigned g_bytes, s_bytes, nbr_bytes, orow_bytes;
+};
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define LGS_AS3(p) ((__attribute__((address_space(3))) void *)(p))
+// s_waitcnt immediates (gfx9 encoding): vmcnt = N with expcnt / lgkmcnt left alone
+#define LGS_VMCNT(n) __builtin_amdgcn_s_waitcnt((((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14)))
+
+__host__ __device__ constexpr int ps_wave_lds(int nw) { return 3 * nw * 1024 + 2 * (nw * 512 + 64); }
+
+// the loop of one wave that owns NW kernel offsets (koff) of the map; NCS = 32-channel blocks of the stationary slice
+template <int NW, int NCS>
+__device__ __forceinline__ void ps_wave(const PsArgs &a, char *smem, const int wave_off, const int (&koff)[NW], const int wlane,
+                                        const int cg0, const int cs0, const int wave, const int lane) {
+  constexpr int CH = kPsChunk;
+  constexpr int SGB = tile_stride(32 * NCS);          // row stride of the stationary tile (bytes)
+  constexpr int PPS = SGB / 16;                       // 16-byte pieces per (padded) stationary row
+  constexpr int NST = 16 * SGB / 1024;                // DMA instructions for this wave's 16 stationary rows
+  constexpr int NIX = NW + 1;                         // index DMA instructions per chunk (NW offsets + output rows)
+  constexpr int IDXB = NW * 512 + 64;                 // bytes per index buffer
+  const View &v = a.v;
+  const int K = v.K;
+  char *Stile = smem;                                 // [2][CH][SGB]
+  char *Aring = smem + wave_off;                      // [3][NW][1 KB] gathered tiles
+  char *idxb = Aring + 3 * NW * 1024;                 // [2][IDXB]: [NW][128] neighbour rows, [16] stationary rows
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;   // LDS byte address of smem
+
+  const int c_begin = wlane * a.chunks_per_lane;
+  const int c_end = min(c_begin + a.chunks_per_lane, a.n_chunks);
+
+  f32x16 acc[NW][NCS];
+#pragma unroll
+  for (int o = 0; o < NW; ++o)
+#pragma unroll
+    for (int b = 0; b < NCS; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[o][b][r] = 0.f;
+
+  constexpr unsigned kOOB = 0xfffff000u;
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.G), 0, (int)a.g_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.S), 0, (int)a.s_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(v.nbr), 0, (int)a.nbr_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(v.out_row ? v.out_row : v.nbr), 0,
+                                                                        (int)(v.out_row ? a.orow_bytes : 0u), 0x00020000);
+  const bool has_orow = v.out_row != nullptr;
+  const unsigned g_row_b = (unsigned)a.cg_real * 2u, s_row_b = (unsigned)a.cs_real * 2u;
+  // gather: lane -> (row lane/4 of the 16-position group, 16-byte piece lane%4 of the 64-byte channel slice)
+  const int g_row = lane >> 2;
+  const unsigned g_ch = (cg0 + (lane & 3) * 8 + 8 <= a.cg_real) ? (unsigned)(cg0 + (lane & 3) * 8) * 2u : kOOB;
+  // tr read: 16-lane group g = lane>>4: cb = g&1 (16-channel half), h = g>>1 (positions 8h..8h+7); lane i = lane&15
+  // supplies the 8-byte address (row 8h + i/4 (+4 for the second read), channel 32*blk + 16*cb + 4*(i%4))
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int tr_row = 8 * (g16 >> 1) + (i16 >> 2);
+  const int tr_col = 16 * (g16 & 1) + 4 * (i16 & 3);
+  const unsigned a_tr = lds0 + (unsigned)wave_off + (unsigned)(tr_row * 64 + tr_col * 2);          // + slot * NW KB + o KB
+  const unsigned s_tr = lds0 + (unsigned)(tr_row * SGB + tr_col * 2);                               // + buf * CH*SGB + 16 s SGB
+  const unsigned idx_rd = lds0 + (unsigned)wave_off + (unsigned)(3 * NW * 1024);
+
+  uint32_t actbits = 0;     // bit 4*slot + o: gathered tile (slot, o) has at least one neighbour
+  int islot = 0;            // ring slot the next issued gather group goes to (3 slots)
+
+  // ---- issue side
+  auto issue_index = [&](int c2) __attribute__((always_inline)) {   // kernel-map rows + output rows of chunk c2
+    char *dst = idxb + (c2 & 1) * IDXB;
+    const bool in = c2 < c_end;
+#pragma unroll
+    for (int o = 0; o < NW; ++o) {
+      const unsigned off = in ? (unsigned)(((int64_t)koff[o] * v.n_pad + (int64_t)c2 * CH + (lane & 31) * 4) * 4) : kOOB;
+      if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_n, LGS_AS3(dst + o * 512), 16, off, 0, 0, 0);
+    }
+    const unsigned off = in ? (unsigned)(((int64_t)c2 * CH + 16 * wave + (lane & 3) * 4) * 4) : kOOB;
+    if (lane < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_o, LGS_AS3(dst + NW * 512), 16, off, 0, 0, 0);
+  };
+  auto issue_stage = [&](int c1) __attribute__((always_inline)) {   // this wave's 16 rows of the stationary tile of chunk c1
+    char *dst = Stile + (c1 & 1) * (CH * SGB) + 16 * wave * SGB;
+    const unsigned srow_rd = idx_rd + (unsigned)((c1 & 1) * IDXB + NW * 512);
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      const int q = j * 64 + lane, row = q / PPS, cp = q % PPS;
+      int32_t sr;
+      if (has_orow) {
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sr) : "v"(srow_rd + (unsigned)row * 4u) : "memory");
+      } else {
+        const int64_t p = (int64_t)c1 * CH + 16 * wave + row;
+        sr = p < v.n_out ? (int32_t)p : -1;
+      }
+      const bool ok = c1 < c_end && sr >= 0 && cp < 4 * NCS && cs0 + cp * 8 + 8 <= a.cs_real;
+      const unsigned off = ok ? (unsigned)sr * s_row_b + (unsigned)(cs0 + cp * 8) * 2u : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, LGS_AS3(dst + j * 1024), 16, off, 0, 0, 0);
+    }
+  };
+  auto issue_gather = [&](int cc, int s) __attribute__((always_inline)) {   // the NW gathered tiles of 16-position group s of chunk cc
+    const unsigned rd = idx_rd + (unsigned)((cc & 1) * IDXB + (16 * s + g_row) * 4);
+    int32_t r[NW];
+#pragma unroll
+    for (int o = 0; o < NW; ++o) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r[o]) : "v"(rd), "n"(o * 512) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int o = 0; o < NW; ++o) asm volatile("" : "+v"(r[o]));
+    uint32_t m = 0;
+    char *dst = Aring + islot * (NW * 1024);
+#pragma unroll
+    for (int o = 0; o < NW; ++o) {
+      const bool ok = cc < c_end && r[o] >= 0;
+      if (__ballot(ok) != 0ull) m |= 1u << o;
+      const unsigned off = (ok && g_ch != kOOB) ? (unsigned)r[o] * g_row_b + g_ch : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, LGS_AS3(dst + o * 1024), 16, off, 0, 0, 0);
+    }
+    actbits = (actbits & ~(0xfu << (4 * islot))) | (m << (4 * islot));
+    islot = islot == 2 ? 0 : islot + 1;
+  };
+  // ---- consume side: group s of chunk cc sits in ring slot cslot
+  int cslot = 0;
+  auto consume = [&](int cc, int s) __attribute__((always_inline)) {
+    const uint32_t m = (actbits >> (4 * cslot)) & 0xfu;
+    if (m != 0) {                                       // wave-uniform
+      // stationary fragments (B) + the first gathered tile (A); the next tile's reads are issued in front of the MFMAs of
+      // the current one (at most two A fragments are live: the accumulators leave ~60 registers for everything else)
+      u32x2 fbr[NCS][2], far_[NW][2];
+      const unsigned sb = s_tr + (unsigned)((cc & 1) * (CH * SGB) + 16 * s * SGB);
+      const unsigned ab = a_tr + (unsigned)(cslot * (NW * 1024));
+#pragma unroll
+      for (int b = 0; b < NCS; ++b) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(fbr[b][0]) : "v"(sb), "n"(64 * b) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(fbr[b][1]) : "v"(sb), "n"(64 * b + 4 * SGB) : "memory");
+      }
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=&v"(far_[0][0]) : "v"(ab) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=&v"(far_[0][1]) : "v"(ab) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int b = 0; b < NCS; ++b) { asm volatile("" : "+v"(fbr[b][0])); asm volatile("" : "+v"(fbr[b][1])); }
+      asm volatile("" : "+v"(far_[0][0])); asm volatile("" : "+v"(far_[0][1]));
+      bf16x8 fb[NCS];
+#pragma unroll
+      for (int b = 0; b < NCS; ++b) {
+        u32x4 pk; pk.x = fbr[b][0].x; pk.y = fbr[b][0].y; pk.z = fbr[b][1].x; pk.w = fbr[b][1].y;
+        fb[b] = __builtin_bit_cast(bf16x8, pk);
+      }
+#pragma unroll
+      for (int o = 0; o < NW; ++o) {
+        if (o + 1 < NW) {
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(far_[o + 1 < NW ? o + 1 : 0][0]) : "v"(ab), "n"((o + 1) * 1024) : "memory");
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(far_[o + 1 < NW ? o + 1 : 0][1]) : "v"(ab), "n"((o + 1) * 1024 + 256) : "memory");
+        }
+        if ((m >> o) & 1u) {                            // wave-uniform
+          u32x4 pk; pk.x = far_[o][0].x; pk.y = far_[o][0].y; pk.z = far_[o][1].x; pk.w = far_[o][1].y;
+          const bf16x8 fa = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+          for (int b = 0; b < NCS; ++b) acc[o][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[b], acc[o][b], 0, 0, 0);
+        }
+        if (o + 1 < NW) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          asm volatile("" : "+v"(far_[o + 1 < NW ? o + 1 : 0][0])); asm volatile("" : "+v"(far_[o + 1 < NW ? o + 1 : 0][1]));
+        }
+      }
+    }
+    cslot = cslot == 2 ? 0 : cslot + 1;
+  };
+  auto barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+
+  // ---- prologue: indices of the first two chunks, then the first stationary tile and two gather groups
+  issue_index(c_begin);
+  issue_index(c_begin + 1);
+  LGS_VMCNT(0);
+  issue_stage(c_begin);
+  issue_gather(c_begin, 0);
+  issue_gather(c_begin, 1);
+  LGS_VMCNT(2 * NW);           // the stationary rows have landed (the two gather groups may still be in flight)
+  barrier();
+
+  for (int cc = c_begin; cc < c_end; ++cc) {
+    // program order of the DMA stream:  ... G(cc,0) G(cc,1) | ST(cc+1) G(cc,2) .. G(cc,7) IX(cc+2) G(cc+1,0) G(cc+1,1) | ...
+    issue_stage(cc + 1);
+    issue_gather(cc, 2);
+    LGS_VMCNT(2 * NW + NST);   // group 0 landed; behind it: G1, ST, G2
+    consume(cc, 0);
+    issue_gather(cc, 3);
+    LGS_VMCNT(2 * NW);         // group 1 (and the stationary rows issued before G2) landed; behind it: G2, G3
+    consume(cc, 1);
+#pragma unroll
+    for (int s = 2; s < 6; ++s) {
+      issue_gather(cc, s + 2);
+      LGS_VMCNT(2 * NW);
+      consume(cc, s);
+    }
+    issue_index(cc + 2);       // buffer cc % 2: its last reader was issue_gather(cc, 7)
+    issue_gather(cc + 1, 0);
+    LGS_VMCNT(2 * NW + NIX);   // group 6 landed; behind it: G7, IX, G(cc+1,0)
+    consume(cc, 6);
+    issue_gather(cc + 1, 1);
+    LGS_VMCNT(2 * NW + NIX);   // group 7 landed; behind it: IX, G(cc+1,0), G(cc+1,1)
+    consume(cc, 7);
+    barrier();                 // stationary tile of chunk cc+1 complete (landed before group 1's wait); this one is free
+  }
+  LGS_VMCNT(0);
+
+  // ---- partial[lane][k][cg][cs]: D[i = cg channel][j = cs channel], lane holds column j = lane&31, rows (r&3)+8(r>>2)+4h
+  const int vx = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int o = 0; o < NW; ++o) {
+    const int k = koff[o];
+    float *dst = a.partial + (((int64_t)wlane * K + k) * a.cg_pad) * (int64_t)a.cs_pad;
+#pragma unroll
+    for (int b = 0; b < NCS; ++b) {
+      const int cj = cs0 + 32 * b + vx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = cg0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (ci < a.cg_pad && cj < a.cs_pad) dst[(int64_t)ci * a.cs_pad + cj] = acc[o][b][r];
+      }
+    }
+  }
+}
+
+// KIND 27: 3^3 map, waves own 3/3/3/3/4/4/4/3 offsets;  KIND 8: 2^3 map, one offset per wave
+template <int KIND, int NCS>
+__global__ __launch_bounds__(512, 2) void k_wgrad_ps(PsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned bx = blockIdx.x, xcd = bx & 7u, tq = bx >> 3;
+  const int n_sl = a.n_cg * a.n_cs;
+  // xcd_map: the slices of one lane share an XCD (= its L2); otherwise (more slices than an XCD has CUs) plain order
+  const int slice = (int)((a.xcd_map ? tq : bx) % (unsigned)n_sl);
+  const int wlane = a.xcd_map ? (int)(tq / (unsigned)n_sl) * 8 + (int)xcd : (int)(bx / (unsigned)n_sl);
+  if (wlane >= a.n_lanes) return;
+  const int cg0 = (slice % a.n_cg) * 32, cs0 = (slice / a.n_cg) * 32 * NCS;
+  constexpr int SGB = tile_stride(32 * NCS);
+  constexpr int S_BYTES = 2 * kPsChunk * SGB;
+  if constexpr (KIND == 27) {
+    // waves 0-3 and 7 own three offsets, waves 4-6 four: their LDS regions are sized accordingly
+    const int n4 = wave <= 4 ? 0 : (wave <= 7 ? wave - 4 : 3);          // four-offset waves in front of this one
+    const int wave_off = S_BYTES + (wave - n4) * ps_wave_lds(3) + n4 * ps_wave_lds(4);
+    if (wave >= 4 && wave <= 6) {
+      const int koff[4] = {kPsOff27[wave][0], kPsOff27[wave][1], kPsOff27[wave][2], kPsOff27[wave][3]};
+      ps_wave<4, NCS>(a, smem, wave_off, koff, wlane, cg0, cs0, wave, lane);
+    } else {
+      const int koff[3] = {kPsOff27[wave][0], kPsOff27[wave][1], kPsOff27[wave][2]};
+      ps_wave<3, NCS>(a, smem, wave_off, koff, wlane, cg0, cs0, wave, lane);
+    }
+  } else {
+    const int koff[1] = {wave};
+    ps_wave<1, NCS>(a, smem, S_BYTES + wave * ps_wave_lds(1), koff, wlane, cg0, cs0, wave, lane);
+  }
+}
+
+// gw[k][ci][co] = sum over the lane slabs, fixed order.  Slabs hold D_k[cg][cs]; transpose = 1 when the stationary
+// operand was the op's INPUT (transposed conv: D_k = gw[k]^T).  One thread = 4 consecutive cs channels.
+__global__ __launch_bounds__(256) void k_wgrad_reduce_ps(const float *__restrict__ partial, int S, int K, int cg_pad, int cs_pad,
+                                                         int cg, int cs, int transpose, float *__restrict__ gw) {
+  const int cq = (cs + 3) / 4;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)K * cg * cq;
+  if (idx >= total) return;
+  const int q = (int)(idx % cq);
+  const int ig = (int)((idx / cq) % cg);
+  const int k = (int)(idx / ((int64_t)cq * cg));
+  const int64_t slab = (int64_t)K * cg_pad * cs_pad;
+  const float *src = partial + ((int64_t)k * cg_pad + ig) * cs_pad + 4 * q;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  int x = 0;
+  for (; x + 4 <= S; x += 4) {
+    const float4 v0 = *reinterpret_cast<const float4 *>(src + (int64_t)(x + 0) * slab);
+    const float4 v1 = *reinterpret_cast<const float4 *>(src + (int64_t)(x + 1) * slab);
+    const float4 v2 = *reinterpret_cast<const float4 *>(src + (int64_t)(x + 2) * slab);
+    const float4 v3 = *reinterpret_cast<const float4 *>(src + (int64_t)(x + 3) * slab);
+    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+    a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+    a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+  }
+  for (; x < S; ++x) {
+    const float4 v0 = *reinterpret_cast<const float4 *>(src + (int64_t)x * slab);
+    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+  }
+  const float r[4] = {(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                      (a0.w + a1.w) + (a2.w + a3.w)};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int is = 4 * q + j;
+    if (is >= cs) continue;
+    // plain: gw[k][ci = ig][co = is];  transposed: gw[k][ci = is][co = ig]
+    if (!transpose) gw[((int64_t)k * cg + ig) * cs + is] = r[j];
+    else gw[((int64_t)k * cs + is) * cg + ig] = r[j];
+  }
+}
+
 // ------------------------------------------------------------------------------------ host side
 struct WgradPlan {
   int S;          // partial slots
@@ -458,7 +780,8 @@ inline WgradPlan wgrad_plan(const View &v, int cin, int cout, int dtype) {
     // large maps: one offset per wave (4 offsets share a range's rows in L1/L2); small maps and the grouped views
     // (whose positions are sorted by offset, so a range holds a single offset): one offset per workgroup, the four
     // waves split the range
-    p.kpw = (v.n_pad >= 65536 && v.KS > 1) ? (v.K >= 4 ? 4 : (v.K >= 2 ? 2 : 1)) : 1;
+    // (kpw is 4 or 1 only: the accumulator fold of sub-range waves below shares ONE LDS tile per workgroup)
+    p.kpw = (v.n_pad >= 65536 && v.KS > 1 && v.K >= 4) ? 4 : 1;
     // smaller maps: ranges of 1024 positions, dealt round-robin to S "lanes" of co-resident workgroups (see the
     // kernel): S is what fits the chip's workgroup slots (LDS bound, <= 4 per CU), a multiple of 8 (XCD pinning), and
     // every lane costs one partial slab of K x Cin x Cout floats
@@ -505,10 +828,55 @@ inline WgradPlan wgrad_plan(const View &v, int cin, int cout, int dtype) {
   return p;
 }
 
+// ---- plan of the position-stationary kernel
+struct PsPlan {
+  bool ok = false;
+  int noff = 0, ncs = 0;
+  int cg_pad = 0, cs_pad = 0, n_cg = 0, n_cs = 0, n_lanes = 0, cpl = 0, n_chunks = 0, xcd_map = 1;
+  int64_t partial_bytes = 0;
+};
+inline PsPlan ps_plan(const View &v, int cg, int cs) {
+  PsPlan p;
+  if (!(v.K == 27 || v.K == 8) || v.KS != v.K || v.nbr == nullptr || v.n_pad < kPsChunk || v.n_pad % kPsChunk != 0) return p;
+  if (cg % 8 != 0 || cs % 8 != 0) return p;
+  p.cg_pad = pad32(cg); p.cs_pad = pad32(cs);
+  const int nbs = p.cs_pad / 32;
+  p.noff = v.K == 27 ? 4 : 1;
+  if (v.K == 27) p.ncs = nbs == 1 ? 1 : (nbs % 3 == 0 ? 3 : (nbs % 2 == 0 ? 2 : 3));     // <= 3: 4 offsets x 3 blocks = 192 accumulators
+  else p.ncs = nbs <= 4 ? nbs : (nbs % 4 == 0 ? 4 : (nbs % 3 == 0 ? 3 : 4));
+  p.n_cg = p.cg_pad / 32;
+  p.n_cs = (nbs + p.ncs - 1) / p.ncs;
+  p.n_chunks = (int)(v.n_pad / kPsChunk);
+  // One (K = 27: LDS / register bound) or two workgroups per CU.  Workgroup b runs on XCD b % 8 and the slices of a lane
+  // are placed on one XCD (they share its rows in that L2), so the lanes of an XCD must fit ITS 32 CUs: with 3 slices
+  // 85 lanes would put 33 workgroups on five of the XCDs and the 33rd runs alone in a second round (measured 2x).
+  const int lds_wg = 2 * kPsChunk * tile_stride(32 * p.ncs) + (v.K == 27 ? 5 * ps_wave_lds(3) + 3 * ps_wave_lds(4) : 8 * ps_wave_lds(1));
+  const int wg_per_cu = v.K == 27 ? 1 : (2 * lds_wg <= 160 * 1024 ? 2 : 1);
+  const int per_xcd = 32 * wg_per_cu, n_sl = p.n_cg * p.n_cs;
+  p.xcd_map = n_sl <= per_xcd ? 1 : 0;
+  int lanes = p.xcd_map ? 8 * (per_xcd / n_sl) : (8 * per_xcd) / n_sl;
+  if (lanes < 1) lanes = 1;
+  if (lanes > p.n_chunks) lanes = p.n_chunks;
+  p.cpl = (p.n_chunks + lanes - 1) / lanes;
+  p.n_lanes = (p.n_chunks + p.cpl - 1) / p.cpl;         // every lane owns at least one chunk
+  p.partial_bytes = (int64_t)p.n_lanes * v.K * p.cg_pad * p.cs_pad * 4;
+  p.ok = p.partial_bytes <= (2ll << 30);
+  return p;
+}
+inline bool ps_enabled() {
+  static const bool on = getenv("LGS_WGRAD_OLD") == nullptr;   // debugging knob: force the pair-list kernel
+  return on;
+}
+
 int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype) {
   WgradPlan a = wgrad_plan(km->fwd, cin, cout, dtype), b = wgrad_plan(km->bwd, cin, cout, dtype);
   int64_t per = (int64_t)km->K * pad32(cin) * pad32(cout) * 4;
   int64_t bytes = align256((int64_t)(a.S > b.S ? a.S : b.S) * per) + 256;
+  if (dtype == LGS_BF16) {   // position-stationary kernel: forward direction (gathered = in) and transposed (gathered = gout)
+    PsPlan f = ps_plan(km->fwd, cin, cout), t = ps_plan(km->fwd, cout, cin);
+    const int64_t pb = (f.ok ? f.partial_bytes : 0) > (t.ok ? t.partial_bytes : 0) ? (f.ok ? f.partial_bytes : 0) : (t.ok ? t.partial_bytes : 0);
+    if (align256(pb) + 256 > bytes) bytes = align256(pb) + 256;
+  }
   if (dtype == LGS_BF16 && cin % 8 != 0) {
     int64_t nmax = km->fwd.n_in > km->bwd.n_in ? km->fwd.n_in : km->bwd.n_in;
     bytes += align256(nmax * (int64_t)((cin + 7) / 8 * 8) * 2);
@@ -536,6 +904,61 @@ int launch_wgrad_bf16(const View &v, const WgradPlan &p, const bf16_t *in, int c
   const unsigned nblocks = (unsigned)(((n_lanes + 7) / 8) * 8 * KG * n_tasks);
   hipLaunchKernelGGL((k_wgrad_bf16<NCI, NCO, D, OCC>), dim3(nblocks), 256, 4 * WAVE_BYTES, s, v, in, cin, go, cout, p.cin_pad,
                      p.cout_pad, p.span, p.kpw, p.n_ci_tasks, n_tasks, n_ranges, n_lanes, partial, (unsigned)in_b, (unsigned)go_b);
+  return 0;
+}
+
+template <int KIND, int NCS>
+int launch_wgrad_ps(const PsArgs &a, const PsPlan &p, hipStream_t s) {
+  constexpr int SGB = tile_stride(32 * NCS);
+  constexpr int LDS = 2 * kPsChunk * SGB + (KIND == 27 ? 5 * ps_wave_lds(3) + 3 * ps_wave_lds(4) : 8 * ps_wave_lds(1));
+  static_assert(LDS <= 160 * 1024, "k_wgrad_ps: LDS budget of one CU");
+  static bool attr_set = false;
+  if (!attr_set) {
+    LGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_ps<KIND, NCS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  const unsigned nblocks = (unsigned)((p.xcd_map ? ((p.n_lanes + 7) / 8) * 8 : p.n_lanes) * p.n_cg * p.n_cs);
+  hipLaunchKernelGGL((k_wgrad_ps<KIND, NCS>), dim3(nblocks), 512, LDS, s, a);
+  return 0;
+}
+
+// gw[K][cin][cout] through the position-stationary kernel.  v = the map's forward view (3^3, or the coarse-stationary
+// 2^3 view); transposed = 0: gathered operand = in (rows of v's input side), stationary = gout;  transposed = 1 (the
+// transposed conv that reuses the strided conv's map): gathered = gout (fine rows), stationary = in (coarse rows).
+int conv_wgrad_ps(const View &v, int transposed, const bf16_t *in, int cin, const bf16_t *go, int cout, float *gw, void *workspace,
+                  hipStream_t s, bool *done) {
+  *done = false;
+  if (!ps_enabled()) return 0;
+  const int cg = transposed ? cout : cin, cs = transposed ? cin : cout;
+  const PsPlan p = ps_plan(v, cg, cs);
+  if (!p.ok) return 0;
+  const int64_t g_rows = v.n_in, s_rows = v.n_out;
+  const uint64_t g_b = (uint64_t)g_rows * cg * 2, s_b = (uint64_t)s_rows * cs * 2, n_b = (uint64_t)v.KS * v.n_pad * 4, o_b = (uint64_t)v.n_pad * 4;
+  if (!(g_b < 0xfffff000ull && s_b < 0xfffff000ull && n_b < 0xfffff000ull)) return 0;   // beyond the 32-bit descriptor path
+  PsArgs a;
+  a.v = v; a.v.mirror = 0;
+  a.G = transposed ? go : in; a.S = transposed ? in : go;
+  a.cg_real = cg; a.cs_real = cs; a.cg_pad = p.cg_pad; a.cs_pad = p.cs_pad; a.n_cg = p.n_cg; a.n_cs = p.n_cs;
+  a.n_lanes = p.n_lanes; a.chunks_per_lane = p.cpl; a.n_chunks = p.n_chunks; a.xcd_map = p.xcd_map;
+  a.partial = reinterpret_cast<float *>(workspace);
+  a.g_bytes = (unsigned)g_b; a.s_bytes = (unsigned)s_b; a.nbr_bytes = (unsigned)n_b; a.orow_bytes = (unsigned)o_b;
+  int rc = 0;
+  if (p.noff == 4) {
+    if (p.ncs == 1) rc = launch_wgrad_ps<27, 1>(a, p, s);
+    else if (p.ncs == 2) rc = launch_wgrad_ps<27, 2>(a, p, s);
+    else rc = launch_wgrad_ps<27, 3>(a, p, s);
+  } else {
+    if (p.ncs == 1) rc = launch_wgrad_ps<8, 1>(a, p, s);
+    else if (p.ncs == 2) rc = launch_wgrad_ps<8, 2>(a, p, s);
+    else if (p.ncs == 3) rc = launch_wgrad_ps<8, 3>(a, p, s);
+    else rc = launch_wgrad_ps<8, 4>(a, p, s);
+  }
+  if (rc) return rc;
+  const int64_t total = (int64_t)v.K * cg * ((cs + 3) / 4);
+  hipLaunchKernelGGL(k_wgrad_reduce_ps, (unsigned)((total + 255) / 256), 256, 0, s, a.partial, p.n_lanes, v.K, p.cg_pad, p.cs_pad, cg, cs,
+                     transposed, gw);
+  LGS_HIP(hipGetLastError());
+  *done = true;
   return 0;
 }
 
@@ -621,6 +1044,12 @@ int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const 
   }
   if (dtype == LGS_F32) return conv_wgrad_f32path<float>(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
   if (dtype == LGS_BF16) {
+    if (km->fwd.n_pad > 0 && (km->ks == 3 || km->ks == 2)) {
+      bool done = false;
+      int rc = conv_wgrad_ps(km->fwd, transposed, reinterpret_cast<const bf16_t *>(in), cin, reinterpret_cast<const bf16_t *>(grad_out),
+                             cout, grad_weight, workspace, s, &done);
+      if (rc || done) return rc;
+    }
     if (cout % 8 == 0) return conv_wgrad_bf16(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
     return conv_wgrad_f32path<bf16_t>(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
   }

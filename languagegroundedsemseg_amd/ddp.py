@@ -16,15 +16,20 @@ import torch.distributed as dist
 
 
 class BucketedDDP:
-    def __init__(self, module, bucket_mb=32.0, process_group=None):
+    """force_collectives=True issues the all-reduces even with a world of one rank (used by the single-GPU RCCL test:
+    the collective path, its stream ordering and the bucket views are then the ones an 8-GPU run executes)."""
+
+    def __init__(self, module, bucket_mb=32.0, process_group=None, force_collectives=False):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.reduce = self.world > 1 or (force_collectives and dist.is_initialized())
+        self._defer = False
         params = [p for p in module.parameters() if p.requires_grad]
         # gradients become ready roughly in reverse registration order
         params = list(reversed(params))
         cap = int(bucket_mb * 1024 * 1024 / 4)
-        self.buckets = []  # dict(flat, params, pending, handle)
+        self.buckets = []  # dict(flat, params, pending, launched, views)
         cur, cur_n = [], 0
         for p in params:
             if cur and cur_n + p.numel() > cap:
@@ -35,7 +40,7 @@ class BucketedDDP:
         if cur:
             self._make_bucket(cur)
         self._handles = []
-        if self.world > 1:
+        if self.reduce:
             for p in params:
                 dist.broadcast(p.data, src=0, group=self.group)
             for b in module.buffers():
@@ -46,14 +51,14 @@ class BucketedDDP:
         n = sum(p.numel() for p in params)
         flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
         off = 0
-        bucket = {"flat": flat, "params": params, "pending": len(params), "n": len(params), "views": []}
+        bucket = {"flat": flat, "params": params, "pending": len(params), "n": len(params), "views": [], "launched": False}
         for p in params:
             # the engine's backward kernels write gradients straight into this slot (me.modules.grad_slot_view);
             # any other producer falls back to autograd's own accumulation into the same memory
             p._lgs_grad_slot = (flat, off, tuple(p.shape))
             bucket["views"].append((p, off))
             off += p.numel()
-            if self.world > 1:
+            if self.reduce:
                 p.register_post_accumulate_grad_hook(self._hook(bucket))
         self.buckets.append(bucket)
 
@@ -71,52 +76,75 @@ class BucketedDDP:
 
     def _hook(self, bucket):
         def fn(param):
+            if self._defer:                      # no_sync(): gradients accumulate locally, nothing is reduced
+                return
             bucket["pending"] -= 1
             if bucket["pending"] == 0:
                 self._launch(bucket)
+            elif bucket["pending"] < 0:
+                raise RuntimeError("BucketedDDP: a gradient arrived after its bucket was reduced -- call zero_grad() before "
+                                   "every backward, or wrap all but the last micro-batch of an accumulation in no_sync()")
         return fn
 
     def _collect(self, bucket):
-        """gradients produced outside the engine (plain autograd) are copied into their slot, so that the flat bucket
-        always holds every gradient of its parameters"""
-        # after the first step only the parameters seen to stray are re-checked (keeps the host off the critical path)
-        cand = bucket["views"] if bucket.get("stray") is None else bucket["stray"]
-        stray = []
-        for p, off in cand:
+        """Every parameter's gradient must live in its slot of the flat bucket before the bucket is reduced / handed to
+        the optimiser.  Gradients the engine wrote there directly (conv weights on the side stream, BN affine) already
+        do; anything autograd produced elsewhere (torch modules, the engine's non-slot fallbacks, a cloned view) is
+        copied in and `.grad` re-pointed at the slot.  The check is one pointer compare per parameter on the host,
+        every step: a cached list of "stray" parameters went stale whenever a producer changed its mind after step 1."""
+        base = bucket["flat"].data_ptr()
+        for p, off in bucket["views"]:
             g = p.grad
-            if g is not None and g.data_ptr() != bucket["flat"].data_ptr() + off * 4:
+            if g is not None and g.data_ptr() != base + off * 4:
                 bucket["flat"][off:off + p.numel()].copy_(g.reshape(-1))
                 p.grad = bucket["flat"][off:off + p.numel()].view_as(p)
-                stray.append((p, off))
-        if bucket.get("stray") is None:
-            # parameters without an engine slot writer: anything that is not a conv kernel / BN affine of the engine
-            bucket["stray"] = [(p, off) for p, off in bucket["views"] if not getattr(p, "_lgs_engine_written", False)]
 
     def _launch(self, bucket):
         self._join_side()
         self._collect(bucket)
-        bucket["flat"].div_(self.world)
+        bucket["launched"] = True
+        if self.world > 1:
+            bucket["flat"].div_(self.world)
         self._handles.append(dist.all_reduce(bucket["flat"], group=self.group, async_op=True))
 
     def zero_grad(self):
         for b in self.buckets:
             b["flat"].zero_()
             b["pending"] = b["n"]
+            b["launched"] = False
             for p, _ in b["views"]:
                 p.grad = None
+
+    class _NoSync:
+        def __init__(self, ddp):
+            self.ddp = ddp
+
+        def __enter__(self):
+            self.prev, self.ddp._defer = self.ddp._defer, True
+
+        def __exit__(self, *exc):
+            self.ddp._defer = self.prev
+
+    def no_sync(self):
+        """Gradient accumulation (the reference's insseg trainer supports iter_size > 1): backward passes inside the
+        context only accumulate into the flat buckets; the first backward outside it reduces them."""
+        return BucketedDDP._NoSync(self)
 
     def finalize(self):
         """call after backward(): waits for the side-stream weight gradients and the in-flight bucket all-reduces
         (and flushes buckets whose parameters received no gradient this step -- the reference runs
-        find_unused_parameters=True)."""
+        find_unused_parameters=True).  Buckets that were not launched from a hook are flushed in fixed bucket order, the
+        same on every rank.  Inside no_sync() nothing is reduced."""
         self._join_side()
-        if self.world > 1:
+        if self.reduce and not self._defer:
             for b in self.buckets:
-                if b["pending"] > 0:
+                if not b["launched"]:
                     self._launch(b)
-                    b["pending"] = 0
             for h in self._handles:
                 h.wait()
+            for b in self.buckets:      # ready for the next backward even if the caller clears grads some other way
+                b["pending"] = b["n"]
+                b["launched"] = False
         else:
             for b in self.buckets:
                 self._collect(b)

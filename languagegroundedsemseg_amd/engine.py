@@ -23,6 +23,7 @@ EXPORTS = [
     "lgs_bn_workspace_bytes", "lgs_bn_forward", "lgs_bn_backward",
     "lgs_bn_stats", "lgs_bn_sync_combine", "lgs_bn_apply", "lgs_bn_backward_reduce", "lgs_bn_backward_apply",
     "lgs_clip_similarity", "lgs_clip_workspace_bytes",
+    "lgs_clip_loss_workspace_bytes", "lgs_clip_loss_forward", "lgs_clip_loss_backward",
     "lgs_ce_forward_backward",
     "lgs_voxelize", "lgs_label_vote", "lgs_cluster_workspace_bytes", "lgs_cluster", "lgs_sgd_step",
 ]
@@ -76,6 +77,8 @@ def lib():
         "lgs_bn_backward_apply": [vp, vp, vp, i64, ci, vp, vp, vp, vp, cf, vp, ci, vp, vp, ci, vp],
         "lgs_clip_similarity": [vp, i64, ci, vp, ci, vp, vp, ci, vp, vp],
         "lgs_ce_forward_backward": [vp, i64, ci, vp, i64, vp, vp, vp, ci, vp],
+        "lgs_clip_loss_forward": [vp, i64, ci, vp, ci, vp, vp, ci, i64, vp, vp, vp, vp, vp, vp, ci, vp, vp],
+        "lgs_clip_loss_backward": [vp, i64, ci, vp, ci, vp, vp, ci, i64, vp, vp, vp, vp, vp, vp, ci, vp],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -89,6 +92,8 @@ def lib():
     L.lgs_bn_workspace_bytes.argtypes = [i64, ci]
     L.lgs_clip_workspace_bytes.restype = i64
     L.lgs_clip_workspace_bytes.argtypes = [ci, ci, ci]
+    L.lgs_clip_loss_workspace_bytes.restype = i64
+    L.lgs_clip_loss_workspace_bytes.argtypes = [ci, ci, ci]
     if L.lgs_abi_version() != 1:
         raise RuntimeError("liblgs_engine.so ABI version mismatch")
     _lib = L

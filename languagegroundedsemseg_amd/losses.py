@@ -33,9 +33,10 @@ class _FusedCE(torch.autograd.Function):
 
 
 def fused_cross_entropy(logits, labels, ignore_index=-1):
-    """mean softmax cross-entropy over the non-ignored rows; logits may be bf16 or fp32."""
+    """mean softmax cross-entropy over the non-ignored rows; logits may be bf16 or fp32, any class count the kernel's
+    half-wave holds (512 fp32 / 1024 bf16); wider heads go through torch's device op."""
     backend = get_backend()
-    if hasattr(backend, "cross_entropy"):
+    if hasattr(backend, "cross_entropy") and logits.shape[1] <= (1024 if logits.dtype == torch.bfloat16 else 512):
         return _FusedCE.apply(logits, labels, ignore_index)
     return torch.nn.functional.cross_entropy(logits.float(), labels, ignore_index=ignore_index)
 
@@ -70,6 +71,37 @@ class _ClipSimilarity(torch.autograd.Function):
 
 def clip_similarity(feats, anchors):
     return _ClipSimilarity.apply(feats, anchors, anchors.requires_grad)
+
+
+class _ClipLossFused(torch.autograd.Function):
+    """(d_pos, d_neg, pred[, sim]) of the text-anchor loss in ONE pass over the features (lgs_clip_loss_forward: MFMA
+    contraction with the gathers, the arg-max and 1/|f| in its epilogue -- the [N, A] similarity matrix is never written
+    unless asked for); backward = lgs_clip_loss_backward, a streaming kernel that uses the 4-sparse upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, feats, anchors, labels, neg, ignore_label, want_sim):
+        be = get_backend()
+        d_pos, d_neg, pred, saved, sim = be.clip_loss_forward(feats, anchors, labels, neg, ignore_label, want_sim)
+        ctx.ignore_label = ignore_label
+        ctx.save_for_backward(*saved, d_pos, d_neg)
+        ctx.mark_non_differentiable(pred)
+        if sim is None:
+            sim = d_pos.new_empty(0)
+        ctx.mark_non_differentiable(sim)
+        return d_pos, d_neg, pred, sim
+
+    @staticmethod
+    def backward(ctx, g_dpos, g_dneg, _gp, _gs):
+        *saved, d_pos, d_neg = ctx.saved_tensors
+        gf = get_backend().clip_loss_backward(tuple(saved), d_pos, d_neg, g_dpos, g_dneg, ctx.ignore_label)
+        return gf, None, None, None, None, None
+
+
+def feature_sim(output_feats, anchor_feats):
+    """lib/losses/utils.py:80-103, cosine branch: S[n, a] = <f^_n, t^_a> (attribute anchors: the plain ones, :83-84)."""
+    if anchor_feats.dim() == 3:
+        anchor_feats = anchor_feats[:, 0, :]
+    return clip_similarity(output_feats.detach(), anchor_feats.detach())
 
 
 class ContrastiveLanguageLoss(nn.Module):
@@ -111,31 +143,47 @@ class ContrastiveLanguageLoss(nn.Module):
         idx = torch.minimum(r + (r >= own).long(), (n_present - 1).clamp_min(0))   # a single-class batch has no negatives: own class
         return cls_of_rank[idx]
 
-    def forward(self, features, labels, anchor_feats, neg_indices=None, return_similarity=False):
+    def forward(self, features, labels, anchor_feats, neg_indices=None, return_similarity=False, return_pred=False):
+        """-> (loss, pos_loss, neg_loss[, sim][, pred]); pred = argmax_a <f^, t^_a>, what the reference's trainer gets from
+        feature_sim(...).argmax(1) (pl_RepresentationTrainer.py:237-238) -- here a by-product of the same pass."""
         if features.dim() != 2:
             raise ValueError("`features` needs to be [n_points, feat_dim]")
         if anchor_feats.dim() == 3:                               # anchors with attributes: use the plain ones (:122-123)
             anchor_feats = anchor_feats[:, 0, :]
         labels = labels.long()
-        sim = clip_similarity(features, anchor_feats)             # [N, num_labels] -- the MFMA contraction
-        valid = labels != self.ignore_label
-        lab = labels.clamp_min(0)
         if neg_indices is None:
             neg_indices = self.sample_negatives(labels)
-        d_pos = 1.0 - sim.gather(1, lab[:, None]).squeeze(1)
-        d_neg = 1.0 - sim.gather(1, neg_indices).mean(1)
-        zero = torch.zeros((), dtype=sim.dtype, device=sim.device)
-        d_pos = torch.where(valid, d_pos, zero)
-        d_neg = torch.where(valid, d_neg, zero)
+        be = get_backend()
+        fused = (hasattr(be, "clip_loss_forward") and not anchor_feats.requires_grad and features.is_cuda
+                 and anchor_feats.shape[0] % 4 == 0 and 4 <= anchor_feats.shape[0] <= be.CLIP_LOSS_MAX_ANCHORS
+                 and 1 <= neg_indices.shape[1] <= 7)
+        if fused:
+            d_pos, d_neg, pred, sim = _ClipLossFused.apply(features, anchor_feats, labels, neg_indices, self.ignore_label,
+                                                           bool(return_similarity))
+        else:
+            # learned anchor projections (gradient w.r.t. the anchors), > 224 anchors, or the CPU oracle backend of the
+            # tests: dense similarity matrix + index gathers
+            sim = clip_similarity(features, anchor_feats)         # [N, num_labels] -- the MFMA contraction
+            valid = labels != self.ignore_label
+            lab = labels.clamp_min(0)
+            d_pos = 1.0 - sim.gather(1, lab[:, None]).squeeze(1)
+            d_neg = 1.0 - sim.gather(1, neg_indices).mean(1)
+            zero = torch.zeros((), dtype=sim.dtype, device=sim.device)
+            d_pos = torch.where(valid, d_pos, zero)
+            d_neg = torch.where(valid, d_neg, zero)
+            pred = sim.detach().argmax(1) if return_pred else None
         pos_loss = torch.relu(d_pos - self.pos_thresh)
         neg_loss = torch.relu(self.neg_thresh - d_neg)
         if self.reduction == "mean":
             loss = pos_loss.mean() + neg_loss.mean() * self.neg_weight
         else:
             loss = pos_loss + neg_loss * self.neg_weight
+        out = (loss, pos_loss, neg_loss)
         if return_similarity:
-            return loss, pos_loss, neg_loss, sim
-        return loss, pos_loss, neg_loss
+            out = out + (sim,)
+        if return_pred:
+            out = out + (pred,)
+        return out
 
 
 def sample_categories_for_balancing(loss, targets, frequency_organized_cats, head_ratio, common_ratio, ignore_label=-1,

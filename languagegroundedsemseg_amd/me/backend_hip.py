@@ -320,6 +320,47 @@ class HipBackend:
                                                _stream()))
         return sim, inv[:n]
 
+    # ---- fused CLIP text-anchor loss: lgs_clip_loss_forward / lgs_clip_loss_backward
+    CLIP_LOSS_MAX_ANCHORS = 224
+
+    def clip_loss_forward(self, feats, anchors, labels, neg, ignore_label, want_sim=False):
+        """one pass over the features -> (d_pos [N], d_neg [N], pred [N] int64, saved-for-backward tuple, sim or None)"""
+        _require_dev(feats, "features")
+        L = engine.lib()
+        feats = feats.contiguous()
+        anchors = anchors.detach().contiguous().float()
+        labels = labels.contiguous().to(torch.int64)
+        neg = neg.contiguous().to(torch.int64)
+        n, c = feats.shape
+        na, k = anchors.shape[0], neg.shape[1]
+        dt = _dtype_code(feats)
+        dev = feats.device
+        with torch.cuda.device(dev):
+            d_pos = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+            d_neg = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+            inv = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+            pred = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+            tn = torch.empty((na, c), dtype=torch.float32, device=dev)
+            sim = torch.empty((n, na), dtype=torch.float32, device=dev) if want_sim else None
+            ws = _ws(L.lgs_clip_loss_workspace_bytes(c, na, dt), dev)
+            engine.check(L.lgs_clip_loss_forward(_ptr(feats), n, c, _ptr(anchors), na, _ptr(labels), _ptr(neg), int(k),
+                                                 int(ignore_label), _ptr(d_pos), _ptr(d_neg), _ptr(pred), _ptr(inv), _ptr(tn),
+                                                 _ptr(sim), dt, _ptr(ws), _stream()))
+        return d_pos[:n], d_neg[:n], pred[:n], (feats, tn, labels, neg, inv), sim
+
+    def clip_loss_backward(self, saved, d_pos, d_neg, g_dpos, g_dneg, ignore_label):
+        L = engine.lib()
+        feats, tn, labels, neg, inv = saved
+        n, c = feats.shape
+        with torch.cuda.device(feats.device):
+            gf = torch.empty_like(feats)
+            gp = g_dpos.contiguous().float() if g_dpos is not None else None
+            gn = g_dneg.contiguous().float() if g_dneg is not None else None
+            engine.check(L.lgs_clip_loss_backward(_ptr(feats), n, c, _ptr(tn), tn.shape[0], _ptr(labels), _ptr(neg), int(neg.shape[1]),
+                                                  int(ignore_label), _ptr(inv), _ptr(d_pos), _ptr(d_neg), _ptr(gp), _ptr(gn), _ptr(gf),
+                                                  _dtype_code(feats), _stream()))
+        return gf
+
     # ---- fused softmax cross-entropy: lgs_ce_forward_backward
     def cross_entropy(self, logits, labels, ignore_index, want_grad=True, grad_scale=None):
         """mean CE over the non-ignored rows.  want_grad=False: loss only; grad_scale (device scalar): gradient only,
@@ -331,7 +372,8 @@ class HipBackend:
         n, c = logits.shape
         dt = _dtype_code(logits)
         with torch.cuda.device(logits.device):
-            valid = (labels != ignore_index).sum().to(torch.float32).clamp_min(1.0)
+            # the same predicate the kernel uses: a label outside [0, C) is an ignored row, not a counted one
+            valid = ((labels != ignore_index) & (labels >= 0) & (labels < c)).sum().to(torch.float32).clamp_min(1.0)
             scale = valid.reciprocal()
             if grad_scale is not None:
                 scale = scale * grad_scale.to(torch.float32).reshape(())

@@ -38,7 +38,6 @@ def grad_slot_view(param):
     n = 1
     for d in shape:
         n *= d
-    param._lgs_engine_written = True   # BucketedDDP need not look for a stray gradient of this parameter again
     return flat[off:off + n].view(shape)
 
 
@@ -245,8 +244,11 @@ class MinkowskiBatchNorm(nn.Module):
 
 
 class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
-    """Cross-rank batch statistics (main.py:122-123).  Statistics of all ranks are exchanged with ONE
-    packed all-reduce per layer ([sum, sumsq, count]) instead of torch SyncBatchNorm's gather."""
+    """Cross-rank batch statistics (main.py:122-123) on the engine's split BN kernels (ddp._SyncBNFused): every rank
+    contributes one [mean | M2 | count] record to ONE all-gather per layer, the records are combined with Chan's
+    parallel formula in one kernel; backward exchanges [sum dy | sum dy xhat] with ONE all-reduce of 2C floats.
+    `force_sync` (class attribute, tests only) takes the collective path even in a world of one rank."""
+    force_sync = False
 
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, process_group=None):
         super().__init__(num_features, eps, momentum, affine, track_running_stats)
@@ -254,7 +256,8 @@ class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
 
     def forward(self, input, relu=False, residual=None):
         import torch.distributed as dist
-        if not (self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1):
+        if not (self.training and dist.is_available() and dist.is_initialized()
+                and (dist.get_world_size(self.process_group) > 1 or MinkowskiSyncBatchNorm.force_sync)):
             return super().forward(input, relu=relu, residual=residual)
         from ..ddp import sync_batch_norm
         res = residual.F if isinstance(residual, SparseTensor) else residual

@@ -9,6 +9,11 @@
 2. contrastive_loss.npz   inputs/outputs of the reference's own ContrastiveLanguageLoss.feat_dist +
                           hinge (lib/losses/ContrastiveLanguageLoss.py:73-95,185-192) on CPU, with the
                           sampled negative indices made explicit (the reference's sampling is thread-racy).
+2b. feature_sim.npz       the reference's feature_sim (lib/losses/utils.py:80-103, cosine branch) + argmax on the
+                          contrastive fixture's features / anchors (2-D anchors and the 3-D attribute layout).
+2c. balancing.npz         the reference's sample_categories_for_balancing (lib/losses/utils.py:13-77) on fixed
+                          labels: kept points per class (recovered with one-hot losses), the head/common/tail
+                          split of a random loss and loss_items.
 3. res16unet14a_forward.npz / res16unet34c_forward.npz
                           logits + features of the REFERENCE's forward code (res16unet.py:196-270,
                           resnet_block.py:41-57) run on the CPU oracle backend with name-keyed
@@ -79,6 +84,57 @@ def contrastive():
             out["%s_%s" % (tag, k)] = v.numpy()
     np.savez_compressed(os.path.join(HERE, "contrastive_loss.npz"), **out)
     print("contrastive fixture written")
+
+
+def _loss_utils():
+    if "torchmetrics" not in sys.modules:
+        sys.modules["torchmetrics"] = types.SimpleNamespace(Metric=object)
+    import lib.losses.utils as U
+    return U
+
+
+def feature_sim_fixture():
+    U = _loss_utils()
+    fx = np.load(os.path.join(HERE, "contrastive_loss.npz"))
+    cfg = types.SimpleNamespace(representation_distance_type="cos")
+    out = {}
+    for tag in ("c512", "c96"):
+        F, T = torch.from_numpy(fx[tag + "_F"]), torch.from_numpy(fx[tag + "_T"])
+        sim = U.feature_sim(F.clone(), T, cfg)
+        # 3-D anchors (category, attribute, C): the reference keeps attribute 0 (:83-84)
+        T3 = torch.stack([T, T.flip(0), T * 0.5], 1)
+        sim3 = U.feature_sim(F.clone(), T3, cfg)
+        assert torch.equal(sim, sim3)
+        out[tag + "_sim"] = sim.numpy().astype(np.float32)
+        out[tag + "_pred"] = sim.argmax(1).numpy()
+    np.savez_compressed(os.path.join(HERE, "feature_sim.npz"), **out)
+    print("feature_sim fixture:", {k: v.shape for k, v in out.items()})
+
+
+def balancing_fixture():
+    U = _loss_utils()
+    L, n = 20, 5000
+    g = torch.Generator().manual_seed(11)
+    targets = torch.randint(-1, L, (n,), generator=g)
+    targets[targets == 17] = 3                                   # one class absent from the batch
+    foc = torch.zeros(L, 3, dtype=torch.bool)
+    foc[:7, 0] = True; foc[7:14, 1] = True; foc[14:, 2] = True
+    loss = torch.rand(n, generator=g) + 0.1
+    ds = types.SimpleNamespace(NUM_LABELS=L, frequency_organized_cats=foc)
+    out = {"targets": targets.numpy(), "foc": foc.numpy(), "loss": loss.numpy()}
+    for tag, (hr, cr) in {"a": (0.3, 0.6), "b": (0.0, 0.45)}.items():
+        cfg = types.SimpleNamespace(ignore_label=-1, balanced_sample_head_ratio=hr, balanced_sample_common_ratio=cr)
+        keep = np.zeros(L, np.int64)
+        for c in range(L):                                       # one-hot loss: mean * n = points of class c that were kept
+            np.random.seed(100 + c)
+            m, _, _ = U.sample_categories_for_balancing((targets == c).float(), cfg, ds, targets)
+            keep[c] = int(round(float(m) * n))
+        np.random.seed(5)
+        m, (head, common, tail), items = U.sample_categories_for_balancing(loss.clone(), cfg, ds, targets)
+        out.update({tag + "_ratios": np.array([hr, cr], np.float64), tag + "_keep": keep, tag + "_head": head.numpy(),
+                    tag + "_common": common.numpy(), tag + "_tail": tail.numpy(), tag + "_items": items.numpy()})
+    np.savez_compressed(os.path.join(HERE, "balancing.npz"), **out)
+    print("balancing fixture: keep(a) =", out["a_keep"].tolist(), "keep(b) =", out["b_keep"].tolist())
 
 
 def forward_fixture(name, seed, n):
@@ -159,7 +215,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "insseg":
         insseg_fixture()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "losses":
+        feature_sim_fixture()
+        balancing_fixture()
+        sys.exit(0)
     manifest()
     contrastive()
+    feature_sim_fixture()
+    balancing_fixture()
     forward_fixture("Res16UNet14A", 3, 1500)
     forward_fixture("Res16UNet34C", 5, 1200)

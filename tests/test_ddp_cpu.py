@@ -134,3 +134,66 @@ def test_flat_sgd_equals_torch_sgd():
     for (n1, p1), (n2, p2) in zip(a.named_parameters(), b.named_parameters()):
         assert torch.allclose(p1, p2, atol=1e-6), n1
     assert torch.equal(a.unused.weight, b.unused.weight)   # untouched on both sides
+
+
+def _multi_step_job(rank, world):
+    """three optimiser steps (the second with 2-micro-batch accumulation under no_sync): every step's gradients must
+    reach the flat buckets -- gradients autograd produced outside a slot on step 1 must still be collected on steps 2+"""
+    from languagegroundedsemseg_amd.ddp import BucketedDDP, FlatSGD
+    torch.manual_seed(100)
+    net = Net()
+    ddp = BucketedDDP(net, bucket_mb=0.0005)
+    opt = FlatSGD(ddp, lr=0.05, momentum=0.9, dampening=0.1, weight_decay=1e-2)
+    torch.manual_seed(7)
+    full, target = torch.randn(3, 8, 8), torch.randn(3, 8, 4)
+    for step in range(3):
+        x, y = full[step, rank * 4:(rank + 1) * 4], target[step, rank * 4:(rank + 1) * 4]
+        ddp.zero_grad()
+        if step == 1:                                   # accumulate two half micro-batches, reduce on the second
+            with ddp.no_sync():
+                (((ddp(x[:2]) - y[:2]) ** 2).mean() * 0.5).backward()
+                ddp.finalize()
+            (((ddp(x[2:]) - y[2:]) ** 2).mean() * 0.5).backward()
+        else:
+            ((ddp(x) - y) ** 2).mean().backward()
+        ddp.finalize()
+        opt.step()
+    return torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+
+
+def test_multi_step_and_accumulation_match_torch_sgd_on_the_full_batch():
+    p0, p1 = run_distributed(_multi_step_job)
+    assert torch.equal(p0, p1)
+    torch.manual_seed(100)
+    net = Net()
+    to = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, dampening=0.1, weight_decay=1e-2)
+    torch.manual_seed(7)
+    full, target = torch.randn(3, 8, 8), torch.randn(3, 8, 4)
+    for step in range(3):
+        to.zero_grad(set_to_none=True)
+        ((net(full[step]) - target[step]) ** 2).mean().backward()
+        to.step()
+    ref = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    assert torch.allclose(p0, ref, atol=1e-6)
+
+
+def _double_backward_job(rank, world):
+    from languagegroundedsemseg_amd.ddp import BucketedDDP
+    torch.manual_seed(0)
+    net = Net()
+    ddp = BucketedDDP(net, bucket_mb=0.0005)
+    x = torch.randn(4, 8)
+    ddp.zero_grad()
+    ddp(x).sum().backward()
+    try:
+        ddp(x).sum().backward()
+    except RuntimeError as e:
+        ddp.finalize()
+        return "after its bucket was reduced" in str(e)
+    ddp.finalize()
+    return False
+
+
+def test_hook_after_reduce_raises():
+    """a second backward without zero_grad()/no_sync() would accumulate into a bucket whose all-reduce may be in flight"""
+    assert all(run_distributed(_double_backward_job))

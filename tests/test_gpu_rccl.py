@@ -1,0 +1,89 @@
+"""RCCL on the GPU box: the `nccl` backend (= RCCL on ROCm) initialised with a world of ONE rank,
+BucketedDDP and MinkowskiSyncBatchNorm forced down their collective paths (dist.all_reduce on the flat gradient
+buckets launched from the post-accumulate hooks, dist.all_gather_into_tensor / all_reduce of the SyncBN records).
+A one-rank all-reduce is the identity, so the forced-collective step must reproduce the non-distributed step: this
+executes the RCCL calls, their stream ordering against the engine's side stream, and the bucket views exactly as an
+8-GPU run issues them."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from test_ddp_cpu import _free_port
+
+pytestmark = pytest.mark.gpu
+
+
+def _step(m, ddp, opt, coords, feats, dev, steps=2):
+    """-> (gradients of the LAST step, parameters after it, gradients of the FIRST step)"""
+    import MinkowskiEngine as ME
+    out, first = None, None
+    for _ in range(steps):
+        ddp.zero_grad()
+        logits, _ = m(ME.SparseTensor(feats, coords))
+        logits.F.float().square().mean().backward()
+        ddp.finalize()
+        out = {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}
+        first = first or out
+        opt.step()
+    torch.cuda.synchronize()
+    return out, {k: p.detach().float().cpu().clone() for k, p in m.named_parameters()}, first
+
+
+def _worker(rank, port, ret):
+    import torch.distributed as dist
+    import MinkowskiEngine as ME
+    from helpers import Cfg, deterministic_init
+    from languagegroundedsemseg_amd.ddp import BucketedDDP, FlatSGD
+    from languagegroundedsemseg_amd.models import load_model
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        assert dist.get_backend() == "nccl"
+        coords_np, feats_np, _ = make_batch([0, 1], voxel=0.05, n_target=6000)
+        coords, feats = torch.from_numpy(coords_np).to(dev), torch.from_numpy(feats_np).to(dev).bfloat16()
+
+        def build(sync):
+            m = deterministic_init(load_model("Res16UNet14A")(3, 20, Cfg()), 42).to(dev).train()
+            return ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(m) if sync else m
+        # (1) gradient buckets through RCCL all_reduce vs no collective at all: bit-identical
+        a = build(False)
+        da = BucketedDDP(a, bucket_mb=1.0, force_collectives=True)
+        assert da.reduce and len(da.buckets) > 3
+        ga, pa, _ = _step(a, da, FlatSGD(da, lr=0.1, momentum=0.9, dampening=0.1, weight_decay=1e-4), coords, feats, dev)
+        b = build(False)
+        db = BucketedDDP(b, bucket_mb=1.0)
+        assert not db.reduce
+        gb, pb, _ = _step(b, db, FlatSGD(db, lr=0.1, momentum=0.9, dampening=0.1, weight_decay=1e-4), coords, feats, dev)
+        same = all(torch.equal(ga[k], gb[k]) for k in gb) and all(torch.equal(pa[k], pb[k]) for k in pb) and set(ga) == set(gb)
+        # (2) + SyncBN records through RCCL all_gather_into_tensor / all_reduce (Chan's combination of ONE record is
+        # the same statistics up to the last float bit: compared with a tolerance, not bitwise)
+        f32 = feats.float()
+        d = build(False)
+        dd = BucketedDDP(d, bucket_mb=1.0)
+        _, _, gd = _step(d, dd, FlatSGD(dd, lr=1e-3), coords, f32, dev)
+        ME.MinkowskiSyncBatchNorm.force_sync = True
+        c = build(True)
+        dc = BucketedDDP(c, bucket_mb=1.0, force_collectives=True)
+        _, _, gc_ = _step(c, dc, FlatSGD(dc, lr=1e-3), coords, f32, dev)
+        ME.MinkowskiSyncBatchNorm.force_sync = False
+        worst = max(float((gc_[k] - gd[k]).norm() / gd[k].norm().clamp_min(1e-12)) for k in gd)
+        rm = float((c.bn0.bn.running_mean - d.bn0.bn.running_mean).abs().max())
+        ret["out"] = (same, worst, rm, int(c.bn0.bn.num_batches_tracked))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collective_paths_with_one_rank_reproduce_the_local_step():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    same, worst, rm, nbt = ret["out"]
+    assert same, "RCCL all_reduce of the gradient buckets (world 1) must leave the step bit-identical"
+    print("SyncBN over RCCL (world 1) vs local BatchNorm: worst gradient rel-L2 %.3e, running_mean diff %.3e" % (worst, rm))
+    assert worst < 2e-2 and rm < 1e-5 and nbt == 2

@@ -1,10 +1,13 @@
 """Per-op timings on the GPU (HIP events on torch's current stream) for the hot layer shapes.
 usage: python tools/microbench.py [scenes]"""
+import os
 import sys
 import time
 
 import numpy as np
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import MinkowskiEngine as ME
 from languagegroundedsemseg_amd.synthetic import make_batch
@@ -99,6 +102,17 @@ def clip():
             byts = n * c * f.element_size() + n * 200 * 4
             print("clip similarity N=%d C=%d %-8s %.3f ms  %.1f TFLOP/s  %.2f TB/s (read F + write S)" % (
                 n, c, str(dtype).split(".")[1], ms, flop / ms / 1e9, byts / ms / 1e9))
+            lab = torch.randint(-1, 200, (n,), device=DEV)
+            neg = torch.randint(0, 200, (n, 3), device=DEV)
+            ms = timeit(lambda: be.clip_loss_forward(f, t, lab, neg, -1))
+            byts = n * c * f.element_size() + n * (3 * 4 + 8 + 4 * 8)
+            print("fused clip loss fwd (d_pos, d_neg, argmax, 1/|f|; no S) %.3f ms  %.1f TFLOP/s (%.1f %% of 2.5 PF)  %.2f TB/s "
+                  "(%.1f %% of 8 TB/s)" % (ms, flop / ms / 1e9, flop / ms / 1e9 / 25.0, byts / ms / 1e9, byts / ms / 1e9 / 80.0))
+            d_pos, d_neg, pred, saved, _ = be.clip_loss_forward(f, t, lab, neg, -1)
+            gp, gn = torch.randn(n, device=DEV), torch.randn(n, device=DEV)
+            ms = timeit(lambda: be.clip_loss_backward(saved, d_pos, d_neg, gp, gn, -1))
+            byts = 2 * n * c * f.element_size()
+            print("fused clip loss bwd (4-sparse upstream) %.3f ms  %.2f TB/s (read F + write gF)" % (ms, byts / ms / 1e9))
 
 
 def quantize():
@@ -198,7 +212,45 @@ def coarse():
                 lvl, n, M, cin, cout, tf, flop / tf / 1e9, tw, flop / tw / 1e9))
 
 
+def wgrad():
+    """every weight-gradient shape of a Res16UNet34C step on the maps of the 8-scene batch (bf16)"""
+    coords, feats, labels = make_batch(list(range(8)), n_target=150000, shift_seed=0)
+    c = torch.from_numpy(coords).to(DEV)
+    x = ME.SparseTensor(torch.zeros(coords.shape[0], 3, device=DEV), c)
+    m = x.coordinate_manager
+    keys = [x.coordinate_map_key]
+    for lvl in range(4):
+        keys.append(m.stride(keys[-1], 2))
+    # (level, kernel, cin, cout, transposed, count per step)
+    shapes = [(0, 3, 3, 32, 0, 1), (0, 3, 128, 96, 0, 1), (0, 3, 96, 96, 0, 3), (0, 2, 32, 32, 0, 1), (0, 2, 96, 96, 1, 1),
+              (1, 3, 32, 32, 0, 4), (1, 3, 128, 96, 0, 1), (1, 3, 96, 96, 0, 3), (1, 2, 32, 32, 0, 1), (1, 2, 128, 96, 1, 1),
+              (2, 3, 32, 64, 0, 1), (2, 3, 64, 64, 0, 5), (2, 3, 192, 128, 0, 1), (2, 3, 128, 128, 0, 3), (2, 2, 64, 64, 0, 1), (2, 2, 256, 128, 1, 1),
+              (3, 3, 64, 128, 0, 1), (3, 3, 128, 128, 0, 7), (3, 3, 384, 256, 0, 1), (3, 3, 256, 256, 0, 3), (3, 2, 128, 128, 0, 1), (3, 2, 256, 256, 1, 1),
+              (4, 3, 128, 256, 0, 1), (4, 3, 256, 256, 0, 11)]
+    tot = 0.0
+    for lvl, ks, cin, cout, tr, cnt in shapes:
+        if ks == 3:
+            km = m.kernel_map_handle(keys[lvl], keys[lvl], 3)
+            n_in = n_out = m.size(keys[lvl])
+        else:
+            km = m.kernel_map_handle(keys[lvl], keys[lvl + 1], 2)
+            n_in, n_out = (m.size(keys[lvl + 1]), m.size(keys[lvl])) if tr else (m.size(keys[lvl]), m.size(keys[lvl + 1]))
+        M = km.export()[0].shape[0]
+        f = torch.randn(n_in, cin, device=DEV).bfloat16()
+        g = torch.randn(n_out, cout, device=DEV).bfloat16()
+        tw = timeit(lambda: km.conv_wgrad(f, g, bool(tr)), 10, 3)
+        flop = 2.0 * M * cin * cout
+        byts = M * (cin + cout) * 2 + 8 * M
+        tot += tw * cnt
+        print("L%d k%d%s %3d->%3d rows %7d pairs %8d x%-2d  wgrad %.3f ms (%.0f TF, %.2f TB/s alg)" % (
+            lvl, ks, "T" if tr else " ", cin, cout, n_out, M, cnt, tw, flop / tw / 1e9, byts / tw / 1e9))
+    print("sum over a step (stand-alone launches): %.2f ms" % tot)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "wgrad":
+        wgrad()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "coarse":
         coarse()
         sys.exit(0)
