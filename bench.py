@@ -50,12 +50,20 @@ class Cfg:
 
 # ----------------------------------------------------------------------------------------------- byte model
 class ConvLog:
-    """Wraps HipKernelMap conv entry points to log (kind, M, n_out, cin, cout, K, t_ms) per launch."""
+    """Wraps HipKernelMap conv entry points to log (kind, M, n_out, cin, cout, K, HIP events) per launch.
+    mode "all": every launch (the one instrumented DISCOVERY step: ~250 event pairs stretch that step, so its numbers
+    only rank the shapes); mode "only": just the launches of one shape key (a handful of event pairs per step, used
+    INSIDE the timed steps -- the reported roofline comes from these)."""
 
     def __init__(self):
         self.rows = []
-        self.enabled = False
+        self.mode = None          # None | "all" | "only"
+        self.only_key = None
         self._patched = False
+
+    @staticmethod
+    def key_of(kind, K, cin, cout, n_out):
+        return "conv_gather K=%d %d->%d rows=%d" % (K, cin, cout, n_out)
 
     def patch(self):
         if self._patched:
@@ -65,7 +73,7 @@ class ConvLog:
         pairs_cache = {}
 
         def n_pairs(km):
-            key = id(km)
+            key = (id(km.mgr), km.in_key, km.out_key, km.ks)
             if key not in pairs_cache:
                 pairs_cache[key] = int(km.export()[0].shape[0])
             return pairs_cache[key]
@@ -74,28 +82,32 @@ class ConvLog:
             orig = getattr(bh.HipKernelMap, name)
 
             def f(self, *a, **k):
-                if not log.enabled:
+                if log.mode is None:
                     return orig(self, *a, **k)
-                M = n_pairs(self)
+                if kind == "wgrad":
+                    cin, cout, n_out = a[0].shape[1], a[1].shape[1], a[1].shape[0]
+                elif kind == "fwd":
+                    cin, cout = a[0].shape[1], a[1].shape[-1]
+                    n_in, n_out = self._rows(a[3])
+                else:  # dgrad: "output" side is the op's input
+                    cin, cout = a[0].shape[1], a[1].shape[-2]
+                    n_out, _ = self._rows(a[2])
+                key = ConvLog.key_of(kind, self.K, cin, cout, n_out)
+                if log.mode == "only" and (kind == "wgrad" or key != log.only_key):
+                    return orig(self, *a, **k)
+                M = n_pairs(self) if log.mode == "all" else log.M_of.get(key, 0)
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 out = orig(self, *a, **k)
                 e.record()
-                if kind == "wgrad":
-                    cin, cout, n_out = a[0].shape[1], a[1].shape[1], a[1].shape[0]
-                elif kind == "fwd":
-                    w = a[1]
-                    cin, cout, n_out = a[0].shape[1], w.shape[-1], out.shape[0]
-                else:  # dgrad: "output" side is the op's input
-                    w = a[1]
-                    cin, cout, n_out = a[0].shape[1], w.shape[-2], out.shape[0]
                 log.rows.append(dict(kind=kind, M=M, n_out=n_out, cin=cin, cout=cout, K=self.K, ev=(s, e),
-                                     e=a[0].element_size()))
+                                     e=a[0].element_size(), key=key))
                 return out
             setattr(bh.HipKernelMap, name, f)
         wrap("conv_forward", "fwd")
         wrap("conv_dgrad", "dgrad")
         wrap("conv_wgrad", "wgrad")
+        self.M_of = {}
         self._patched = True
 
     def summarize(self):
@@ -114,8 +126,8 @@ class ConvLog:
             else:
                 b = M * r["cin"] * e + r["n_out"] * r["cout"] * e + idx + K * r["cin"] * r["cout"] * e
                 fam["bytes"] += b; fam["ms"] += t; fam["n"] += 1
-                key = "%s K=%d %d->%d rows=%d" % ("conv_gather", K, r["cin"], r["cout"], r["n_out"])
-                g = groups.setdefault(key, dict(bytes=0.0, ms=0.0, n=0, flop=0.0))
+                self.M_of[r["key"]] = M
+                g = groups.setdefault(r["key"], dict(bytes=0.0, ms=0.0, n=0, flop=0.0))
                 g["bytes"] += b; g["ms"] += t; g["n"] += 1; g["flop"] += 2.0 * M * r["cin"] * r["cout"]
         top = sorted(groups.items(), key=lambda kv: -kv[1]["ms"])
         return fam, wg, top
@@ -166,15 +178,16 @@ def train_step(model, ddp, opt, coords, feats, labels, dtype, step_idx, shift=Tr
     return loss
 
 
-def cpu_baseline(seconds_budget=25.0, model_name="Res16UNet34C"):
-    """Oracle ("port"): MinkowskiEngine-CPU-style gather -> BLAS GEMM -> scatter restated with torch CPU ops,
-    same model, one synthetic 5cm scene (~26k voxels), all host cores, fwd + loss + bwd."""
+def cpu_baseline(seconds_budget=30.0, model_name="Res16UNet34C", voxels=150000):
+    """Oracle ("port"): MinkowskiEngine-CPU-style gather -> BLAS GEMM -> scatter restated with torch CPU ops, same
+    model, ONE synthetic 2 cm scene of ~150k voxels (BASELINE.md section 2, config 2 -- the scene unit the GPU runs eight
+    of per step), host cores, fwd + loss + bwd.  Bounded: one warm-up step, then timed steps until the budget is spent."""
     from oracle.backend import OracleBackend
     prev = ME.set_backend(OracleBackend("torch"))
     try:
         cores = min(host_cores(), 16)  # more threads only add OpenMP contention to the small per-offset GEMMs
         torch.set_num_threads(cores)
-        coords, feats, labels = make_batch([0], voxel=0.05, n_target=25000)
+        coords, feats, labels = make_batch([0], voxel=0.02, n_target=voxels)
         torch.manual_seed(42)
         model = models.load_model(model_name)(3, 200, Cfg()).train()
         c, f, l = torch.from_numpy(coords), torch.from_numpy(feats), torch.from_numpy(labels)
@@ -186,32 +199,82 @@ def cpu_baseline(seconds_budget=25.0, model_name="Res16UNet34C"):
             logits, _ = model(x)
             loss = torch.nn.functional.cross_entropy(logits.F, l, ignore_index=-1)
             loss.backward()
+        t_all = time.perf_counter()
         one()  # warm-up (builds nothing persistent: maps are per step, as in the reference)
-        times, t_all = [], time.perf_counter()
-        while len(times) < 5 and (time.perf_counter() - t_all) < seconds_budget:
+        times = []
+        while len(times) < 3 and (not times or (time.perf_counter() - t_all) < seconds_budget):
             t0 = time.perf_counter()
             one()
             times.append(time.perf_counter() - t0)
         best = min(times)
         return {"value": coords.shape[0] / best, "unit": "voxels/s", "cores": cores, "kind": "port",
-                "sample": "%s fwd+loss+bwd, 1 synthetic scene @5cm (%d voxels), fp32, best of %d; oracle BLAS "
-                          "gather-GEMM-scatter restatement of ME's CPU algorithm (not ME itself)" % (
-                              model_name, coords.shape[0], len(times))}
+                "sample": "%s fwd+loss+bwd, 1 synthetic scene @2cm (%d voxels), fp32, best of %d after 1 warm-up (%.1f s of CPU "
+                          "work); oracle BLAS gather-GEMM-scatter restatement of ME's CPU algorithm (not ME itself)" % (
+                              model_name, coords.shape[0], len(times), time.perf_counter() - t_all)}
     finally:
         ME.set_backend(prev)
 
 
 def pmc_traffic(dom_key, args):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
-    MI355X_MICROARCH.md prescribes); only valid for the default workload the counters were collected on."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not (os.path.exists(path) and args.scenes == 8 and args.voxels == 150000 and args.dtype == "bf16"
-            and "K=27 96->96" in dom_key):
-        return None
+    """HBM bytes per launch of the dominant kernel.  STATIC: read from the committed PMC passes of this round
+    (profiles/r02_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected with rocprofv3 --pmc in separate passes, read side
+    doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for the default workload they were collected on, null
+    otherwise.  It is not measured inside this run (PMC collection needs the profiler)."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            break
+    else:
+        return None, None
+    if not (args.scenes == 8 and args.voxels == 150000 and args.dtype == "bf16" and "K=27 96->96" in dom_key):
+        return None, None
     try:
-        return json.load(open(path))["traffic_bytes"]
+        return json.load(open(path))["traffic_bytes"], "static: profiles/%s (rocprofv3 --pmc passes of this workload)" % name
     except Exception:
-        return None
+        return None, None
+
+
+def single_scene_line(model, ddp, opt, dtype, device, args, steps=15, warmup=5):
+    """Secondary line: ONE ~150k-voxel scene per step (the unit SURVEY 8d tabulates).  With ~720 launches on the critical
+    path the step is launch / latency bound at this size; reported so the 8-scene headline is not read as per-scene."""
+    c_np, f_np, l_np = make_batch([1000], voxel=0.02, n_target=args.voxels)
+    c, f, l = torch.from_numpy(c_np).to(device), torch.from_numpy(f_np).to(device), torch.from_numpy(l_np).to(device)
+    for i in range(warmup):
+        train_step(model, ddp, opt, c, f, l, dtype, 5000 + i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        train_step(model, ddp, opt, c, f, l, dtype, 6000 + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"scenes_per_step": 1, "voxels": int(c.shape[0]), "ms_per_step": dt / steps * 1e3, "value": c.shape[0] * steps / dt,
+            "unit": "voxels/s", "steps": steps}
+
+
+def clip_mfma_report(out_dim, n, dtype, device, iters=10):
+    """MFMA sub-report of north_star for the one dense contraction (per-voxel features x 200 text anchors) as the fused
+    CLIP-loss kernel runs it: achieved TFLOP/s vs the 2.5 PF bf16 peak and its bytes (features read once) vs 8 TB/s."""
+    be = ME.get_backend()
+    f = torch.randn(n, out_dim, device=device).to(dtype)
+    t = torch.randn(200, out_dim, device=device)
+    lab = torch.randint(-1, 200, (n,), device=device)
+    neg = torch.randint(0, 200, (n, 3), device=device)
+    for _ in range(3):
+        be.clip_loss_forward(f, t, lab, neg, -1)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        be.clip_loss_forward(f, t, lab, neg, -1)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    flop = 2.0 * n * out_dim * 200
+    byts = n * out_dim * f.element_size() + n * (3 * 4 + 8 + 4 * 8)
+    peak = 2.5e15 if dtype == torch.bfloat16 else 157.3e12
+    return {"kernel": "k_conv_gather<EPI=1> fused CLIP loss forward (normalize + [N,%d]x[%d,200] + gathers + argmax)" % (out_dim, out_dim),
+            "ms": ms, "achieved": flop / (ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / peak,
+            "hbm": {"achieved": byts / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": byts / (ms * 1e-3) / HBM_PEAK},
+            "note": "arithmetic intensity ~%d flop/B: the contraction is bandwidth-limited at this K (SURVEY 8d)" % int(flop / byts)}
 
 
 def log(msg):
@@ -243,6 +306,7 @@ def main():
                          "(scripts/text_representation_train.sh: Res16UNet34D, 512-d text anchors)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-single-scene", action="store_true", help="skip the secondary 1-scene-per-step measurement")
     ap.add_argument("--sync-bn", type=int, default=1, help="convert to MinkowskiSyncBatchNorm when gpus > 1 (main.py:122)")
     ap.add_argument("--compute-priority", type=int, default=0, help="run the compute stream at this HIP stream priority "
                                                                      "(-1 = high: dgrad/BN chain ahead of the side-stream wgrad)")
@@ -303,9 +367,30 @@ def main():
     import gc
     gc.collect()
     gc.disable()   # no cyclic-GC pauses inside the timed region (tensors are freed by refcount as usual)
+    clog = None
+    if rank == 0 and not args.no_roofline:
+        clog = ConvLog()
+        clog.patch()
+    disc = None
     for i in range(args.warmup):   # un-synchronised, like the timed loop: allocator pools reach their pipelined steady state
-        train_step(model, ddp, opt, coords, feats, labels, dtype, i)
+        if i == max(0, args.warmup - 2) and not args.no_roofline:
+            # DISCOVERY step (inside the warm-up, every rank runs it): every conv launch is bracketed by HIP events to rank
+            # the launch shapes and to evaluate the byte model on the real maps; this stretches the step, so its
+            # durations are only used to pick the dominant shape
+            if clog is not None:
+                clog.mode = "all"
+            train_step(model, ddp, opt, coords, feats, labels, dtype, i)
+            if clog is not None:
+                fam, wg, top = clog.summarize()
+                disc = dict(fam=fam, wg=wg, top=top, rows=list(clog.rows))
+                clog.rows = []
+                clog.mode = "only"              # from here on only the dominant shape's launches are bracketed
+                clog.only_key = top[0][0]
+        else:
+            train_step(model, ddp, opt, coords, feats, labels, dtype, i)
     torch.cuda.synchronize()
+    if clog is not None:
+        clog.rows = []                          # keep only the samples of the timed steps
     log("warmup done (%d steps)" % args.warmup)
     if world > 1:
         dist.barrier()
@@ -350,57 +435,58 @@ def main():
         "final_loss": final_loss,
     }
 
-    if rank == 0 and not args.no_roofline:
-        clog = ConvLog()
-        clog.patch()
-        clog.enabled = True
-        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        # NB: in a multi-rank run the other ranks must take part in the collectives of this extra step
-    else:
-        clog = None
-    if not args.no_roofline:
-        if clog is not None:
-            s_ev.record()
-        train_step(model, ddp, opt, coords, feats, labels, dtype, args.warmup + args.steps)
-        if clog is not None:
-            e_ev.record()
-            fam, wg, top = clog.summarize()
-            clog.enabled = False
-            step_ms = s_ev.elapsed_time(e_ev)
-            e = 2 if args.dtype == "bf16" else 4
-            # BN byte model: 3 N C e fwd + 5 N C e bwd per norm layer
-            bn_bytes = 0.0
-            # every BN follows exactly one conv forward launch with the same (n_out, cout), except `final`
-            fwd_rows = [r for r in clog.rows if r["kind"] == "fwd"]
-            for r in fwd_rows[:-1]:
-                bn_bytes += 8.0 * r["n_out"] * r["cout"] * e
-            b_alg_step = fam["bytes"] + wg["bytes"] + bn_bytes
-            # dominant kernel = the k_conv_gather launch shape with the largest total time in the step
-            dom_key, dom = top[0]
-            achieved = dom["bytes"] / (dom["ms"] * 1e-3) if dom["ms"] > 0 else 0.0
-            fam_ach = fam["bytes"] / (fam["ms"] * 1e-3) if fam["ms"] > 0 else 0.0
-            out["roofline"] = {
-                "bound": "hbm",
-                "kernel": "k_conv_gather (sparse-conv forward/dgrad implicit GEMM), dominant launch shape: " + dom_key,
-                "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                "traffic": pmc_traffic(dom_key, args),
-                "launches": dom["n"], "avg_launch_ms": dom["ms"] / max(dom["n"], 1),
-                "alg_bytes_per_launch": dom["bytes"] / max(dom["n"], 1),
-                "mfma_tflops_on_real_pairs": dom["flop"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0,
+    if clog is not None and disc is not None:
+        clog.mode = None
+        fam, wg, top = disc["fam"], disc["wg"], disc["top"]
+        e = 2 if args.dtype == "bf16" else 4
+        # BN byte model: 3 N C e fwd + 5 N C e bwd per norm layer; every BN follows exactly one conv forward
+        # launch with the same (n_out, cout), except the classifier `final` (fine-tune workload)
+        fwd_rows = [r for r in disc["rows"] if r["kind"] == "fwd"]
+        bn_bytes = sum(8.0 * r["n_out"] * r["cout"] * e for r in (fwd_rows[:-1] if args.workload == "ce" else fwd_rows))
+        b_alg_step = fam["bytes"] + wg["bytes"] + bn_bytes
+        dom_key, dom_disc = top[0]
+        # the dominant shape's launches sampled INSIDE the timed steps (un-instrumented otherwise)
+        samp = [r for r in clog.rows if r["key"] == dom_key]
+        samp_ms = [r["ev"][0].elapsed_time(r["ev"][1]) for r in samp]
+        n_s = max(len(samp_ms), 1)
+        avg_ms = sum(samp_ms) / n_s
+        alg_bytes = dom_disc["bytes"] / max(dom_disc["n"], 1)
+        flop = dom_disc["flop"] / max(dom_disc["n"], 1)
+        achieved = alg_bytes / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(dom_key, args)
+        fam_ach = fam["bytes"] / (fam["ms"] * 1e-3) if fam["ms"] > 0 else 0.0
+        out["roofline"] = {
+            "bound": "hbm",
+            "kernel": "k_conv_gather (sparse-conv forward/dgrad implicit GEMM), dominant launch shape: " + dom_key,
+            "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "launches_sampled": len(samp_ms), "launches_per_step": dom_disc["n"], "avg_launch_ms": avg_ms,
+            "min_launch_ms": min(samp_ms) if samp_ms else None, "max_launch_ms": max(samp_ms) if samp_ms else None,
+            "alg_bytes_per_launch": alg_bytes,
+            "mfma_tflops_on_real_pairs": flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
+            "measured": "HIP events on the launching stream around the %d launches of this shape inside the %d timed steps "
+                        "(weight pack ~6 us + kernel); all other launches of the timed steps are un-instrumented" % (len(samp_ms), args.steps),
+            "discovery_step": {
+                "note": "one fully instrumented warm-up step (every conv launch bracketed: the step is stretched, durations "
+                        "rank the shapes and feed the byte model only)",
                 "family": {"kernel": "k_conv_gather, all %d launches of the step" % fam["n"], "achieved": fam_ach / 1e9,
                            "frac": fam_ach / HBM_PEAK, "total_ms": fam["ms"], "avg_launch_ms": fam["ms"] / max(fam["n"], 1)},
-                "wgrad": {"kernel": "k_wgrad_bf16 + k_wgrad_reduce, all %d launches" % wg["n"],
+                "wgrad": {"kernel": "k_wgrad_ps / k_wgrad_bf16 + reduce, all %d launches (side stream)" % wg["n"],
                           "achieved": (wg["bytes"] / (wg["ms"] * 1e-3) / 1e9) if wg["ms"] > 0 else 0.0,
                           "frac": (wg["bytes"] / (wg["ms"] * 1e-3) / HBM_PEAK) if wg["ms"] > 0 else 0.0, "total_ms": wg["ms"]},
-                "step": {"b_alg_bytes": b_alg_step, "b_alg_per_voxel": b_alg_step / n_vox,
-                         "frac_of_hbm_peak": b_alg_step / (ms_per_step * 1e-3) / HBM_PEAK,
-                         "conv_gather_ms": fam["ms"], "wgrad_ms": wg["ms"], "instrumented_step_ms": step_ms},
-                "note": "durations are HIP events on torch's current stream around each engine call (pack + kernel); "
-                        "traffic: see profiles/ for the PMC passes",
-            }
+                "top_shapes": [{"shape": k, "launches": g["n"], "ms": g["ms"], "alg_GBps": g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] else 0.0}
+                               for k, g in top[:6]]},
+            "step": {"b_alg_bytes": b_alg_step, "b_alg_per_voxel": b_alg_step / n_vox,
+                     "frac_of_hbm_peak": b_alg_step / (ms_per_step * 1e-3) / HBM_PEAK},
+        }
+        if args.workload == "clip":
+            out["roofline"]["mfma"] = clip_mfma_report(out_dim=model.PLANES[7], n=n_vox, dtype=dtype, device=device)
     log("roofline pass done")
+    if rank == 0 and world == 1 and not args.no_single_scene and args.scenes != 1:
+        out["single_scene"] = single_scene_line(model, ddp, opt, dtype, device, args)
+        log("single-scene line done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(model_name=args.model)
+        out["cpu_baseline"] = cpu_baseline(model_name=args.model, voxels=args.voxels)
         log("cpu baseline done")
     if rank == 0:
         print(json.dumps(out))

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LGS_ABI_VERSION 1
+#define LGS_ABI_VERSION 2
 
 enum lgs_dtype { LGS_F32 = 0, LGS_BF16 = 1 };
 
@@ -105,9 +105,17 @@ int lgs_kmap_export(lgs_kmap *km, int32_t *k, int32_t *in_row, int32_t *out_row,
  * op's input/output channels.  `workspace` must hold lgs_conv_workspace_bytes(...) bytes. */
 int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype, int op /*0 fwd,1 dgrad,2 wgrad*/);
 
-/* out[n_out,cout] = conv(in[n_in,cin]) (+ bias[cout] if non-NULL) */
+/* out[n_out,cout] = conv(in[n_in,cin]) (+ bias[cout] if non-NULL)
+ * bn_partial (may be NULL): the BatchNorm that follows the conv in every block of the model family
+ *   (/root/reference/models/modules/resnet_block.py:41-57: conv -> norm) needs sum / sum of squares of this output per
+ *   channel; the conv epilogue can emit them per position tile -- float32 [rows][2][cout], rows =
+ *   lgs_conv_bn_partial_rows(...) (0 = this launch shape cannot, pass NULL) -- as sum(y - pivot), sum((y - pivot)^2) of the
+ *   STORED values, so lgs_bn_forward / lgs_bn_stats need not read the output again for their statistics pass.
+ *   bn_pivot: float32 [cout] per-channel shift (BatchNorm's running mean), NULL = 0. */
+int lgs_conv_bn_partial_rows(const lgs_kmap *km, int transposed, int cout, int dtype);
 int lgs_conv_forward(lgs_kmap *km, int transposed, const void *in, int cin, const float *weight, int cout,
-                     const float *bias, void *out, int dtype, void *workspace, void *stream);
+                     const float *bias, void *out, int dtype, void *workspace, float *bn_partial, const float *bn_pivot,
+                     void *stream);
 /* grad_in[n_in,cin] from grad_out[n_out,cout] */
 int lgs_conv_dgrad(lgs_kmap *km, int transposed, const void *grad_out, int cout, const float *weight, int cin,
                    void *grad_in, int dtype, void *workspace, void *stream);
@@ -122,11 +130,15 @@ int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const 
  * on return mean[C], invstd[C].  running_mean/var (float32 [C]) updated with `momentum`
  * (unbiased variance), may be NULL; num_batches_tracked (device int64 scalar, nn.BatchNorm1d's buffer) is
  * incremented by the same kernel, may be NULL.  residual may be NULL.  y may alias x.
- * workspace: lgs_bn_workspace_bytes(n, c) bytes of caller-owned device scratch (no allocation inside). */
+ * workspace: lgs_bn_workspace_bytes(n, c) bytes of caller-owned device scratch (no allocation inside).
+ * conv_partials / conv_partial_rows / pivot: statistics already produced by the preceding lgs_conv_forward (see there);
+ * NULL / 0 = compute them from x. */
 int64_t lgs_bn_workspace_bytes(int64_t n, int c);
 int lgs_bn_forward(const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps,
                    float momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked,
-                   const void *residual, int relu, void *y, float *stats, int dtype, void *workspace, void *stream);
+                   const void *residual, int relu, void *y, float *stats, int dtype, void *workspace,
+                   const float *conv_partials /* lgs_conv_forward's bn_partial or NULL */, int conv_partial_rows,
+                   const float *pivot /* the bn_pivot that conv call was given */, void *stream);
 /* Backward of the fused op.  x = forward input, stats = the forward's mean/invstd.
  * relu: 0 = none; 1 = ReLU mask taken from the forward OUTPUT y (required when a residual was added);
  *       2 = mask recomputed from x as (xhat*gamma + beta > 0), y may be NULL (one tensor read fewer).
@@ -150,7 +162,8 @@ int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t dy_row
  *   (all-reduce of sums)
  *   lgs_bn_backward_apply  <- sums[2C] (all-reduced), 1/N either by value (inv_n_total) or, if inv_n_device != NULL,
  *                             read from the device scalar lgs_bn_sync_combine wrote (no host sync) */
-int lgs_bn_stats(const void *x, int64_t n, int c, float *rec /* [2C+1] */, int dtype, void *workspace, void *stream);
+int lgs_bn_stats(const void *x, int64_t n, int c, float *rec /* [2C+1] */, int dtype, void *workspace,
+                 const float *conv_partials, int conv_partial_rows, const float *pivot, void *stream);
 int lgs_bn_sync_combine(const float *all_stats, int world, int c, float eps, float momentum, float *running_mean,
                         float *running_var, int64_t *num_batches_tracked, float *stats, float *inv_n_total, void *stream);
 int lgs_bn_apply(const void *x, int64_t n, int c, const float *gamma, const float *beta, const float *stats,

@@ -134,7 +134,18 @@ struct ClipEpi {
   float *d_pos = nullptr, *d_neg = nullptr, *inv_norm = nullptr;
   int64_t *pred = nullptr;
 };
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// BatchNorm statistics from the conv epilogue (EPI = 0): when `partial` is set, every workgroup also writes, for its
+// rows and channels, sum(y - pivot) and sum((y - pivot)^2) of the values it STORES (after the bf16 rounding, so they
+// are the statistics of the tensor BatchNorm will read) to partial[tile][2][cout]: the [N, C] output is not read again
+// for the statistics pass (k_colreduce<0> was ~6 % of the step).  pivot (may be NULL = 0) is a per-channel shift that
+// keeps var = E[d^2] - E[d]^2 well conditioned; the caller passes BatchNorm's running mean.
+struct BnEpi {
+  float *partial = nullptr;     // [gridDim.x][2][cout_real]
+  const float *pivot = nullptr; // [cout_real] or NULL
+};
+template <typename T> __device__ inline float stored_value(float x);
+template <> __device__ inline float stored_value<float>(float x) { return x; }
+template <> __device__ inline float stored_value<bf16_t>(float x) { return bf16_to_f32(f32_to_bf16(x)); }
 template <typename T> __device__ inline float sq16(const u32x4 &f, float s);
 template <> __device__ inline float sq16<bf16_t>(const u32x4 &f, float s) {
   // two bf16 per dword: the high one IS an fp32 with the low half masked off, the low one is a 16-bit shift away
@@ -162,7 +173,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
                                                              float *__restrict__ out_f32_arg,
                                                              const float *__restrict__ row_scale,
                                                              unsigned in_bytes, unsigned w_bytes, int64_t zstride,
-                                                             ClipEpi ce) {
+                                                             ClipEpi ce, BnEpi be) {
   static_assert(EPI == 0 || (RB == 1 && WN == 1), "the CLIP epilogue owns whole rows: one row block, all columns per wave");
   // SC = 32-channel chunks per weight SLAB: the weights of (offset, slab) are staged in LDS once per workgroup
   // and one barrier separates slabs, while the gathered feature fragments stream chunk by chunk through a
@@ -202,7 +213,16 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     for (int g = 0; g < (TM + 63) / 64; ++g) smask |= v.mask64[pos_wg / 64 + g];
   } else if (v.tile_k) {
     kw_single = v.tile_k[pos_wg / 64];
-    if (kw_single < 0) return;  // padding group: nothing to write
+    if (kw_single < 0) {        // padding group: nothing to write (its statistics row is all zeros)
+      if constexpr (EPI == 0) {
+        if (be.partial != nullptr)
+          for (int e = tid; e < 2 * WB * 32; e += NT) {
+            const int st = e / (WB * 32), ch = nb_wg * 32 + e % (WB * 32);
+            if (ch < cout_real) be.partial[((int64_t)tile * 2 + st) * cout_real + ch] = 0.f;
+          }
+      }
+      return;
+    }
   }
   // Slot split (gridDim.z == 3, 3^3 maps of the coarse levels): this workgroup sums only 9 of the 27 offsets into
   // its own fp32 partial image; k_sum_partials adds the three in a fixed order.  A coarse level has too few row
@@ -514,6 +534,76 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
       }
     }
   }
+  if constexpr (EPI == 0) {
+    if (be.partial != nullptr) {   // kernel-uniform
+      // ---- BatchNorm statistics of this workgroup's rows.  Lane (vx, h) holds, per row block, the 16 NCB channels
+      // nb*32 + 8q + 4h + i of voxel vx: sum the row blocks in registers, then a HALVING butterfly over the 32 lanes of a
+      // half wave (step k: a lane keeps one half of its values and adds the partner's copy of that half) -- V values cost
+      // ~V shuffles instead of 5 V -- leaves every lane with NCB finished column sums; the WM waves are folded through
+      // the (now idle) weight LDS in wave order, i.e. deterministically.
+      constexpr int V = 32 * NCB;              // [stat][nb][r]: 16 NCB sums + 16 NCB sums of squares
+      float vst[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) vst[j] = 0.f;
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const int64_t p = pos_w + rb * 32 + vx;
+        const int32_t orow = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
+        const bool live = orow >= 0;
+#pragma unroll
+        for (int nb = 0; nb < NCB; ++nb) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c0 = (nb_w + nb) * 32 + 8 * q + 4 * h;
+            float pv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (be.pivot && c0 < cout_real) { const float4 t4 = *reinterpret_cast<const float4 *>(be.pivot + c0); pv[0] = t4.x; pv[1] = t4.y; pv[2] = t4.z; pv[3] = t4.w; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float o = acc[rb][nb][4 * q + i];
+              if (bias && c0 + i < cout_real) o += bias[c0 + i];
+              const float d = (live && c0 < cout_real) ? stored_value<T>(o) - pv[i] : 0.f;
+              vst[nb * 16 + 4 * q + i] += d;
+              vst[16 * NCB + nb * 16 + 4 * q + i] += d * d;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int n = V >> k;                  // values held before this step
+        const bool up = (vx >> k) & 1;         // this lane keeps the upper half
+#pragma unroll
+        for (int i = 0; i < n / 2; ++i) {
+          const float keep = up ? vst[n / 2 + i] : vst[i];
+          const float send = up ? vst[i] : vst[n / 2 + i];
+          vst[i] = keep + __shfl_xor(send, 1 << k);
+        }
+      }
+      // lane (vx, h) now holds original indices j = sum_k bit_k(vx) * (V >> (k+1)) + t, t < NCB
+      __syncthreads();                         // every wave is done with the weight LDS
+      float *stage = reinterpret_cast<float *>(&lds[0][0]);     // [WM][2][WB*32]
+      constexpr int CT = WB * 32;
+      int jbase = 0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) jbase += ((vx >> k) & 1) * (V >> (k + 1));
+#pragma unroll
+      for (int t = 0; t < NCB; ++t) {
+        const int j = jbase + t, st = j / (16 * NCB), jj = j % (16 * NCB), nb = jj / 16, r = jj % 16;
+        const int cl = (wn * NCB + nb) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);       // channel inside the workgroup's tile
+        stage[(wm * 2 + st) * CT + cl] = vst[t];
+      }
+      __syncthreads();
+      for (int e = tid; e < 2 * CT; e += NT) {
+        const int st = e / CT, cl = e % CT, ch = nb_wg * 32 + cl;
+        if (ch < cout_real) {
+          float sum = 0.f;
+#pragma unroll
+          for (int w = 0; w < WM; ++w) sum += stage[(w * 2 + st) * CT + cl];
+          be.partial[((int64_t)tile * 2 + st) * cout_real + ch] = sum;
+        }
+      }
+    }
+  }
 }
 
 // rows that no position of the view writes must still be defined: the forward output of a strided
@@ -524,7 +614,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
 // Tile choice: 256 positions x up to 128 channels when the map fills the chip, otherwise 128-position x 64-channel
 // tiles, one 32 x 64 block per wave (coarse levels: few rows, many channels).
 // SC = chunks per weight slab (sized to ~6-8 staging registers per thread), D = depth of the gather ring.
-struct GatherCfg { int id, sc, wb; };
+struct GatherCfg { int id, sc, wb, tm; };   // tm = positions per workgroup tile
 template <typename T>
 GatherCfg gather_cfg(const View &v, int nb_total) {
   constexpr bool kF32 = (sizeof(T) == 4);
@@ -532,24 +622,24 @@ GatherCfg gather_cfg(const View &v, int nb_total) {
   if (big) {
     // 5..7 blocks (e.g. the 200 classes / 200 CLIP anchors = 7 blocks): one 128-position tile spans ALL output
     // channels, so the [N, C] feature matrix is streamed exactly once (dense GEMM with a small N)
-    if (nb_total >= 5 && nb_total <= 7 && v.nbr == nullptr) return {6, kF32 ? 1 : 2, 7};
-    if (nb_total == 1) return {0, kF32 ? 2 : 4, 1};
-    if (nb_total == 2) return {1, kF32 ? 2 : 4, 2};
-    if (nb_total == 3 || (nb_total % 3 == 0 && nb_total % 4 != 0)) return {2, kF32 ? 2 : 4, 3};
+    if (nb_total >= 5 && nb_total <= 7 && v.nbr == nullptr) return {6, kF32 ? 1 : 2, 7, 128};
+    if (nb_total == 1) return {0, kF32 ? 2 : 4, 1, 256};
+    if (nb_total == 2) return {1, kF32 ? 2 : 4, 2, 256};
+    if (nb_total == 3 || (nb_total % 3 == 0 && nb_total % 4 != 0)) return {2, kF32 ? 2 : 4, 3, 256};
     // wide outputs (>= 256 channels, e.g. the 512-d CLIP representation model): 256 positions x 256 channels per
     // 8-wave workgroup -- every staged weight fragment serves two row blocks and the rows are gathered half as often
-    if (!kF32 && nb_total % 8 == 0) return {15, 2, 8};
-    if (!kF32) return {7, 2, 4};   // bf16: 128-position tiles, 4 column blocks per wave at 3 waves/SIMD
-    return {3, kF32 ? 1 : 2, 4};
+    if (!kF32 && nb_total % 8 == 0) return {15, 2, 8, 256};
+    if (!kF32) return {7, 2, 4, 128};   // bf16: 128-position tiles, 4 column blocks per wave at 3 waves/SIMD
+    return {3, kF32 ? 1 : 2, 4, 256};
   }
-  if (nb_total == 1) return {4, kF32 ? 2 : 4, 1};
+  if (nb_total == 1) return {4, kF32 ? 2 : 4, 1, 64};
   static const int small_override = getenv("LGS_SMALL_CFG") ? atoi(getenv("LGS_SMALL_CFG")) : 0;  // tuning knob
-  if (!kF32 && small_override == 5) return {5, 4, 2};
-  if (!kF32 && small_override == 9) return {9, 4, 4};
-  if (!kF32 && small_override == 10) return {10, 4, 2};
-  if (!kF32 && small_override == 11) return {11, 4, 4};
-  if (!kF32) return {8, 4, 2};   // measured best on the L3/L4 shapes (tools/microbench.py coarse): 128 positions x 64 channels
-  return {5, 2, 2};
+  if (!kF32 && small_override == 5) return {5, 4, 2, 64};
+  if (!kF32 && small_override == 9) return {9, 4, 4, 64};
+  if (!kF32 && small_override == 10) return {10, 4, 2, 64};
+  if (!kF32 && small_override == 11) return {11, 4, 4, 64};
+  if (!kF32) return {8, 4, 2, 128};   // measured best on the L3/L4 shapes (tools/microbench.py coarse): 128 positions x 64 channels
+  return {5, 2, 2, 64};
 }
 
 // out = p0 + p1 + p2 (+ bias), fixed order; 4 elements per thread
@@ -583,7 +673,8 @@ inline int64_t split_partial_bytes(int K, int64_t n_out, int o_real) {
 template <typename T>
 int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real, int nc, const uint4 *wp,
                   int nb_total, int ncp, int nbp, int K, T *out, int cout_real, const float *bias, hipStream_t s,
-                  float *out_f32 = nullptr, const float *row_scale = nullptr, float *zpartial = nullptr) {
+                  float *out_f32 = nullptr, const float *row_scale = nullptr, float *zpartial = nullptr,
+                  const BnEpi *bn = nullptr, int *bn_rows = nullptr) {
   if (v.n_pad == 0) return 0;
   constexpr int LDc = Tr<T>::LD;
   const uint64_t in_bytes64 = (uint64_t)v.n_in * (uint64_t)cin_real * sizeof(T);
@@ -606,7 +697,9 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
     if (did_split) grid.z = 3;                                                                                    \
     hipLaunchKernelGGL((k_conv_gather<T, RB, NCB, WM, WN, SC, D>), grid, dim3(WM *WN * 64), 0, s, v, in, cin_real, nc,    \
                        reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, out, cout_real, did_split ? nullptr : bias, \
-                       did_split ? zpartial : out_f32, row_scale, in_bytes, w_bytes, zstride, ClipEpi());         \
+                       did_split ? zpartial : out_f32, row_scale, in_bytes, w_bytes, zstride, ClipEpi(),           \
+                       (bn && !did_split) ? *bn : BnEpi());                                                       \
+    if (bn_rows) *bn_rows = did_split ? 0 : (int)grid.x;                                                          \
   } while (0)
   switch (cfg.id) {
     case 0: LGS_LAUNCH(2, 1, 4, 1, (kF32 ? 2 : 4), (kF32 ? 3 : 4)); break;
@@ -632,10 +725,23 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
   return 0;
 }
 
+// rows of BatchNorm statistics the forward launch of this shape writes (= its position tiles), 0 if the launch cannot
+// produce them (slot-split launches sum partial images afterwards; odd output widths go through a scratch image)
+template <typename T>
+int bn_partial_rows_t(const View &v, int K, int o_real) {
+  if (v.n_pad == 0 || o_real % 4 != 0) return 0;
+  const int nb_total = pad32(o_real) / 32;
+  const GatherCfg cfg = gather_cfg<T>(v, nb_total);
+  const int64_t gx = v.n_pad / cfg.tm, gy = (nb_total + cfg.wb - 1) / cfg.wb;
+  const bool split = sizeof(T) == 2 && getenv("LGS_NO_SPLIT") == nullptr && v.KS > 1 && K == 27 &&
+                     split_partial_bytes(K, v.n_out, o_real) > 0 && gx * gy < 600;
+  return split ? 0 : (int)gx;
+}
+
 template <typename T>
 int conv_gather_op(const View &v, const void *in_v, int g_real, const float *weight, int K, int cin_w, int cout_w,
                    int transposed_w, int o_real, const float *bias, void *out_v, void *workspace, hipStream_t s,
-                   int w_o_real = -1) {
+                   int w_o_real = -1, const BnEpi *bn = nullptr) {
   if (w_o_real < 0) w_o_real = o_real;
   constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
   const int g_pad = pad32(g_real), nc = g_pad / 32, nb_total = pad32(o_real) / 32;
@@ -687,8 +793,13 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
   float *zpartial = nullptr;
   if (w_o_real == o_real && split_partial_bytes(K, v.n_out, o_real) > 0)
     zpartial = reinterpret_cast<float *>(ws + wbytes + ((g_real % EPL != 0) ? align256(v.n_in * (int64_t)g_pad * (int64_t)sizeof(T)) : 0));
-  return launch_gather<T>(v, cfg, in, g_stride, nc, wp, nb_total, ncp, nbp, K, reinterpret_cast<T *>(out_v), o_real, bias, s,
-                          nullptr, nullptr, zpartial);
+  int rows = 0;
+  int rc = launch_gather<T>(v, cfg, in, g_stride, nc, wp, nb_total, ncp, nbp, K, reinterpret_cast<T *>(out_v), o_real, bias, s,
+                            nullptr, nullptr, zpartial, bn, &rows);
+  if (rc) return rc;
+  LGS_REQUIRE(!(bn && bn->partial) || rows == bn_partial_rows_t<T>(v, K, o_real),
+              "conv forward: BatchNorm statistics rows differ from lgs_conv_bn_partial_rows (internal error)");
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------ CLIP contraction
@@ -779,7 +890,7 @@ int clip_loss_forward_t(const void *feat, int64_t n, int c, const float *anchors
 #define LGS_CLIP(NCB, SC, D)                                                                                              \
   hipLaunchKernelGGL((k_conv_gather<T, 1, NCB, 4, 1, SC, D, 1>), grid, dim3(256), 0, s, v, f, c, nc,                      \
                      reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, (T *)nullptr, na, (const float *)nullptr, sim, \
-                     (const float *)nullptr, (unsigned)in_bytes64, (unsigned)w_bytes64, (int64_t)0, ce)
+                     (const float *)nullptr, (unsigned)in_bytes64, (unsigned)w_bytes64, (int64_t)0, ce, BnEpi())
   switch (ncb) {
     case 1: LGS_CLIP(1, (kF32 ? 4 : 8), (kF32 ? 4 : 8)); break;
     case 2: LGS_CLIP(2, (kF32 ? 2 : 4), (kF32 ? 3 : 4)); break;
@@ -811,16 +922,29 @@ int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtyp
   return bytes + 256;
 }
 
+int lgs_conv_bn_partial_rows(const lgs_kmap *km, int transposed, int cout, int dtype) {
+  if (!km) return 0;
+  const View &v = transposed ? km->bwd : km->fwd;
+  if (dtype == LGS_F32) return bn_partial_rows_t<float>(v, km->K, cout);
+  if (dtype == LGS_BF16) return bn_partial_rows_t<bf16_t>(v, km->K, cout);
+  return 0;
+}
+
 int lgs_conv_forward(lgs_kmap *km, int transposed, const void *in, int cin, const float *weight, int cout,
-                     const float *bias, void *out, int dtype, void *workspace, void *stream) {
+                     const float *bias, void *out, int dtype, void *workspace, float *bn_partial, const float *bn_pivot,
+                     void *stream) {
   LGS_REQUIRE(km && weight && workspace, "lgs_conv_forward: null argument");
   LGS_REQUIRE(!(transposed && km->ks == 3), "transposed 3x3x3 convolution is not part of the model family");
   const View &v = transposed ? km->bwd : km->fwd;
   View vv = v; vv.mirror = 0;
   hipStream_t s = (hipStream_t)stream;
   if (kmap_wait(km, s)) return 1;
-  if (dtype == LGS_F32) return conv_gather_op<float>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s);
-  if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s);
+  BnEpi bn;
+  bn.partial = bn_partial; bn.pivot = bn_pivot;
+  LGS_REQUIRE(!bn_partial || lgs_conv_bn_partial_rows(km, transposed, cout, dtype) > 0,
+              "lgs_conv_forward: this launch shape produces no BatchNorm statistics (see lgs_conv_bn_partial_rows)");
+  if (dtype == LGS_F32) return conv_gather_op<float>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr);
+  if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr);
   LGS_REQUIRE(false, "lgs_conv_forward: unknown dtype");
 }
 

@@ -166,18 +166,36 @@ __device__ inline void fold_sums(const float *__restrict__ scratch, int nblocks,
     for (int q = 1; q < kFoldSl; ++q) { s += red[q][0][threadIdx.x % kFoldCh]; ss += red[q][1][threadIdx.x % kFoldCh]; }
   }
 }
+// statistics that arrive as per-tile partial rows from the conv epilogue (BnEpi): fold groups of rows into <= 128 rows
+// of the same [row][2][C] layout, fixed order (deterministic)
+__global__ __launch_bounds__(256) void k_partial_reduce(const float *__restrict__ part, int rows, int c2, int rows_per_block,
+                                                        float *__restrict__ out) {
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, rows);
+  for (int col = threadIdx.x; col < c2; col += blockDim.x) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+      a0 += part[(int64_t)(r + 0) * c2 + col]; a1 += part[(int64_t)(r + 1) * c2 + col];
+      a2 += part[(int64_t)(r + 2) * c2 + col]; a3 += part[(int64_t)(r + 3) * c2 + col];
+    }
+    for (; r < r1; ++r) a0 += part[(int64_t)r * c2 + col];
+    out[(int64_t)blockIdx.x * c2 + col] = (a0 + a1) + (a2 + a3);
+  }
+}
+
+// pivot_mode 0: the per-channel pivot is row 0 of x (k_colreduce<0>); 1: pivot_ptr[ch] (or 0 if NULL) -- conv-epilogue partials
 template <typename T>
 __global__ __launch_bounds__(256) void k_fold_fwd(const float *__restrict__ scratch, const T *__restrict__ x, int nblocks, int c,
                                                   int64_t n, float eps, float momentum, float *__restrict__ running_mean,
                                                   float *__restrict__ running_var, long long *__restrict__ nbt,
-                                                  float *__restrict__ stats) {
+                                                  float *__restrict__ stats, int pivot_mode, const float *__restrict__ pivot_ptr) {
   __shared__ double red[kFoldSl][2][kFoldCh];
   const int ch = blockIdx.x * kFoldCh + (threadIdx.x % kFoldCh), part = threadIdx.x / kFoldCh;
   double s, ss;
   fold_sums(scratch, nblocks, c, ch, part, s, ss, red);
   if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;   // nn.BatchNorm1d.num_batches_tracked
   if (part != 0 || ch >= c) return;
-  const double pivot = n > 0 ? (double)ld_elem(x + ch) : 0.0;
+  const double pivot = pivot_mode ? (pivot_ptr ? (double)pivot_ptr[ch] : 0.0) : (n > 0 ? (double)ld_elem(x + ch) : 0.0);
   double dm = n > 0 ? s / (double)n : 0.0;
   double var = n > 0 ? ss / (double)n - dm * dm : 0.0;
   if (var < 0.0) var = 0.0;
@@ -193,13 +211,14 @@ __global__ __launch_bounds__(256) void k_fold_fwd(const float *__restrict__ scra
 // split API (SyncBN): local mean and M2 = sum (x - mean)^2, to be combined across ranks with Chan's formula
 template <typename T>
 __global__ __launch_bounds__(256) void k_fold_stats(const float *__restrict__ scratch, const T *__restrict__ x, int nblocks, int c,
-                                                    int64_t n, float *__restrict__ mean_m2) {
+                                                    int64_t n, float *__restrict__ mean_m2, int pivot_mode,
+                                                    const float *__restrict__ pivot_ptr) {
   __shared__ double red[kFoldSl][2][kFoldCh];
   const int ch = blockIdx.x * kFoldCh + (threadIdx.x % kFoldCh), part = threadIdx.x / kFoldCh;
   double s, ss;
   fold_sums(scratch, nblocks, c, ch, part, s, ss, red);
   if (part != 0 || ch >= c) return;
-  const double pivot = n > 0 ? (double)ld_elem(x + ch) : 0.0;
+  const double pivot = pivot_mode ? (pivot_ptr ? (double)pivot_ptr[ch] : 0.0) : (n > 0 ? (double)ld_elem(x + ch) : 0.0);
   const double dm = n > 0 ? s / (double)n : 0.0;
   double m2 = ss - (double)n * dm * dm;
   if (m2 < 0.0) m2 = 0.0;
@@ -359,19 +378,37 @@ inline int reduce_blocks(int64_t n, int64_t *rows_per_block) {
   return (int)((n + *rows_per_block - 1) / *rows_per_block > 0 ? (n + *rows_per_block - 1) / *rows_per_block : 1);
 }
 
+// statistics source: either the column reduction over x, or the conv epilogue's per-tile partial rows
+template <typename T>
+int stats_partials(const T *x, int64_t n, int c, const float *partials, int partial_rows, float *scratch, hipStream_t s, int *nb_out) {
+  if (partials && partial_rows > 0) {
+    int nb = partial_rows < 128 ? partial_rows : 128;
+    const int rpb = (partial_rows + nb - 1) / nb;
+    nb = (partial_rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(k_partial_reduce, nb, 256, 0, s, partials, partial_rows, 2 * c, rpb, scratch);
+    *nb_out = nb;
+    return 0;
+  }
+  int64_t rpb;
+  const int nb = reduce_blocks(n, &rpb);
+  hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, n, c, 0,
+                     rpb, scratch, (int64_t)c);
+  *nb_out = nb;
+  return 0;
+}
+
 template <typename T>
 int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const float *beta, float eps, float momentum,
                  float *rm, float *rv, long long *nbt, const void *res, int relu, void *yv, float *stats, void *workspace,
-                 hipStream_t s) {
+                 hipStream_t s, const float *partials, int partial_rows, const float *pivot) {
   constexpr int W = Vec<T>::W;
   LGS_REQUIRE(c % W == 0 && c / W <= kNT && c <= 2048, "lgs_bn_forward: channel count unsupported");
-  int64_t rpb;
-  int nb = reduce_blocks(n, &rpb);
+  int nb = 0;
   float *scratch = reinterpret_cast<float *>(workspace);  // caller-owned: no allocator call (and no implicit sync) here
   const T *x = reinterpret_cast<const T *>(xv);
-  hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, n, c, 0,
-                     rpb, scratch, (int64_t)c);
-  hipLaunchKernelGGL((k_fold_fwd<T>), (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, x, nb, c, n, eps, momentum, rm, rv, nbt, stats);
+  const int pm = (partials && partial_rows > 0) ? 1 : 0;
+  stats_partials<T>(x, n, c, partials, partial_rows, scratch, s, &nb);
+  hipLaunchKernelGGL((k_fold_fwd<T>), (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, x, nb, c, n, eps, momentum, rm, rv, nbt, stats, pm, pivot);
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
@@ -406,16 +443,16 @@ int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, in
 }
 
 template <typename T>
-int bn_stats_t(const void *xv, int64_t n, int c, float *mean_m2, void *workspace, hipStream_t s) {
+int bn_stats_t(const void *xv, int64_t n, int c, float *mean_m2, void *workspace, hipStream_t s, const float *partials,
+               int partial_rows, const float *pivot) {
   constexpr int W = Vec<T>::W;
   LGS_REQUIRE(c % W == 0 && c / W <= kNT && c <= 2048, "lgs_bn_stats: channel count unsupported");
-  int64_t rpb;
-  int nb = reduce_blocks(n, &rpb);
+  int nb = 0;
   float *scratch = reinterpret_cast<float *>(workspace);
   const T *x = reinterpret_cast<const T *>(xv);
-  hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, n, c, 0,
-                     rpb, scratch, (int64_t)c);
-  hipLaunchKernelGGL((k_fold_stats<T>), (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, x, nb, c, n, mean_m2);
+  const int pm = (partials && partial_rows > 0) ? 1 : 0;
+  stats_partials<T>(x, n, c, partials, partial_rows, scratch, s, &nb);
+  hipLaunchKernelGGL((k_fold_stats<T>), (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, x, nb, c, n, mean_m2, pm, pivot);
   LGS_HIP(hipGetLastError());
   return 0;
 }
@@ -471,10 +508,11 @@ using namespace lgs;
 
 extern "C" {
 
-int lgs_bn_stats(const void *x, int64_t n, int c, float *mean_m2, int dtype, void *workspace, void *stream) {
+int lgs_bn_stats(const void *x, int64_t n, int c, float *mean_m2, int dtype, void *workspace, const float *conv_partials,
+                 int conv_partial_rows, const float *pivot, void *stream) {
   LGS_REQUIRE(x && mean_m2 && workspace, "lgs_bn_stats: null argument");
-  if (dtype == LGS_F32) return bn_stats_t<float>(x, n, c, mean_m2, workspace, (hipStream_t)stream);
-  if (dtype == LGS_BF16) return bn_stats_t<bf16_t>(x, n, c, mean_m2, workspace, (hipStream_t)stream);
+  if (dtype == LGS_F32) return bn_stats_t<float>(x, n, c, mean_m2, workspace, (hipStream_t)stream, conv_partials, conv_partial_rows, pivot);
+  if (dtype == LGS_BF16) return bn_stats_t<bf16_t>(x, n, c, mean_m2, workspace, (hipStream_t)stream, conv_partials, conv_partial_rows, pivot);
   LGS_REQUIRE(false, "lgs_bn_stats: unknown dtype");
 }
 int lgs_bn_apply(const void *x, int64_t n, int c, const float *gamma, const float *beta, const float *stats,
@@ -516,16 +554,18 @@ int lgs_bn_backward_apply(const void *x, const void *y, const void *dy, int64_t 
 int64_t lgs_bn_workspace_bytes(int64_t n, int c) {
   int64_t rpb;
   int nb = reduce_blocks(n, &rpb);
+  if (nb < 128) nb = 128;   // k_partial_reduce folds conv-epilogue partial rows into <= 128 rows
   return (int64_t)sizeof(float) * 2 * c * (nb + 2) + 256;
 }
 
 int lgs_bn_forward(const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps, float momentum,
                    float *running_mean, float *running_var, int64_t *num_batches_tracked, const void *residual, int relu,
-                   void *y, float *stats, int dtype, void *workspace, void *stream) {
+                   void *y, float *stats, int dtype, void *workspace, const float *conv_partials, int conv_partial_rows,
+                   const float *pivot, void *stream) {
   LGS_REQUIRE(x && y && gamma && beta && stats && workspace, "lgs_bn_forward: null argument");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == LGS_F32) return bn_forward_t<float>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), residual, relu, y, stats, workspace, s);
-  if (dtype == LGS_BF16) return bn_forward_t<bf16_t>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), residual, relu, y, stats, workspace, s);
+  if (dtype == LGS_F32) return bn_forward_t<float>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), residual, relu, y, stats, workspace, s, conv_partials, conv_partial_rows, pivot);
+  if (dtype == LGS_BF16) return bn_forward_t<bf16_t>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), residual, relu, y, stats, workspace, s, conv_partials, conv_partial_rows, pivot);
   LGS_REQUIRE(false, "lgs_bn_forward: unknown dtype");
 }
 

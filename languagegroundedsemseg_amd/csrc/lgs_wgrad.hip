@@ -19,6 +19,7 @@
 #include "lgs_common.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace lgs {
 
@@ -552,7 +553,115 @@ __device__ __forceinline__ void ps_wave(const PsArgs &a, char *smem, const int w
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, LGS_AS3(dst + j * 1024), 16, off, 0, 0, 0);
     }
   };
-  auto issue_gather = [&](int cc, int s) __attribute__((always_inline)) {   // the NW gathered tiles of 16-position group s of chunk cc
+  // One step of the stream: the kernel-map rows of the NEXT gather group (nc, ns) are requested from LDS, then -- once
+  // the DMA of group (cc, s) has landed (vmcnt) -- its fragments; ONE lgkmcnt wait covers both, the next group's DMA
+  // is issued and only then the MFMAs of group (cc, s) run: the LDS round trip is paid once per step, and the new
+  // gathers are in flight during the MFMAs.  nvm = DMA instructions that may still be outstanding behind group (cc, s).
+  int cslot = 0;
+  auto step = [&](int cc, int s, int nc, int ns, auto nvm_tag) __attribute__((always_inline)) {
+    constexpr int NVM = decltype(nvm_tag)::value;
+    // four-offset waves (192 accumulators) have no registers to hold the next group's rows across the fragment reads:
+    // they read them AFTER their MFMAs (one more LDS round trip per step)
+    constexpr bool FUSE = NW <= 3;
+    // (1) kernel-map rows of the next group
+    const unsigned rd = idx_rd + (unsigned)((nc & 1) * IDXB + (16 * ns + g_row) * 4);
+    int32_t r[NW];
+    if constexpr (FUSE) {
+#pragma unroll
+      for (int o = 0; o < NW; ++o) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r[o]) : "v"(rd), "n"(o * 512) : "memory");
+    }
+    // (2) fragments of this group
+    LGS_VMCNT(NVM);
+    const uint32_t m = (actbits >> (4 * cslot)) & 0xfu;
+    u32x2 fbr[NCS][2], far_[NW][2];
+    constexpr int NA0 = NW <= 3 ? NW : 1;              // A tiles read with the B fragments (all of them when registers allow)
+    if (m != 0) {                                      // wave-uniform
+      const unsigned sb = s_tr + (unsigned)((cc & 1) * (CH * SGB) + 16 * s * SGB);
+      const unsigned ab = a_tr + (unsigned)(cslot * (NW * 1024));
+#pragma unroll
+      for (int b = 0; b < NCS; ++b) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(fbr[b][0]) : "v"(sb), "n"(64 * b) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(fbr[b][1]) : "v"(sb), "n"(64 * b + 4 * SGB) : "memory");
+      }
+#pragma unroll
+      for (int o = 0; o < NA0; ++o) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(far_[o][0]) : "v"(ab), "n"(o * 1024) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(far_[o][1]) : "v"(ab), "n"(o * 1024 + 256) : "memory");
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (FUSE) {
+#pragma unroll
+      for (int o = 0; o < NW; ++o) asm volatile("" : "+v"(r[o]));
+    }
+    if (m != 0) {
+#pragma unroll
+      for (int b = 0; b < NCS; ++b) { asm volatile("" : "+v"(fbr[b][0])); asm volatile("" : "+v"(fbr[b][1])); }
+#pragma unroll
+      for (int o = 0; o < NA0; ++o) { asm volatile("" : "+v"(far_[o][0])); asm volatile("" : "+v"(far_[o][1])); }
+    }
+    // (3) DMA of the next group
+    auto issue_next = [&]() __attribute__((always_inline)) {
+      uint32_t mm = 0;
+      char *dst = Aring + islot * (NW * 1024);
+#pragma unroll
+      for (int o = 0; o < NW; ++o) {
+        // a tile without any neighbour is still "fetched" (every lane out of range: zeros, no memory traffic): the DMA
+        // stream stays static and every wait is a compile-time vmcnt.  Skipping such tiles with a run-time vmcnt (scalar
+        // switch over the count) was built and measured SLOWER (L0 96->96: 0.67 vs 0.63 ms).
+        const bool ok = nc < c_end && r[o] >= 0;
+        if (__ballot(ok) != 0ull) mm |= 1u << o;
+        const unsigned off = (ok && g_ch != kOOB) ? (unsigned)r[o] * g_row_b + g_ch : kOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, LGS_AS3(dst + o * 1024), 16, off, 0, 0, 0);
+      }
+      actbits = (actbits & ~(0xfu << (4 * islot))) | (mm << (4 * islot));
+      islot = islot == 2 ? 0 : islot + 1;
+    };
+    if constexpr (FUSE) issue_next();
+    // (4) MFMAs of this group
+    if (m != 0) {
+      const unsigned ab = a_tr + (unsigned)(cslot * (NW * 1024));
+      bf16x8 fb[NCS];
+#pragma unroll
+      for (int b = 0; b < NCS; ++b) {
+        u32x4 pk; pk.x = fbr[b][0].x; pk.y = fbr[b][0].y; pk.z = fbr[b][1].x; pk.w = fbr[b][1].y;
+        fb[b] = __builtin_bit_cast(bf16x8, pk);
+      }
+#pragma unroll
+      for (int o = 0; o < NW; ++o) {
+        // four-offset waves: tile o+1 is requested in front of the MFMAs of tile o (two A fragments live at most)
+        if constexpr (NA0 < NW) {
+          if (o + 1 >= NA0 && o + 1 < NW) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(far_[o + 1 < NW ? o + 1 : 0][0]) : "v"(ab), "n"((o + 1) * 1024) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(far_[o + 1 < NW ? o + 1 : 0][1]) : "v"(ab), "n"((o + 1) * 1024 + 256) : "memory");
+          }
+        }
+        if ((m >> o) & 1u) {                            // wave-uniform
+          u32x4 pk; pk.x = far_[o][0].x; pk.y = far_[o][0].y; pk.z = far_[o][1].x; pk.w = far_[o][1].y;
+          const bf16x8 fa = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+          for (int b = 0; b < NCS; ++b) acc[o][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[b], acc[o][b], 0, 0, 0);
+        }
+        if constexpr (NA0 < NW) {
+          if (o + 1 >= NA0 && o + 1 < NW) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(far_[o + 1 < NW ? o + 1 : 0][0])); asm volatile("" : "+v"(far_[o + 1 < NW ? o + 1 : 0][1]));
+          }
+        }
+      }
+    }
+    if constexpr (!FUSE) {
+#pragma unroll
+      for (int o = 0; o < NW; ++o) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r[o]) : "v"(rd), "n"(o * 512) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int o = 0; o < NW; ++o) asm volatile("" : "+v"(r[o]));
+      issue_next();
+    }
+    cslot = cslot == 2 ? 0 : cslot + 1;
+  };
+  // prologue form: issue a gather group without consuming anything
+  auto issue_gather = [&](int cc, int s) __attribute__((always_inline)) {
     const unsigned rd = idx_rd + (unsigned)((cc & 1) * IDXB + (16 * s + g_row) * 4);
     int32_t r[NW];
 #pragma unroll
@@ -572,53 +681,6 @@ __device__ __forceinline__ void ps_wave(const PsArgs &a, char *smem, const int w
     actbits = (actbits & ~(0xfu << (4 * islot))) | (m << (4 * islot));
     islot = islot == 2 ? 0 : islot + 1;
   };
-  // ---- consume side: group s of chunk cc sits in ring slot cslot
-  int cslot = 0;
-  auto consume = [&](int cc, int s) __attribute__((always_inline)) {
-    const uint32_t m = (actbits >> (4 * cslot)) & 0xfu;
-    if (m != 0) {                                       // wave-uniform
-      // stationary fragments (B) + the first gathered tile (A); the next tile's reads are issued in front of the MFMAs of
-      // the current one (at most two A fragments are live: the accumulators leave ~60 registers for everything else)
-      u32x2 fbr[NCS][2], far_[NW][2];
-      const unsigned sb = s_tr + (unsigned)((cc & 1) * (CH * SGB) + 16 * s * SGB);
-      const unsigned ab = a_tr + (unsigned)(cslot * (NW * 1024));
-#pragma unroll
-      for (int b = 0; b < NCS; ++b) {
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(fbr[b][0]) : "v"(sb), "n"(64 * b) : "memory");
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(fbr[b][1]) : "v"(sb), "n"(64 * b + 4 * SGB) : "memory");
-      }
-      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=&v"(far_[0][0]) : "v"(ab) : "memory");
-      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=&v"(far_[0][1]) : "v"(ab) : "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int b = 0; b < NCS; ++b) { asm volatile("" : "+v"(fbr[b][0])); asm volatile("" : "+v"(fbr[b][1])); }
-      asm volatile("" : "+v"(far_[0][0])); asm volatile("" : "+v"(far_[0][1]));
-      bf16x8 fb[NCS];
-#pragma unroll
-      for (int b = 0; b < NCS; ++b) {
-        u32x4 pk; pk.x = fbr[b][0].x; pk.y = fbr[b][0].y; pk.z = fbr[b][1].x; pk.w = fbr[b][1].y;
-        fb[b] = __builtin_bit_cast(bf16x8, pk);
-      }
-#pragma unroll
-      for (int o = 0; o < NW; ++o) {
-        if (o + 1 < NW) {
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(far_[o + 1 < NW ? o + 1 : 0][0]) : "v"(ab), "n"((o + 1) * 1024) : "memory");
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(far_[o + 1 < NW ? o + 1 : 0][1]) : "v"(ab), "n"((o + 1) * 1024 + 256) : "memory");
-        }
-        if ((m >> o) & 1u) {                            // wave-uniform
-          u32x4 pk; pk.x = far_[o][0].x; pk.y = far_[o][0].y; pk.z = far_[o][1].x; pk.w = far_[o][1].y;
-          const bf16x8 fa = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-          for (int b = 0; b < NCS; ++b) acc[o][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[b], acc[o][b], 0, 0, 0);
-        }
-        if (o + 1 < NW) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          asm volatile("" : "+v"(far_[o + 1 < NW ? o + 1 : 0][0])); asm volatile("" : "+v"(far_[o + 1 < NW ? o + 1 : 0][1]));
-        }
-      }
-    }
-    cslot = cslot == 2 ? 0 : cslot + 1;
-  };
   auto barrier = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
@@ -635,27 +697,21 @@ __device__ __forceinline__ void ps_wave(const PsArgs &a, char *smem, const int w
 
   for (int cc = c_begin; cc < c_end; ++cc) {
     // program order of the DMA stream:  ... G(cc,0) G(cc,1) | ST(cc+1) G(cc,2) .. G(cc,7) IX(cc+2) G(cc+1,0) G(cc+1,1) | ...
+    // issue_stage(cc+1) reads the output rows of chunk cc+1 that IX(cc+1) fetched: IX(cc+1) was issued in the previous
+    // iteration with only G(cc,0), G(cc,1) behind it, so "at most 2 NW outstanding" means it has landed
+    LGS_VMCNT(2 * NW);
     issue_stage(cc + 1);
-    issue_gather(cc, 2);
-    LGS_VMCNT(2 * NW + NST);   // group 0 landed; behind it: G1, ST, G2
-    consume(cc, 0);
-    issue_gather(cc, 3);
-    LGS_VMCNT(2 * NW);         // group 1 (and the stationary rows issued before G2) landed; behind it: G2, G3
-    consume(cc, 1);
-#pragma unroll
-    for (int s = 2; s < 6; ++s) {
-      issue_gather(cc, s + 2);
-      LGS_VMCNT(2 * NW);
-      consume(cc, s);
-    }
-    issue_index(cc + 2);       // buffer cc % 2: its last reader was issue_gather(cc, 7)
-    issue_gather(cc + 1, 0);
-    LGS_VMCNT(2 * NW + NIX);   // group 6 landed; behind it: G7, IX, G(cc+1,0)
-    consume(cc, 6);
-    issue_gather(cc + 1, 1);
-    LGS_VMCNT(2 * NW + NIX);   // group 7 landed; behind it: IX, G(cc+1,0), G(cc+1,1)
-    consume(cc, 7);
-    barrier();                 // stationary tile of chunk cc+1 complete (landed before group 1's wait); this one is free
+    // step(cc, s, next group, N): N = DMA instructions behind group (cc, s) at its wait (the next group is issued after it)
+    step(cc, 0, cc, 2, std::integral_constant<int, NW + NST>());      // behind G0: G1, ST
+    step(cc, 1, cc, 3, std::integral_constant<int, NST + NW>());      // behind G1: ST, G2   (ST lands before G2: covered)
+    step(cc, 2, cc, 4, std::integral_constant<int, NW>());            // behind Gs: G(s+1)
+    step(cc, 3, cc, 5, std::integral_constant<int, NW>());
+    step(cc, 4, cc, 6, std::integral_constant<int, NW>());
+    step(cc, 5, cc, 7, std::integral_constant<int, NW>());
+    issue_index(cc + 2);       // buffer cc % 2: its last reader was the step that issued G(cc,7)
+    step(cc, 6, cc + 1, 0, std::integral_constant<int, NW + NIX>());  // behind G6: G7, IX
+    step(cc, 7, cc + 1, 1, std::integral_constant<int, NIX + NW>());  // behind G7: IX, G(cc+1,0)
+    barrier();                 // stationary tile of chunk cc+1 complete (landed before group 2's wait); this one is free
   }
   LGS_VMCNT(0);
 

@@ -256,10 +256,11 @@ class _SyncBNFused(torch.autograd.Function):
     combination -> fused normalise(+residual)(+ReLU); backward: local sums -> ONE all_reduce of 2C floats."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, nbt, eps, momentum, relu, group, backend):
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, nbt, eps, momentum, relu, group, backend, conv_stats=None):
         c = x.shape[1]
         world = dist.get_world_size(group)
-        local = backend.bn_stats(x)                                    # [mean | M2 | count], 2 kernels
+        # [mean | M2 | count], 2 kernels; the partial sums come from the producing conv's epilogue when it made them
+        local = backend.bn_stats(x, conv_stats) if conv_stats is not None else backend.bn_stats(x)
         allst = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=x.device)
         if dist.get_backend(group) == "nccl":
             dist.all_gather_into_tensor(allst, local, group=group)
@@ -297,11 +298,11 @@ class _SyncBNFused(torch.autograd.Function):
         dx, dres = ctx.backend.bn_backward_apply(x, yy, dy, weight, bias, stats, sums, inv_n, ctx.relu_mode,
                                                  ctx.has_res and ctx.needs_input_grad[3])
         if gview is not None:
-            return dx, gview, bview, dres, None, None, None, None, None, None, None, None
-        return dx, dgamma.to(weight.dtype), dbeta.to(weight.dtype), dres, None, None, None, None, None, None, None, None
+            return dx, gview, bview, dres, None, None, None, None, None, None, None, None, None
+        return dx, dgamma.to(weight.dtype), dbeta.to(weight.dtype), dres, None, None, None, None, None, None, None, None, None
 
 
-def sync_batch_norm(x, bn, group=None, residual=None, relu=False):
+def sync_batch_norm(x, bn, group=None, residual=None, relu=False, conv_stats=None):
     """Batch statistics over the rows of all ranks.  Device tensors run on the engine's fused kernels; the pure
     torch formulation below is only reachable with CPU tensors (the gloo host-logic tests)."""
     rm = bn.running_mean if bn.track_running_stats else None
@@ -309,7 +310,9 @@ def sync_batch_norm(x, bn, group=None, residual=None, relu=False):
     nbt = bn.num_batches_tracked if bn.track_running_stats else None
     if x.is_cuda:
         from .me.core import get_backend
-        return _SyncBNFused.apply(x, bn.weight, bn.bias, residual, rm, rv, nbt, bn.eps, bn.momentum, relu, group, get_backend())
+        if conv_stats is not None and (conv_stats[1] is not None) != (rm is not None):
+            conv_stats = None
+        return _SyncBNFused.apply(x, bn.weight, bn.bias, residual, rm, rv, nbt, bn.eps, bn.momentum, relu, group, get_backend(), conv_stats)
     if nbt is not None:
         nbt += 1
     y = _SyncBNFunction.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, group)

@@ -19,7 +19,7 @@ EXPORTS = [
     "lgs_manager_create", "lgs_manager_destroy", "lgs_manager_insert", "lgs_manager_stride2",
     "lgs_manager_parent_of", "lgs_manager_map_size", "lgs_manager_get_coords", "lgs_manager_kernel_map",
     "lgs_kmap_export",
-    "lgs_conv_workspace_bytes", "lgs_conv_forward", "lgs_conv_dgrad", "lgs_conv_wgrad",
+    "lgs_conv_workspace_bytes", "lgs_conv_bn_partial_rows", "lgs_conv_forward", "lgs_conv_dgrad", "lgs_conv_wgrad",
     "lgs_bn_workspace_bytes", "lgs_bn_forward", "lgs_bn_backward",
     "lgs_bn_stats", "lgs_bn_sync_combine", "lgs_bn_apply", "lgs_bn_backward_reduce", "lgs_bn_backward_apply",
     "lgs_clip_similarity", "lgs_clip_workspace_bytes",
@@ -61,16 +61,17 @@ def lib():
         "lgs_manager_get_coords": [vp, ci, vp, vp],
         "lgs_manager_kernel_map": [vp, ci, ci, ci, vp, pvp],
         "lgs_kmap_export": [vp, vp, vp, vp, vp, pi64],
-        "lgs_conv_forward": [vp, ci, vp, ci, vp, ci, vp, vp, ci, vp, vp],
+        "lgs_conv_forward": [vp, ci, vp, ci, vp, ci, vp, vp, ci, vp, vp, vp, vp],
+        "lgs_conv_bn_partial_rows": [vp, ci, ci, ci],
         "lgs_conv_dgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp],
         "lgs_sgd_step": [vp, vp, vp, vp, i64, cf, cf, cf, cf, ci, vp],
         "lgs_cluster": [vp, vp, vp, i64, cf, ci, vp, ctypes.POINTER(ctypes.c_int32), vp, vp],
         "lgs_voxelize": [vp, i64, ctypes.POINTER(ctypes.c_double), ci, vp, vp],
         "lgs_label_vote": [vp, i64, vp, vp, i64, i64, vp, vp],
         "lgs_conv_wgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp],
-        "lgs_bn_forward": [vp, i64, ci, vp, vp, cf, cf, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp],
+        "lgs_bn_forward": [vp, i64, ci, vp, vp, cf, cf, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, vp, vp],
         "lgs_bn_backward": [vp, vp, vp, i64, i64, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp],
-        "lgs_bn_stats": [vp, i64, ci, vp, ci, vp, vp],
+        "lgs_bn_stats": [vp, i64, ci, vp, ci, vp, vp, ci, vp, vp],
         "lgs_bn_apply": [vp, i64, ci, vp, vp, vp, vp, ci, vp, ci, vp],
         "lgs_bn_backward_reduce": [vp, vp, vp, i64, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp],
         "lgs_bn_sync_combine": [vp, ci, ci, cf, cf, vp, vp, vp, vp, vp, vp],
@@ -94,7 +95,7 @@ def lib():
     L.lgs_clip_workspace_bytes.argtypes = [ci, ci, ci]
     L.lgs_clip_loss_workspace_bytes.restype = i64
     L.lgs_clip_loss_workspace_bytes.argtypes = [ci, ci, ci]
-    if L.lgs_abi_version() != 1:
+    if L.lgs_abi_version() != 2:
         raise RuntimeError("liblgs_engine.so ABI version mismatch")
     _lib = L
     return L

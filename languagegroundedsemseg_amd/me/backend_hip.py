@@ -5,6 +5,7 @@ enqueues on torch's current HIP stream.  There is no fallback: a CPU tensor or a
 raises RuntimeError.
 """
 import ctypes
+import os
 
 import torch
 
@@ -62,7 +63,9 @@ class HipKernelMap:
         n_out = self.mgr.map_size(self.out_key)
         return (n_out, n_in) if transposed else (n_in, n_out)
 
-    def conv_forward(self, x, weight, bias, transposed):
+    def conv_forward(self, x, weight, bias, transposed, bn_pivot=None, want_bn_stats=False):
+        """want_bn_stats: also return the per-tile BatchNorm statistics of the output (None if this launch shape cannot
+        produce them) -> (out, (partials [rows, 2, cout], pivot) | None)"""
         _require_dev(x, "features")
         L = engine.lib()
         x = x.contiguous()
@@ -71,12 +74,20 @@ class HipKernelMap:
         n_in, n_out = self._rows(transposed)
         assert x.shape[0] == n_in and x.shape[1] == cin, (x.shape, n_in, cin)
         dt = _dtype_code(x)
+        part = None
         with torch.cuda.device(x.device):
             out = torch.empty((n_out, cout), dtype=x.dtype, device=x.device)
             ws = _ws(L.lgs_conv_workspace_bytes(self.h, cin, cout, dt, 0), x.device)
             b = bias.detach().reshape(-1).contiguous().float() if bias is not None else None
+            if want_bn_stats:
+                rows = L.lgs_conv_bn_partial_rows(self.h, int(transposed), cout, dt)
+                if rows > 0:
+                    part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+            piv = bn_pivot if part is not None else None
             engine.check(L.lgs_conv_forward(self.h, int(transposed), _ptr(x), cin, _ptr(w), cout, _ptr(b), _ptr(out), dt,
-                                            _ptr(ws), _stream()))
+                                            _ptr(ws), _ptr(part), _ptr(piv), _stream()))
+        if want_bn_stats:
+            return out, ((part, piv) if part is not None else None)
         return out
 
     def conv_dgrad(self, gout, weight, transposed):
@@ -191,6 +202,8 @@ class HipManager:
 class HipBackend:
     name = "hip"
     bn_counts_batches = True    # lgs_bn_forward increments num_batches_tracked itself
+    # lgs_conv_forward can emit the following BatchNorm's statistics from its epilogue -- measured SLOWER in the step (31.5 vs 30.9 ms: the epilogue work on every conv costs more than the skipped column reduction saves), so off unless LGS_CONV_BN_STATS=1
+    conv_bn_stats = os.environ.get("LGS_CONV_BN_STATS") == "1"
 
     def __init__(self):
         self._side = {}
@@ -206,12 +219,15 @@ class HipBackend:
         return self._side[key]
 
     # ---- fused BN(+residual)(+ReLU): lgs_bn_forward / lgs_bn_backward
-    def bn_forward(self, x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, num_batches_tracked=None):
+    def bn_forward(self, x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, num_batches_tracked=None,
+                   conv_stats=None):
+        """conv_stats = (partials, pivot) from conv_forward(want_bn_stats=True): the statistics pass over x is skipped"""
         _require_dev(x, "features")
         L = engine.lib()
         x = x.contiguous()
         n, c = x.shape
         dt = _dtype_code(x)
+        part, piv = conv_stats if conv_stats is not None else (None, None)
         with torch.cuda.device(x.device):
             y = torch.empty_like(x)
             stats = torch.empty(2 * c, dtype=torch.float32, device=x.device)
@@ -219,7 +235,8 @@ class HipBackend:
             ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
             engine.check(L.lgs_bn_forward(_ptr(x), n, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
                                           _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(res), int(relu), _ptr(y),
-                                          _ptr(stats), dt, _ptr(ws), _stream()))
+                                          _ptr(stats), dt, _ptr(ws), _ptr(part), int(part.shape[0]) if part is not None else 0,
+                                          _ptr(piv), _stream()))
         return y, stats
 
     def bn_backward(self, x, y, dy, gamma, beta, stats, relu, want_residual, dgamma_out=None, dbeta_out=None):
@@ -246,15 +263,17 @@ class HipBackend:
         return dx, dres, dgamma, dbeta
 
     # ---- the same op in halves (SyncBN: statistics are exchanged between ranks in the middle)
-    def bn_stats(self, x):
+    def bn_stats(self, x, conv_stats=None):
         """-> float32 [2C+1]: local mean, local M2, row count (the record one rank contributes to SyncBN's all-gather)"""
         L = engine.lib()
         x = x.contiguous()
         n, c = x.shape
+        part, piv = conv_stats if conv_stats is not None else (None, None)
         with torch.cuda.device(x.device):
             out = torch.empty(2 * c + 1, dtype=torch.float32, device=x.device)
             ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
-            engine.check(L.lgs_bn_stats(_ptr(x), n, c, _ptr(out), _dtype_code(x), _ptr(ws), _stream()))
+            engine.check(L.lgs_bn_stats(_ptr(x), n, c, _ptr(out), _dtype_code(x), _ptr(ws), _ptr(part),
+                                        int(part.shape[0]) if part is not None else 0, _ptr(piv), _stream()))
         return out
 
     def bn_sync_combine(self, all_stats, c, eps, momentum, running_mean, running_var, num_batches_tracked):

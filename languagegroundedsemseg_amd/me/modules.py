@@ -48,11 +48,16 @@ class MinkowskiConvolutionFunction(torch.autograd.Function):
     them concurrently fills the machine."""
 
     @staticmethod
-    def forward(ctx, feats, kernel, bias, kmap, transposed):
+    def forward(ctx, feats, kernel, bias, kmap, transposed, bn_pivot=None, want_bn_stats=False):
         ctx.kmap, ctx.transposed, ctx.has_bias = kmap, transposed, bias is not None
         ctx.kshape = kernel.shape
         ctx.kparam = kernel if isinstance(kernel, torch.nn.Parameter) else None
         ctx.save_for_backward(feats, kernel)
+        if want_bn_stats:
+            # the conv epilogue also emits per-tile sum / sum-of-squares of its output for the BatchNorm that follows
+            out, stats = kmap.conv_forward(feats, kernel, bias, transposed, bn_pivot=bn_pivot, want_bn_stats=True)
+            ctx.bn_stats = stats                 # picked up by MinkowskiConvolutionBase.forward (not a graph output)
+            return out
         return kmap.conv_forward(feats, kernel, bias, transposed)
 
     @staticmethod
@@ -78,10 +83,34 @@ class MinkowskiConvolutionFunction(torch.autograd.Function):
             gin = ctx.kmap.conv_dgrad(gout, kernel, ctx.transposed)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gout.sum(0, keepdim=True, dtype=torch.float32)   # fp32 accumulation without an fp32 copy of gout
-        return gin, gw, gb, None, None
+        return gin, gw, gb, None, None, None, None
 
 
 MinkowskiConvolutionTransposeFunction = MinkowskiConvolutionFunction
+
+
+class _StatsHolder:
+    stats = None
+
+
+class _ConvStatsFunction(MinkowskiConvolutionFunction):
+    """MinkowskiConvolutionFunction whose forward also asks the kernel for the next norm's statistics (side output)."""
+
+    @staticmethod
+    def forward(ctx, feats, kernel, kmap, transposed, bn_pivot, holder):
+        out = MinkowskiConvolutionFunction.forward(ctx, feats, kernel, None, kmap, transposed, bn_pivot, True)
+        holder.stats = ctx.bn_stats
+        ctx.bn_stats = None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        gin, gw, _gb, _a, _b, _c, _d = MinkowskiConvolutionFunction.backward(ctx, gout)
+        return gin, gw, None, None, None, None
+
+
+def _conv_with_stats(feats, kernel, kmap, transposed, pivot, holder):
+    return _ConvStatsFunction.apply(feats, kernel, kmap, transposed, pivot, holder)
 
 
 class MinkowskiConvolutionBase(MinkowskiModuleBase):
@@ -128,7 +157,10 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
             if self.bias is not None:
                 self.bias.data.uniform_(-stdv, stdv)
 
-    def forward(self, input, coordinates=None):
+    def forward(self, input, coordinates=None, bn=None):
+        """`bn` (extension used by the build's own models): the MinkowskiBatchNorm this output goes to next.  In training
+        the conv epilogue then also produces that norm's batch statistics (pivoted on its running mean) and hands them
+        over on the output tensor, so the norm does not read the [N, C] tensor a second time for them."""
         assert isinstance(input, SparseTensor)
         assert input.F.shape[1] == self.in_channels, "Channel size mismatch %d != %d" % (input.F.shape[1], self.in_channels)
         mgr = input.coordinate_manager
@@ -143,6 +175,15 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
             # the transposed conv reuses the forward map of the matching strided conv, in/out swapped
             kmap = mgr.kernel_map_handle(out_key, in_key, ks)
             transposed = True
+        want = (bn is not None and bn.bn.training and bn.bn.affine and input.F.is_cuda and self.bias is None
+                and getattr(get_backend(), "conv_bn_stats", False))
+        if want:
+            pivot = bn.bn.running_mean if bn.bn.track_running_stats else None
+            holder = _StatsHolder()
+            out = _conv_with_stats(input.F, self.kernel, kmap, transposed, pivot, holder)
+            st = SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
+            st._bn_stats = holder.stats            # (partials, pivot) or None
+            return st
         out = MinkowskiConvolutionFunction.apply(input.F, self.kernel, self.bias, kmap, transposed)
         return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
 
@@ -172,10 +213,13 @@ class FusedBatchNormFunction(torch.autograd.Function):
     """y = relu?(BN(x) (+ residual)) with batch statistics, one engine call each way."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, backend, nbt=None):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, backend, nbt=None, conv_stats=None):
         ctx.gparam = gamma if isinstance(gamma, torch.nn.Parameter) else None
         ctx.bparam = beta if isinstance(beta, torch.nn.Parameter) else None
-        if nbt is not None:
+        if conv_stats is not None:
+            y, stats = backend.bn_forward(x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, nbt,
+                                          conv_stats=conv_stats)
+        elif nbt is not None:
             y, stats = backend.bn_forward(x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, nbt)
         else:
             y, stats = backend.bn_forward(x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu)
@@ -201,8 +245,8 @@ class FusedBatchNormFunction(torch.autograd.Function):
         dx, dres, dgamma, dbeta = ctx.backend.bn_backward(x, y, dy, gamma, beta, stats, ctx.relu_mode,
                                                           ctx.has_res and ctx.needs_input_grad[3], gview, bview)
         if gview is not None:
-            return dx, gview, bview, dres, None, None, None, None, None, None, None
-        return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), dres, None, None, None, None, None, None, None
+            return dx, gview, bview, dres, None, None, None, None, None, None, None, None
+        return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), dres, None, None, None, None, None, None, None, None
 
 
 class MinkowskiBatchNorm(nn.Module):
@@ -228,7 +272,10 @@ class MinkowskiBatchNorm(nn.Module):
             if nbt is not None and not getattr(backend, "bn_counts_batches", False):
                 nbt += 1
                 nbt = None                                 # (the HIP engine increments it inside the fold kernel)
-            y = FusedBatchNormFunction.apply(x, bn.weight, bn.bias, res, rm, rv, bn.eps, bn.momentum, relu, backend, nbt)
+            cs = getattr(input, "_bn_stats", None)
+            if cs is not None and (cs[1] is not None) != (rm is not None):
+                cs = None                                  # pivot convention mismatch (cannot happen for the conv's own bn)
+            y = FusedBatchNormFunction.apply(x, bn.weight, bn.bias, res, rm, rv, bn.eps, bn.momentum, relu, backend, nbt, cs)
         else:
             y = bn(x.float()).to(x.dtype) if x.dtype != torch.float32 else bn(x)
             if res is not None:
@@ -261,7 +308,7 @@ class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
             return super().forward(input, relu=relu, residual=residual)
         from ..ddp import sync_batch_norm
         res = residual.F if isinstance(residual, SparseTensor) else residual
-        y = sync_batch_norm(input.F, self.bn, self.process_group, residual=res, relu=relu)
+        y = sync_batch_norm(input.F, self.bn, self.process_group, residual=res, relu=relu, conv_stats=getattr(input, "_bn_stats", None))
         return SparseTensor(y, coordinate_map_key=input.coordinate_map_key, coordinate_manager=input.coordinate_manager)
 
     @classmethod

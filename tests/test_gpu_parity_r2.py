@@ -326,3 +326,44 @@ def test_cross_entropy_class_counts_off_the_16_byte_grid(classes, dtype, tol):
     (lt * 2.0).backward()
     assert abs(float(loss) - float(lt)) < 1e-4
     assert rel_l2(xh.grad.float().cpu().numpy(), xt.grad.numpy()) < tol
+
+
+# ------------------------------------------------------------------------------------------- BN statistics from the conv epilogue
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_epilogue_batchnorm_statistics_equal_the_column_reduction(dtype):
+    """lgs_conv_forward(bn_partial) + lgs_bn_forward(conv_partials) == lgs_bn_forward reading the output itself: same
+    mean / invstd / running statistics / normalised output, on 3^3 (big map: plain launch; small map: slot split -> no
+    partials), strided 2^3 and transposed 2^3 (grouped view with padding groups) convolutions"""
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    be = ME.get_backend()
+    coords, _, _ = make_batch([3], voxel=0.02, n_target=70000)
+    c = torch.from_numpy(coords).to(DEV)
+    x0 = ME.SparseTensor(torch.zeros(coords.shape[0], 3, device=DEV), c)
+    m, k0 = x0.coordinate_manager, x0.coordinate_map_key
+    k1 = m.stride(k0, 2)
+    k2 = m.stride(k1, 2)
+    k3 = m.stride(k2, 2)
+    cases = [(m.kernel_map_handle(k0, k0, 3), False, m.size(k0), 32, 96, True),
+             (m.kernel_map_handle(k0, k0, 3), False, m.size(k0), 64, 32, True),
+             (m.kernel_map_handle(k0, k0, 3), False, m.size(k0), 128, 128, True),
+             (m.kernel_map_handle(k0, k1, 2), False, m.size(k0), 32, 64, True),
+             (m.kernel_map_handle(k0, k1, 2), True, m.size(k1), 64, 96, True),
+             (m.kernel_map_handle(k0, k0, 1), False, m.size(k0), 128, 96, True),
+             (m.kernel_map_handle(k3, k3, 3), False, m.size(k3), 128, 128, dtype == torch.float32)]   # bf16: slot split, no partials
+    torch.manual_seed(0)
+    for km, tr, n_in, cin, cout, expect in cases:
+        f = (torch.randn(n_in, cin, device=DEV) + 0.3).to(dtype)
+        w = torch.randn(km.K, cin, cout, device=DEV) * (1.0 / (cin * km.K) ** 0.5)
+        pivot = torch.randn(cout, device=DEV) * 0.05
+        out, cs = km.conv_forward(f, w, None, tr, bn_pivot=pivot, want_bn_stats=True)
+        assert (cs is not None) == expect, (km.K, tr, cin, cout)
+        if cs is None:
+            continue
+        assert torch.equal(out, km.conv_forward(f, w, None, tr))       # the extra epilogue does not touch the output
+        g, b = torch.rand(cout, device=DEV) + 0.5, torch.randn(cout, device=DEV) * 0.1
+        rm1, rv1, rm2, rv2 = pivot.clone(), torch.ones(cout, device=DEV), pivot.clone(), torch.ones(cout, device=DEV)
+        y1, s1 = be.bn_forward(out, g, b, 1e-5, 0.1, rm1, rv1, None, 1)
+        y2, s2 = be.bn_forward(out, g, b, 1e-5, 0.1, rm2, rv2, None, 1, None, conv_stats=(cs[0], rm2))
+        assert torch.allclose(s1, s2, rtol=2e-5, atol=1e-6), (km.K, tr, cin, cout, float((s1 - s2).abs().max()))
+        assert torch.allclose(rm1, rm2, atol=1e-6) and torch.allclose(rv1, rv2, rtol=1e-5, atol=1e-7)
+        assert float((y1.float() - y2.float()).abs().max()) <= (1e-4 if dtype == torch.float32 else 4e-2)

@@ -222,12 +222,16 @@ def wgrad():
     for lvl in range(4):
         keys.append(m.stride(keys[-1], 2))
     # (level, kernel, cin, cout, transposed, count per step)
+    if os.environ.get("LGS_WGRAD_DBG"):
+        shapes_sel = [(0, 3, 96, 96, 0, 3), (0, 3, 128, 96, 0, 1), (1, 3, 96, 96, 0, 3)]
     shapes = [(0, 3, 3, 32, 0, 1), (0, 3, 128, 96, 0, 1), (0, 3, 96, 96, 0, 3), (0, 2, 32, 32, 0, 1), (0, 2, 96, 96, 1, 1),
               (1, 3, 32, 32, 0, 4), (1, 3, 128, 96, 0, 1), (1, 3, 96, 96, 0, 3), (1, 2, 32, 32, 0, 1), (1, 2, 128, 96, 1, 1),
               (2, 3, 32, 64, 0, 1), (2, 3, 64, 64, 0, 5), (2, 3, 192, 128, 0, 1), (2, 3, 128, 128, 0, 3), (2, 2, 64, 64, 0, 1), (2, 2, 256, 128, 1, 1),
               (3, 3, 64, 128, 0, 1), (3, 3, 128, 128, 0, 7), (3, 3, 384, 256, 0, 1), (3, 3, 256, 256, 0, 3), (3, 2, 128, 128, 0, 1), (3, 2, 256, 256, 1, 1),
               (4, 3, 128, 256, 0, 1), (4, 3, 256, 256, 0, 11)]
     tot = 0.0
+    if os.environ.get("LGS_WGRAD_DBG"):
+        shapes = shapes_sel
     for lvl, ks, cin, cout, tr, cnt in shapes:
         if ks == 3:
             km = m.kernel_map_handle(keys[lvl], keys[lvl], 3)

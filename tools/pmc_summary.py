@@ -6,6 +6,7 @@ for f in sorted(glob.glob(sys.argv[1] + '/*/p_counter_collection.csv')):
         k = r['Kernel_Name']
         if 'k_conv_gather' in k: kk = 'k_conv_gather (L0 3^3 96->96 bf16 forward, per launch)'
         elif 'k_wgrad_bf16' in k: kk = 'k_wgrad_bf16<3,3> (L0 3^3 96->96, per launch)'
+        elif 'k_wgrad_ps' in k: kk = 'k_wgrad_ps<27,3> (L0 3^3 96->96, per launch)'
         else: continue
         res[kk][r['Counter_Name']].append(float(r['Counter_Value']))
 for kk, d in res.items():
