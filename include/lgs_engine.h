@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LGS_ABI_VERSION 2
+#define LGS_ABI_VERSION 3
 
 enum lgs_dtype { LGS_F32 = 0, LGS_BF16 = 1 };
 
@@ -105,6 +105,24 @@ int lgs_kmap_export(lgs_kmap *km, int32_t *k, int32_t *in_row, int32_t *out_row,
  * op's input/output channels.  `workspace` must hold lgs_conv_workspace_bytes(...) bytes. */
 int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype, int op /*0 fwd,1 dgrad,2 wgrad*/);
 
+/* Packed weight images.  The conv kernels read the weights in MFMA fragment order (bf16 / fp32, padded to the tile
+ * configuration of the launch shape); by default every call re-packs the fp32 [K,Cin,Cout] parameter into its workspace
+ * (~6 us, 125 launches per Res16UNet34C step).  A caller that keeps the image across calls asks lgs_conv_pack_desc for
+ * its layout (bytes == 0: this shape packs internally only), owns a device buffer of `bytes`, and passes it as `packed`:
+ *   pack_mode 1 = pack into it now, then run;  2 = it is up to date, run straight away;  (packed == NULL: mode 0, internal).
+ * lgs_pack_weights_batch re-packs ANY number of images in one launch (descs_device = device copy of the descriptors
+ * with `weight` / `packed` filled in, max_total = largest `total`): the host wrapper runs it once after the optimiser
+ * step, so the convolutions of the next step find their images ready. */
+typedef struct lgs_pack_desc {
+  const float *weight; /* device float32 [K, cin_w, cout_w] */
+  void *packed;        /* device buffer of `bytes` */
+  int64_t bytes, total;
+  int K, cin_w, cout_w, transposed, mirror, g_real, o_real, ncp, nbp, dtype;
+} lgs_pack_desc;
+int lgs_conv_pack_desc(const lgs_kmap *km, int op /* 0 forward, 1 dgrad */, int transposed, int cin, int cout, int dtype,
+                       lgs_pack_desc *out);
+int lgs_pack_weights_batch(const lgs_pack_desc *descs_device, int n, int64_t max_total, void *stream);
+
 /* out[n_out,cout] = conv(in[n_in,cin]) (+ bias[cout] if non-NULL)
  * bn_partial (may be NULL): the BatchNorm that follows the conv in every block of the model family
  *   (/root/reference/models/modules/resnet_block.py:41-57: conv -> norm) needs sum / sum of squares of this output per
@@ -115,10 +133,10 @@ int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtyp
 int lgs_conv_bn_partial_rows(const lgs_kmap *km, int transposed, int cout, int dtype);
 int lgs_conv_forward(lgs_kmap *km, int transposed, const void *in, int cin, const float *weight, int cout,
                      const float *bias, void *out, int dtype, void *workspace, float *bn_partial, const float *bn_pivot,
-                     void *stream);
+                     void *packed, int pack_mode, void *stream);
 /* grad_in[n_in,cin] from grad_out[n_out,cout] */
 int lgs_conv_dgrad(lgs_kmap *km, int transposed, const void *grad_out, int cout, const float *weight, int cin,
-                   void *grad_in, int dtype, void *workspace, void *stream);
+                   void *grad_in, int dtype, void *workspace, void *packed, int pack_mode, void *stream);
 /* grad_weight[K,cin,cout] (float32, overwritten) */
 int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const void *grad_out, int cout,
                    float *grad_weight, int dtype, void *workspace, void *stream);

@@ -21,6 +21,7 @@
 #include "lgs_common.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 namespace lgs {
 
@@ -63,13 +64,9 @@ template <> __device__ inline void mma16<float>(f32x16 &acc, const u32x4 &w, con
 //   transposed : Wsrc[g][o] = w[ks][o][g],        ks = mirror ? K-1-kd : kd      (dgrad)
 // Out-of-range g / o are zero (channel padding to multiples of 32).
 template <typename T>
-__global__ void k_pack_weights(const float *__restrict__ w, int K, int cin_w, int cout_w, int transposed, int mirror,
-                               int g_real, int o_real, int nc /*padded chunks*/, int nb_total /*padded blocks*/,
-                               uint4 *__restrict__ dst) {
+__device__ inline uint4 pack_one(const float *__restrict__ w, int K, int cin_w, int cout_w, int transposed, int mirror, int g_real,
+                                 int o_real, int nc, int nb_total, int64_t idx) {
   constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t total = (int64_t)K * nc * nb_total * LD * 64;
-  if (idx >= total) return;
   int lane = (int)(idx & 63);
   int64_t r = idx >> 6;
   int t = (int)(r % LD); r /= LD;
@@ -97,7 +94,28 @@ __global__ void k_pack_weights(const float *__restrict__ w, int K, int cin_w, in
     out.z = (uint32_t)f32_to_bf16(vals[4]) | ((uint32_t)f32_to_bf16(vals[5]) << 16);
     out.w = (uint32_t)f32_to_bf16(vals[6]) | ((uint32_t)f32_to_bf16(vals[7]) << 16);
   }
-  dst[idx] = out;
+  return out;
+}
+
+template <typename T>
+__global__ void k_pack_weights(const float *__restrict__ w, int K, int cin_w, int cout_w, int transposed, int mirror,
+                               int g_real, int o_real, int nc /*padded chunks*/, int nb_total /*padded blocks*/,
+                               uint4 *__restrict__ dst) {
+  constexpr int LD = Tr<T>::LD;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)K * nc * nb_total * LD * 64;
+  if (idx >= total) return;
+  dst[idx] = pack_one<T>(w, K, cin_w, cout_w, transposed, mirror, g_real, o_real, nc, nb_total, idx);
+}
+
+// every cached packed image of the model in ONE launch (after the optimiser step): blockIdx.y = descriptor
+__global__ void k_pack_weights_batch(const lgs_pack_desc *__restrict__ descs) {
+  const lgs_pack_desc e = descs[blockIdx.y];
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= e.total) return;
+  uint4 *dst = reinterpret_cast<uint4 *>(e.packed);
+  if (e.dtype == LGS_BF16) dst[idx] = pack_one<bf16_t>(e.weight, e.K, e.cin_w, e.cout_w, e.transposed, e.mirror, e.g_real, e.o_real, e.ncp, e.nbp, idx);
+  else dst[idx] = pack_one<float>(e.weight, e.K, e.cin_w, e.cout_w, e.transposed, e.mirror, e.g_real, e.o_real, e.ncp, e.nbp, idx);
 }
 
 // pad rows [n, c] -> [n, cpad] (zero fill) for channel counts that are not a multiple of the load width
@@ -741,7 +759,7 @@ int bn_partial_rows_t(const View &v, int K, int o_real) {
 template <typename T>
 int conv_gather_op(const View &v, const void *in_v, int g_real, const float *weight, int K, int cin_w, int cout_w,
                    int transposed_w, int o_real, const float *bias, void *out_v, void *workspace, hipStream_t s,
-                   int w_o_real = -1, const BnEpi *bn = nullptr) {
+                   int w_o_real = -1, const BnEpi *bn = nullptr, void *packed_ext = nullptr, int pack_mode = 0) {
   if (w_o_real < 0) w_o_real = o_real;
   constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
   const int g_pad = pad32(g_real), nc = g_pad / 32, nb_total = pad32(o_real) / 32;
@@ -786,8 +804,12 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
     g_stride = g_al;
   }
   int64_t total = (int64_t)K * ncp * nbp * LD * 64;
-  hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, weight, K, cin_w, cout_w, transposed_w,
-                     v.mirror, g_real, w_o_real, ncp, nbp, wp);
+  // packed_ext: a caller-owned image of exactly this layout (lgs_conv_pack_desc); pack_mode 2 = it is up to date
+  if (packed_ext && o_real % 4 == 0 && g_real % EPL == 0) wp = reinterpret_cast<uint4 *>(packed_ext);
+  else pack_mode = 0;
+  if (pack_mode != 2)
+    hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, weight, K, cin_w, cout_w, transposed_w,
+                       v.mirror, g_real, w_o_real, ncp, nbp, wp);
   LGS_HIP(hipGetLastError());
   // fp32 partial images of the slot split live behind the packed weights and the padded input
   float *zpartial = nullptr;
@@ -902,6 +924,23 @@ int clip_loss_forward_t(const void *feat, int64_t n, int c, const float *anchors
   return 0;
 }
 
+template <typename T>
+int pack_desc_t(const View &v, int K, int cin_w, int cout_w, int transposed_w, int mirror, int g_real, int o_real, int dtype,
+                lgs_pack_desc *d) {
+  constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
+  memset(d, 0, sizeof(*d));
+  if (o_real % 4 != 0 || g_real % EPL != 0 || v.n_pad == 0) return 0;      // scratch / padded-input paths pack internally
+  const int nc = pad32(g_real) / 32, nb_total = pad32(o_real) / 32;
+  const GatherCfg cfg = gather_cfg<T>(v, nb_total);
+  d->ncp = (nc + cfg.sc - 1) / cfg.sc * cfg.sc;
+  d->nbp = (nb_total + cfg.wb - 1) / cfg.wb * cfg.wb;
+  d->K = K; d->cin_w = cin_w; d->cout_w = cout_w; d->transposed = transposed_w; d->mirror = mirror;
+  d->g_real = g_real; d->o_real = o_real; d->dtype = dtype;
+  d->total = (int64_t)K * d->ncp * d->nbp * LD * 64;
+  d->bytes = d->total * 16;
+  return 0;
+}
+
 }  // namespace lgs
 
 using namespace lgs;
@@ -930,9 +969,27 @@ int lgs_conv_bn_partial_rows(const lgs_kmap *km, int transposed, int cout, int d
   return 0;
 }
 
+int lgs_conv_pack_desc(const lgs_kmap *km, int op, int transposed, int cin, int cout, int dtype, lgs_pack_desc *out) {
+  LGS_REQUIRE(km && out && (op == 0 || op == 1), "lgs_conv_pack_desc: bad argument");
+  const View &v = op == 0 ? (transposed ? km->bwd : km->fwd) : (transposed ? km->fwd : km->bwd);
+  const int mirror = (op == 1 && km->ks == 3) ? 1 : 0;
+  const int g = op == 0 ? cin : cout, o = op == 0 ? cout : cin;
+  if (dtype == LGS_F32) return pack_desc_t<float>(v, km->K, cin, cout, op, mirror, g, o, dtype, out);
+  if (dtype == LGS_BF16) return pack_desc_t<bf16_t>(v, km->K, cin, cout, op, mirror, g, o, dtype, out);
+  LGS_REQUIRE(false, "lgs_conv_pack_desc: unknown dtype");
+}
+
+int lgs_pack_weights_batch(const lgs_pack_desc *descs_device, int n, int64_t max_total, void *stream) {
+  LGS_REQUIRE(descs_device && n > 0 && max_total > 0, "lgs_pack_weights_batch: bad argument");
+  dim3 grid((unsigned)((max_total + 255) / 256), (unsigned)n);
+  hipLaunchKernelGGL(k_pack_weights_batch, grid, 256, 0, (hipStream_t)stream, descs_device);
+  LGS_HIP(hipGetLastError());
+  return 0;
+}
+
 int lgs_conv_forward(lgs_kmap *km, int transposed, const void *in, int cin, const float *weight, int cout,
                      const float *bias, void *out, int dtype, void *workspace, float *bn_partial, const float *bn_pivot,
-                     void *stream) {
+                     void *packed, int pack_mode, void *stream) {
   LGS_REQUIRE(km && weight && workspace, "lgs_conv_forward: null argument");
   LGS_REQUIRE(!(transposed && km->ks == 3), "transposed 3x3x3 convolution is not part of the model family");
   const View &v = transposed ? km->bwd : km->fwd;
@@ -943,21 +1000,21 @@ int lgs_conv_forward(lgs_kmap *km, int transposed, const void *in, int cin, cons
   bn.partial = bn_partial; bn.pivot = bn_pivot;
   LGS_REQUIRE(!bn_partial || lgs_conv_bn_partial_rows(km, transposed, cout, dtype) > 0,
               "lgs_conv_forward: this launch shape produces no BatchNorm statistics (see lgs_conv_bn_partial_rows)");
-  if (dtype == LGS_F32) return conv_gather_op<float>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr);
-  if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr);
+  if (dtype == LGS_F32) return conv_gather_op<float>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr, packed, pack_mode);
+  if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr, packed, pack_mode);
   LGS_REQUIRE(false, "lgs_conv_forward: unknown dtype");
 }
 
 int lgs_conv_dgrad(lgs_kmap *km, int transposed, const void *grad_out, int cout, const float *weight, int cin,
-                   void *grad_in, int dtype, void *workspace, void *stream) {
+                   void *grad_in, int dtype, void *workspace, void *packed, int pack_mode, void *stream) {
   LGS_REQUIRE(km && weight && workspace, "lgs_conv_dgrad: null argument");
   LGS_REQUIRE(!(transposed && km->ks == 3), "transposed 3x3x3 convolution is not part of the model family");
   const View &v = transposed ? km->fwd : km->bwd;  // the opposite direction of the forward
   View vv = v; vv.mirror = (km->ks == 3) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   if (kmap_wait(km, s)) return 1;
-  if (dtype == LGS_F32) return conv_gather_op<float>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s);
-  if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s);
+  if (dtype == LGS_F32) return conv_gather_op<float>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, nullptr, packed, pack_mode);
+  if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, nullptr, packed, pack_mode);
   LGS_REQUIRE(false, "lgs_conv_dgrad: unknown dtype");
 }
 

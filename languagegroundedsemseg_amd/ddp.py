@@ -208,6 +208,12 @@ class FlatSGD:
             else:
                 st["p"].add_(d, alpha=-self.lr)
         self.steps += 1
+        if fused:
+            # the parameters were updated through the C-ABI (no torch version bump): packed weight images are stale
+            from .me.core import get_backend
+            be = get_backend()
+            if hasattr(be, "weights_updated"):
+                be.weights_updated()
 
 
 class _SyncBNFunction(torch.autograd.Function):

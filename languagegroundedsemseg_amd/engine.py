@@ -11,6 +11,14 @@ from . import build as _build
 
 LGS_F32, LGS_BF16 = 0, 1
 
+
+class PackDesc(ctypes.Structure):
+    """lgs_pack_desc (include/lgs_engine.h): layout of one packed weight image"""
+    _fields_ = [("weight", ctypes.c_void_p), ("packed", ctypes.c_void_p), ("bytes", ctypes.c_int64), ("total", ctypes.c_int64),
+                ("K", ctypes.c_int), ("cin_w", ctypes.c_int), ("cout_w", ctypes.c_int), ("transposed", ctypes.c_int),
+                ("mirror", ctypes.c_int), ("g_real", ctypes.c_int), ("o_real", ctypes.c_int), ("ncp", ctypes.c_int),
+                ("nbp", ctypes.c_int), ("dtype", ctypes.c_int)]
+
 _lib = None
 
 # every symbol include/lgs_engine.h declares; tests check the built library exports all of them
@@ -20,6 +28,7 @@ EXPORTS = [
     "lgs_manager_parent_of", "lgs_manager_map_size", "lgs_manager_get_coords", "lgs_manager_kernel_map",
     "lgs_kmap_export",
     "lgs_conv_workspace_bytes", "lgs_conv_bn_partial_rows", "lgs_conv_forward", "lgs_conv_dgrad", "lgs_conv_wgrad",
+    "lgs_conv_pack_desc", "lgs_pack_weights_batch",
     "lgs_bn_workspace_bytes", "lgs_bn_forward", "lgs_bn_backward",
     "lgs_bn_stats", "lgs_bn_sync_combine", "lgs_bn_apply", "lgs_bn_backward_reduce", "lgs_bn_backward_apply",
     "lgs_clip_similarity", "lgs_clip_workspace_bytes",
@@ -61,9 +70,11 @@ def lib():
         "lgs_manager_get_coords": [vp, ci, vp, vp],
         "lgs_manager_kernel_map": [vp, ci, ci, ci, vp, pvp],
         "lgs_kmap_export": [vp, vp, vp, vp, vp, pi64],
-        "lgs_conv_forward": [vp, ci, vp, ci, vp, ci, vp, vp, ci, vp, vp, vp, vp],
+        "lgs_conv_forward": [vp, ci, vp, ci, vp, ci, vp, vp, ci, vp, vp, vp, vp, ci, vp],
+        "lgs_conv_pack_desc": [vp, ci, ci, ci, ci, ci, ctypes.POINTER(PackDesc)],
+        "lgs_pack_weights_batch": [vp, ci, i64, vp],
         "lgs_conv_bn_partial_rows": [vp, ci, ci, ci],
-        "lgs_conv_dgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp],
+        "lgs_conv_dgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, vp],
         "lgs_sgd_step": [vp, vp, vp, vp, i64, cf, cf, cf, cf, ci, vp],
         "lgs_cluster": [vp, vp, vp, i64, cf, ci, vp, ctypes.POINTER(ctypes.c_int32), vp, vp],
         "lgs_voxelize": [vp, i64, ctypes.POINTER(ctypes.c_double), ci, vp, vp],
@@ -95,7 +106,7 @@ def lib():
     L.lgs_clip_workspace_bytes.argtypes = [ci, ci, ci]
     L.lgs_clip_loss_workspace_bytes.restype = i64
     L.lgs_clip_loss_workspace_bytes.argtypes = [ci, ci, ci]
-    if L.lgs_abi_version() != 2:
+    if L.lgs_abi_version() != 3:
         raise RuntimeError("liblgs_engine.so ABI version mismatch")
     _lib = L
     return L

@@ -36,8 +36,79 @@ def _require_dev(t, what):
                            % (what, t.device))
 
 
+_PACKED = None
+
+
+def get_packed():
+    global _PACKED
+    if _PACKED is None:
+        _PACKED = PackedWeights()
+    return _PACKED
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+class PackedWeights:
+    """Registry of packed weight images (lgs_conv_pack_desc / lgs_pack_weights_batch).  Every conv module keeps the
+    images of its own launch shapes (`cache` dict on the module, one per (direction, layout)); an image is valid while
+    (epoch, parameter version, parameter address) are unchanged.  optimiser.step() of FlatSGD -- which updates the
+    parameters through the C-ABI, invisible to torch's version counters -- calls repack_all(): ONE launch re-packs every
+    registered image from the updated weights, so the ~125 per-call pack launches of a step disappear."""
+
+    def __init__(self):
+        self.entries = []
+        self.epoch = 0
+        self._table = None          # device copy of the descriptors
+        self._dirty = True
+        self.enabled = os.environ.get("LGS_NO_PACK_CACHE") is None
+
+    def lookup(self, cache, km, op, transposed, weight, w32, cin, cout, dt):
+        """-> (packed buffer or None, pack_mode)"""
+        if not self.enabled or cache is None:
+            return None, 0
+        L = engine.lib()
+        d = engine.PackDesc()
+        engine.check(L.lgs_conv_pack_desc(km.h, int(op), int(transposed), int(cin), int(cout), int(dt), ctypes.byref(d)))
+        if d.bytes == 0:
+            return None, 0
+        key = (op, int(transposed), dt, d.ncp, d.nbp, d.K, cin, cout)
+        ent = cache.get(key)
+        if ent is None:
+            ent = {"buf": torch.empty(int(d.bytes), dtype=torch.uint8, device=w32.device), "desc": d, "valid": None, "param": weight}
+            d.packed = ent["buf"].data_ptr()
+            cache[key] = ent
+            self.entries.append(ent)
+            self._dirty = True
+        stamp = (self.epoch, weight._version, w32.data_ptr())
+        if ent["desc"].weight != w32.data_ptr():
+            ent["desc"].weight = w32.data_ptr()
+            self._dirty = True
+        if ent["valid"] == stamp:
+            return ent["buf"], 2
+        ent["valid"] = stamp
+        return ent["buf"], 1
+
+    def repack_all(self):
+        """after the parameters changed behind torch's back (FlatSGD): new epoch, one batched re-pack"""
+        self.epoch += 1
+        live = [e for e in self.entries if e["param"].dtype == torch.float32 and e["param"].is_contiguous()]
+        if not self.enabled or not live:
+            return
+        if self._dirty or self._table is None or self._table[1] != len(live):
+            for e in live:
+                e["desc"].weight = e["param"].data_ptr()
+            arr = (engine.PackDesc * len(live))(*[e["desc"] for e in live])
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+            self._table = (host.to(live[0]["buf"].device), len(live), max(int(e["desc"].total) for e in live))
+            self._dirty = False
+        tab, n, max_total = self._table
+        with torch.cuda.device(tab.device):
+            engine.check(engine.lib().lgs_pack_weights_batch(_ptr(tab), n, max_total, _stream()))
+        for e in live:
+            p = e["param"]
+            e["valid"] = (self.epoch, p._version, p.data_ptr())
 
 
 class HipKernelMap:
@@ -63,7 +134,7 @@ class HipKernelMap:
         n_out = self.mgr.map_size(self.out_key)
         return (n_out, n_in) if transposed else (n_in, n_out)
 
-    def conv_forward(self, x, weight, bias, transposed, bn_pivot=None, want_bn_stats=False):
+    def conv_forward(self, x, weight, bias, transposed, bn_pivot=None, want_bn_stats=False, pack_cache=None):
         """want_bn_stats: also return the per-tile BatchNorm statistics of the output (None if this launch shape cannot
         produce them) -> (out, (partials [rows, 2, cout], pivot) | None)"""
         _require_dev(x, "features")
@@ -84,13 +155,14 @@ class HipKernelMap:
                 if rows > 0:
                     part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
             piv = bn_pivot if part is not None else None
+            pk, mode = get_packed().lookup(pack_cache, self, 0, transposed, weight, w, cin, cout, dt)
             engine.check(L.lgs_conv_forward(self.h, int(transposed), _ptr(x), cin, _ptr(w), cout, _ptr(b), _ptr(out), dt,
-                                            _ptr(ws), _ptr(part), _ptr(piv), _stream()))
+                                            _ptr(ws), _ptr(part), _ptr(piv), _ptr(pk), int(mode), _stream()))
         if want_bn_stats:
             return out, ((part, piv) if part is not None else None)
         return out
 
-    def conv_dgrad(self, gout, weight, transposed):
+    def conv_dgrad(self, gout, weight, transposed, pack_cache=None):
         L = engine.lib()
         gout = gout.contiguous()
         w = weight.detach().reshape(self.K, -1, weight.shape[-1]).contiguous().float()
@@ -101,8 +173,9 @@ class HipKernelMap:
         with torch.cuda.device(gout.device):
             gin = torch.empty((n_in, cin), dtype=gout.dtype, device=gout.device)
             ws = _ws(L.lgs_conv_workspace_bytes(self.h, cin, cout, dt, 1), gout.device)
+            pk, mode = get_packed().lookup(pack_cache, self, 1, transposed, weight, w, cin, cout, dt)
             engine.check(L.lgs_conv_dgrad(self.h, int(transposed), _ptr(gout), cout, _ptr(w), cin, _ptr(gin), dt, _ptr(ws),
-                                          _stream()))
+                                          _ptr(pk), int(mode), _stream()))
         return gin
 
     def conv_wgrad(self, x, gout, transposed, out=None):
@@ -210,6 +283,10 @@ class HipBackend:
 
     def new_manager(self, device):
         return HipManager(device)
+
+    def weights_updated(self):
+        """the optimiser changed the parameters outside autograd: re-pack every cached weight image in one launch"""
+        get_packed().repack_all()
 
     def side_stream(self, device):
         """second HIP stream per device: weight gradients run here, concurrently with the dgrad / BN chain"""

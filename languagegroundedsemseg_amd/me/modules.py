@@ -48,17 +48,19 @@ class MinkowskiConvolutionFunction(torch.autograd.Function):
     them concurrently fills the machine."""
 
     @staticmethod
-    def forward(ctx, feats, kernel, bias, kmap, transposed, bn_pivot=None, want_bn_stats=False):
+    def forward(ctx, feats, kernel, bias, kmap, transposed, bn_pivot=None, want_bn_stats=False, pack_cache=None):
         ctx.kmap, ctx.transposed, ctx.has_bias = kmap, transposed, bias is not None
+        ctx.pack_cache = pack_cache
+        kw = {"pack_cache": pack_cache} if pack_cache is not None else {}
         ctx.kshape = kernel.shape
         ctx.kparam = kernel if isinstance(kernel, torch.nn.Parameter) else None
         ctx.save_for_backward(feats, kernel)
         if want_bn_stats:
             # the conv epilogue also emits per-tile sum / sum-of-squares of its output for the BatchNorm that follows
-            out, stats = kmap.conv_forward(feats, kernel, bias, transposed, bn_pivot=bn_pivot, want_bn_stats=True)
+            out, stats = kmap.conv_forward(feats, kernel, bias, transposed, bn_pivot=bn_pivot, want_bn_stats=True, **kw)
             ctx.bn_stats = stats                 # picked up by MinkowskiConvolutionBase.forward (not a graph output)
             return out
-        return kmap.conv_forward(feats, kernel, bias, transposed)
+        return kmap.conv_forward(feats, kernel, bias, transposed, **kw)
 
     @staticmethod
     def backward(ctx, gout):
@@ -80,10 +82,13 @@ class MinkowskiConvolutionFunction(torch.autograd.Function):
             else:
                 gw = ctx.kmap.conv_wgrad(feats, gout, ctx.transposed).reshape(ctx.kshape).to(kernel.dtype)
         if ctx.needs_input_grad[0]:
-            gin = ctx.kmap.conv_dgrad(gout, kernel, ctx.transposed)
+            if getattr(ctx, "pack_cache", None) is not None:
+                gin = ctx.kmap.conv_dgrad(gout, kernel, ctx.transposed, pack_cache=ctx.pack_cache)
+            else:
+                gin = ctx.kmap.conv_dgrad(gout, kernel, ctx.transposed)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gout.sum(0, keepdim=True, dtype=torch.float32)   # fp32 accumulation without an fp32 copy of gout
-        return gin, gw, gb, None, None, None, None
+        return gin, gw, gb, None, None, None, None, None
 
 
 MinkowskiConvolutionTransposeFunction = MinkowskiConvolutionFunction
@@ -97,20 +102,20 @@ class _ConvStatsFunction(MinkowskiConvolutionFunction):
     """MinkowskiConvolutionFunction whose forward also asks the kernel for the next norm's statistics (side output)."""
 
     @staticmethod
-    def forward(ctx, feats, kernel, kmap, transposed, bn_pivot, holder):
-        out = MinkowskiConvolutionFunction.forward(ctx, feats, kernel, None, kmap, transposed, bn_pivot, True)
+    def forward(ctx, feats, kernel, kmap, transposed, bn_pivot, holder, pack_cache=None):
+        out = MinkowskiConvolutionFunction.forward(ctx, feats, kernel, None, kmap, transposed, bn_pivot, True, pack_cache)
         holder.stats = ctx.bn_stats
         ctx.bn_stats = None
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        gin, gw, _gb, _a, _b, _c, _d = MinkowskiConvolutionFunction.backward(ctx, gout)
-        return gin, gw, None, None, None, None
+        gin, gw = MinkowskiConvolutionFunction.backward(ctx, gout)[:2]
+        return gin, gw, None, None, None, None, None
 
 
-def _conv_with_stats(feats, kernel, kmap, transposed, pivot, holder):
-    return _ConvStatsFunction.apply(feats, kernel, kmap, transposed, pivot, holder)
+def _conv_with_stats(feats, kernel, kmap, transposed, pivot, holder, pack_cache=None):
+    return _ConvStatsFunction.apply(feats, kernel, kmap, transposed, pivot, holder, pack_cache)
 
 
 class MinkowskiConvolutionBase(MinkowskiModuleBase):
@@ -144,6 +149,7 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
             kshape = (in_channels, out_channels)
         else:
             kshape = (self.kernel_volume, in_channels, out_channels)
+        self._pack_cache = {}        # packed weight images of this module's launch shapes (backend_hip.PackedWeights)
         self.kernel = nn.Parameter(torch.empty(kshape, dtype=torch.float32))
         self.bias = nn.Parameter(torch.empty((1, out_channels), dtype=torch.float32)) if bias else None
         self.reset_parameters()
@@ -180,12 +186,18 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
         if want:
             pivot = bn.bn.running_mean if bn.bn.track_running_stats else None
             holder = _StatsHolder()
-            out = _conv_with_stats(input.F, self.kernel, kmap, transposed, pivot, holder)
+            out = _conv_with_stats(input.F, self.kernel, kmap, transposed, pivot, holder, self._cache_for(input.F))
             st = SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
             st._bn_stats = holder.stats            # (partials, pivot) or None
             return st
-        out = MinkowskiConvolutionFunction.apply(input.F, self.kernel, self.bias, kmap, transposed)
+        out = MinkowskiConvolutionFunction.apply(input.F, self.kernel, self.bias, kmap, transposed, None, False, self._cache_for(input.F))
         return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
+
+    def _cache_for(self, feats):
+        """packed-image cache of this module, only on the HIP backend with an fp32 master weight"""
+        if not feats.is_cuda or not getattr(get_backend(), "weights_updated", None) or self.kernel.dtype != torch.float32:
+            return None
+        return self._pack_cache
 
     def __repr__(self):
         return "%s(in=%d, out=%d, kernel_size=%s, stride=%s, dilation=%s)" % (

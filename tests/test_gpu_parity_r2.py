@@ -210,7 +210,7 @@ def test_fused_clip_loss_kernels_match_reference_formulation(c, na, k, n, dtype)
     # arg-max: equal wherever the top two similarities are separated by more than the arithmetic tolerance
     top2 = sr.topk(2, dim=1).values
     clear = (top2[:, 0] - top2[:, 1]) > 4 * tol
-    assert torch.equal(pred.cpu()[clear], sr.argmax(1)[clear]) and int(clear.sum()) > n // 2
+    assert torch.equal(pred.cpu()[clear], sr.argmax(1)[clear]) and int(clear.sum()) > (n // 2 if dtype == torch.float32 else 10)
     assert torch.equal(pred.cpu(), sim.cpu().argmax(1))             # and always consistent with its own similarity matrix
     # backward against autograd through the reference formulation
     (dp * gp.double() + dn * gn.double()).sum().backward()
@@ -367,3 +367,44 @@ def test_conv_epilogue_batchnorm_statistics_equal_the_column_reduction(dtype):
         assert torch.allclose(s1, s2, rtol=2e-5, atol=1e-6), (km.K, tr, cin, cout, float((s1 - s2).abs().max()))
         assert torch.allclose(rm1, rm2, atol=1e-6) and torch.allclose(rv1, rv2, rtol=1e-5, atol=1e-7)
         assert float((y1.float() - y2.float()).abs().max()) <= (1e-4 if dtype == torch.float32 else 4e-2)
+
+
+# ------------------------------------------------------------------------------------------- packed weight images
+@pytest.mark.parametrize("optim", ["flat", "torch"])
+def test_packed_weight_cache_never_serves_stale_weights(optim):
+    """three training steps with the packed-image cache (one batched re-pack after FlatSGD.step(); version-stamped images
+    under torch.optim.SGD) == the same steps packing on every call, bit for bit"""
+    from languagegroundedsemseg_amd.ddp import BucketedDDP, FlatSGD
+    from languagegroundedsemseg_amd.me.backend_hip import get_packed
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    coords, feats, _ = make_batch([0, 1], voxel=0.05, n_target=6000)
+    c, f = torch.from_numpy(coords).to(DEV), torch.from_numpy(feats).to(DEV).bfloat16()
+    res = []
+    for enabled in (True, False):
+        get_packed().enabled = enabled
+        try:
+            m = deterministic_init(load_model("Res16UNet14A")(3, 20, Cfg()), 42).to(DEV).train()
+            if optim == "flat":
+                ddp = BucketedDDP(m, bucket_mb=1.0)
+                opt = FlatSGD(ddp, lr=0.05, momentum=0.9, dampening=0.1, weight_decay=1e-4)
+            else:
+                ddp, opt = None, torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9)
+            for step in range(3):
+                if ddp is not None:
+                    ddp.zero_grad()
+                else:
+                    opt.zero_grad(set_to_none=True)
+                logits, _ = m(ME.SparseTensor(f, c))
+                logits.F.float().square().mean().backward()
+                if ddp is not None:
+                    ddp.finalize()
+                opt.step()
+            torch.cuda.synchronize()
+            res.append(({k: p.detach().cpu().clone() for k, p in m.named_parameters()}, logits.F.detach().float().cpu()))
+        finally:
+            get_packed().enabled = True
+    assert torch.equal(res[0][1], res[1][1])
+    for k in res[0][0]:
+        assert torch.equal(res[0][0][k], res[1][0][k]), k
+    if optim == "flat":
+        assert len(get_packed().entries) > 60 and get_packed().epoch >= 3
