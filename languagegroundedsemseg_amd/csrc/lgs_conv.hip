@@ -703,7 +703,7 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
   // bf16 storage only: the fp32 path is the parity mode and keeps ONE accumulator per output (a different summation
   // order moves results by ~1e-7, which BatchNorm over a handful of coarse rows with near-zero variance amplifies into
   // ReLU gate flips against the oracle -- measured on the 14A fixture)
-  const bool no_split = getenv("LGS_NO_SPLIT") != nullptr;   // debugging knob (read per call)
+  static const bool no_split = getenv("LGS_NO_SPLIT") != nullptr;   // debugging knob (read once)
   const bool can_split = !no_split && sizeof(T) == 2 && zpartial && !out_f32 && v.KS > 1 && K == 27 && split_partial_bytes(K, v.n_out, cout_real) > 0;
   const int64_t zstride = v.n_out * (int64_t)cout_real;
   bool did_split = false;
@@ -751,7 +751,8 @@ int bn_partial_rows_t(const View &v, int K, int o_real) {
   const int nb_total = pad32(o_real) / 32;
   const GatherCfg cfg = gather_cfg<T>(v, nb_total);
   const int64_t gx = v.n_pad / cfg.tm, gy = (nb_total + cfg.wb - 1) / cfg.wb;
-  const bool split = sizeof(T) == 2 && getenv("LGS_NO_SPLIT") == nullptr && v.KS > 1 && K == 27 &&
+  static const bool no_split = getenv("LGS_NO_SPLIT") != nullptr;
+  const bool split = sizeof(T) == 2 && !no_split && v.KS > 1 && K == 27 &&
                      split_partial_bytes(K, v.n_out, o_real) > 0 && gx * gy < 600;
   return split ? 0 : (int)gx;
 }

@@ -261,6 +261,32 @@ class FusedBatchNormFunction(torch.autograd.Function):
         return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), dres, None, None, None, None, None, None, None, None
 
 
+class EvalBatchNormFunction(torch.autograd.Function):
+    """eval-mode BatchNorm (running statistics) (+ residual) (+ ReLU) on the engine's apply kernels: forward =
+    lgs_bn_apply with stats = [running_mean | 1/sqrt(running_var + eps)]; backward (frozen statistics: fine-tuning with
+    BN in eval mode) = lgs_bn_backward_reduce for d gamma / d beta and lgs_bn_backward_apply with zero batch sums."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, stats, relu, backend):
+        y = backend.bn_apply(x, gamma, beta, stats, residual, relu)
+        ctx.backend, ctx.has_res = backend, residual is not None
+        ctx.relu_mode = 0 if not relu else (1 if residual is not None else 2)
+        ctx.save_for_backward(x, gamma, beta, stats, y if ctx.relu_mode == 1 else x.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        yy = y if ctx.relu_mode == 1 else None
+        c = x.shape[1]
+        sums = ctx.backend.bn_backward_reduce(x, yy, dy, gamma, beta, stats, ctx.relu_mode)
+        zero = torch.zeros_like(sums)
+        dx, dres = ctx.backend.bn_backward_apply(x, yy, dy, gamma, beta, stats, zero, 0.0, ctx.relu_mode,
+                                                 ctx.has_res and ctx.needs_input_grad[3])
+        return dx, sums[c:].to(gamma.dtype), sums[:c].to(gamma.dtype), dres, None, None, None
+
+
 class MinkowskiBatchNorm(nn.Module):
     """`.bn` is a plain nn.BatchNorm1d so state-dict keys are `*.bn.{weight,bias,running_*}`."""
 
@@ -288,7 +314,12 @@ class MinkowskiBatchNorm(nn.Module):
             if cs is not None and (cs[1] is not None) != (rm is not None):
                 cs = None                                  # pivot convention mismatch (cannot happen for the conv's own bn)
             y = FusedBatchNormFunction.apply(x, bn.weight, bn.bias, res, rm, rv, bn.eps, bn.momentum, relu, backend, nbt, cs)
-        else:
+        elif hasattr(backend, "bn_apply") and bn.affine and bn.track_running_stats and x.is_cuda:
+            # eval mode on the engine too (inference / validation passes, BN frozen during fine-tuning)
+            with torch.no_grad():
+                stats = torch.cat([bn.running_mean.float(), torch.rsqrt(bn.running_var.float() + bn.eps)])
+            y = EvalBatchNormFunction.apply(x, bn.weight, bn.bias, res, stats, relu, backend)
+        else:   # CPU oracle backend of the tests / norms without affine parameters
             y = bn(x.float()).to(x.dtype) if x.dtype != torch.float32 else bn(x)
             if res is not None:
                 y = y + res

@@ -408,3 +408,40 @@ def test_packed_weight_cache_never_serves_stale_weights(optim):
         assert torch.equal(res[0][0][k], res[1][0][k]), k
     if optim == "flat":
         assert len(get_packed().entries) > 60 and get_packed().epoch >= 3
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+def test_eval_mode_batchnorm_on_the_engine_matches_torch(dtype, tol):
+    """MinkowskiBatchNorm in eval mode (running statistics) with the fused residual / ReLU tail, forward + backward"""
+    torch.manual_seed(1)
+    n, c = 5003, 96
+    coords = torch.cat([torch.zeros(n, 1, dtype=torch.int32), torch.arange(n, dtype=torch.int32)[:, None].repeat(1, 3)], 1).to(DEV)
+    xs = ME.SparseTensor(torch.randn(n, c, device=DEV).to(dtype), coords)
+    bn = ME.MinkowskiBatchNorm(c).to(DEV)
+    with torch.no_grad():
+        bn.bn.running_mean.uniform_(-0.5, 0.5); bn.bn.running_var.uniform_(0.5, 2.0)
+        bn.bn.weight.uniform_(0.5, 1.5); bn.bn.bias.uniform_(-0.3, 0.3)
+    bn.eval()
+    for relu, with_res in ((False, False), (True, False), (True, True)):
+        x = xs.F.detach().clone().requires_grad_(True)
+        r = torch.randn(n, c, device=DEV).to(dtype).requires_grad_(True) if with_res else None
+        xin = ME.SparseTensor(x, coordinate_map_key=xs.coordinate_map_key, coordinate_manager=xs.coordinate_manager)
+        y = bn(xin, relu=relu, residual=r).F
+        g = torch.randn_like(y)
+        bn.zero_grad()
+        y.backward(g)
+        x2 = xs.F.detach().float().clone().requires_grad_(True)
+        r2 = r.detach().float().clone().requires_grad_(True) if with_res else None
+        t = torch.nn.functional.batch_norm(x2, bn.bn.running_mean, bn.bn.running_var, bn.bn.weight, bn.bn.bias, False, 0.0, bn.bn.eps)
+        if with_res:
+            t = t + r2
+        if relu:
+            t = torch.relu(t)
+        gw0, gb0 = bn.bn.weight.grad.clone(), bn.bn.bias.grad.clone()
+        bn.zero_grad()
+        t.backward(g.float())
+        assert rel_l2(y.detach().float().cpu().numpy(), t.detach().cpu().numpy()) < tol
+        assert rel_l2(x.grad.float().cpu().numpy(), x2.grad.cpu().numpy()) < tol
+        if with_res:
+            assert rel_l2(r.grad.float().cpu().numpy(), r2.grad.cpu().numpy()) < tol
+        assert rel_l2(gw0.cpu().numpy(), bn.bn.weight.grad.cpu().numpy()) < tol and rel_l2(gb0.cpu().numpy(), bn.bn.bias.grad.cpu().numpy()) < tol

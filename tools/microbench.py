@@ -107,7 +107,7 @@ def clip():
             ms = timeit(lambda: be.clip_loss_forward(f, t, lab, neg, -1))
             byts = n * c * f.element_size() + n * (3 * 4 + 8 + 4 * 8)
             print("fused clip loss fwd (d_pos, d_neg, argmax, 1/|f|; no S) %.3f ms  %.1f TFLOP/s (%.1f %% of 2.5 PF)  %.2f TB/s "
-                  "(%.1f %% of 8 TB/s)" % (ms, flop / ms / 1e9, flop / ms / 1e9 / 25.0, byts / ms / 1e9, byts / ms / 1e9 / 80.0))
+                  "(%.1f %% of 8 TB/s)" % (ms, flop / ms / 1e9, flop / ms / 1e9 / 2500.0 * 100.0, byts / ms / 1e9, byts / ms / 1e9 / 8.0 * 100.0))
             d_pos, d_neg, pred, saved, _ = be.clip_loss_forward(f, t, lab, neg, -1)
             gp, gn = torch.randn(n, device=DEV), torch.randn(n, device=DEV)
             ms = timeit(lambda: be.clip_loss_backward(saved, d_pos, d_neg, gp, gn, -1))
