@@ -449,6 +449,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
 // s_waitcnt vmcnt(N).  hipcc would fence each ds_read behind a pending LDS-DMA with vmcnt(0), so the LDS reads of the
 // loop are inline asm and the waits are explicit; the per-chunk barrier is a raw s_barrier.
 // Partial slabs: one per workgroup "lane" (<= 256 / slices), written once, folded by k_wgrad_reduce_ps in fixed order.
+// Measured dead ends: 64-position chunks with a 4-slot ring and three groups in flight (0.65 vs 0.63 ms at L0 96->96:
+// the extra barriers cost what the deeper queue gains); skipping neighbour-less tiles with a run-time vmcnt (0.67 ms).
 constexpr int kPsChunk = 128;
 // offsets per wave for K = 27 (k = (dx+1) + 3(dy+1) + 9(dz+1)): centre / faces / edges / corners spread so that every
 // wave sees about the same number of pairs; waves 4..6 own four offsets, the others three
@@ -737,7 +739,10 @@ __device__ __forceinline__ void ps_wave(const PsArgs &a, char *smem, const int w
 template <int KIND, int NCS>
 __global__ __launch_bounds__(512, 2) void k_wgrad_ps(PsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave index as a SCALAR: every LDS destination of the DMA stream (M0) and every ring address derives from it, and
+  // hipcc otherwise re-derives them from the vector thread id with a v_readfirstlane per DMA instruction
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned bx = blockIdx.x, xcd = bx & 7u, tq = bx >> 3;
   const int n_sl = a.n_cg * a.n_cs;
   // xcd_map: the slices of one lane share an XCD (= its L2); otherwise (more slices than an XCD has CUs) plain order

@@ -14,6 +14,10 @@ from .core import SparseTensor, get_backend
 from .kernel import KernelGenerator, RegionType, convert_to_int_list
 
 
+import os as _os
+_DBG_WGRAD = _os.environ.get("LGS_DBG_WGRAD", "")   # "", "skip", "inline": step-time attribution experiments only
+
+
 class MinkowskiModuleBase(nn.Module):
     pass
 
@@ -70,7 +74,12 @@ class MinkowskiConvolutionFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             view = grad_slot_view(ctx.kparam) if ctx.kparam is not None else None
             backend = get_backend()
-            if view is not None and gout.is_cuda and hasattr(backend, "side_stream"):
+            if view is not None and gout.is_cuda and hasattr(backend, "side_stream") and _DBG_WGRAD == "skip":
+                gw = view                                    # profiling knob: no weight gradient at all
+            elif view is not None and gout.is_cuda and hasattr(backend, "side_stream") and _DBG_WGRAD == "inline":
+                ctx.kmap.conv_wgrad(feats, gout, ctx.transposed, out=view.view(ctx.kmap.K, -1, ctx.kshape[-1]))
+                gw = view                                    # profiling knob: weight gradient on the compute stream
+            elif view is not None and gout.is_cuda and hasattr(backend, "side_stream"):
                 main = torch.cuda.current_stream(gout.device)
                 side = backend.side_stream(gout.device)
                 side.wait_stream(main)                       # feats / gout are ready
