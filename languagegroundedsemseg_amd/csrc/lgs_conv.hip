@@ -191,7 +191,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
                                                              float *__restrict__ out_f32_arg,
                                                              const float *__restrict__ row_scale,
                                                              unsigned in_bytes, unsigned w_bytes, int64_t zstride,
-                                                             ClipEpi ce, BnEpi be) {
+                                                             ClipEpi ce, BnEpi be, int gc) {
   static_assert(EPI == 0 || (RB == 1 && WN == 1), "the CLIP epilogue owns whole rows: one row block, all columns per wave");
   // SC = 32-channel chunks per weight SLAB: the weights of (offset, slab) are staged in LDS once per workgroup
   // and one barrier separates slabs, while the gathered feature fragments stream chunk by chunk through a
@@ -263,15 +263,25 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   // fetch is a ds_read (lgkmcnt) and never sits in the VMEM queue in front of the gather ring
   __shared__ int32_t l_idx[27 * TM];
   // ---- feature-side iterator: flat sequence of (slot, chunk)
+  // Order of the reduction: channel GROUPS of gc chunks outermost, then the offsets, then the chunks of the group.
+  // gc = nc (one group) is the plain "offset by offset" order.  With wide rows (512 channels = 1 KB) the plain order
+  // touches every gathered row in sixteen 64-byte pieces per offset and comes back to it ~14 offsets later: the rows of
+  // the co-resident tiles plus 14 MB of weights do not fit the XCD's 4 MB L2 (PMC: L2 hit 51 %, 19x the compulsory HBM
+  // bytes); with 128-channel groups a row's 256-byte segment serves all offsets back to back.
   uint32_t rem = smask;
-  int islot = -1, ichunk = nc;  // forces "advance to first slot" on the first call
+  int islot = -1, gbase = 0, gend = min(gc, nc), ichunk = gend;  // forces "advance to first slot" on the first call
   int32_t idx_i[RB];
   auto advance = [&]() __attribute__((always_inline)) -> bool {
-    if (++ichunk < nc) return true;
-    if (rem == 0) return false;
+    if (++ichunk < gend) return true;
+    if (rem == 0) {                       // next channel group: all offsets again
+      gbase = gend;
+      if (gbase >= nc) return false;
+      gend = min(gbase + gc, nc);
+      rem = smask;
+    }
     islot = __builtin_ctz(rem);
     rem &= rem - 1;
-    ichunk = 0;
+    ichunk = gbase;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       const int r = wm * RB * 32 + rb * 32 + vx;
@@ -304,15 +314,20 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     }
   };
   // ---- weight-side iterator: (slot, slab) in the same order
-  const int nslab = (nc + SC - 1) / SC;
+  const int nslab = (nc + SC - 1) / SC, gs = (gc + SC - 1) / SC;   // slabs per channel group (gc is a multiple of SC or = nc)
   uint32_t wrem = smask;
-  int wslot = -1, wslab = nslab;
+  int wslot = -1, wgbase = 0, wgend = min(gs, nslab), wslab = wgend;
   auto wadvance = [&]() __attribute__((always_inline)) -> bool {
-    if (++wslab < nslab) return true;
-    if (wrem == 0) return false;
+    if (++wslab < wgend) return true;
+    if (wrem == 0) {
+      wgbase = wgend;
+      if (wgbase >= nslab) return false;
+      wgend = min(wgbase + gs, nslab);
+      wrem = smask;
+    }
     wslot = __builtin_ctz(wrem);
     wrem &= wrem - 1;
-    wslab = 0;
+    wslab = wgbase;
     return true;
   };
   // The packed weights are padded to whole slabs (ncp chunks) and whole cout tiles (nbp blocks), zero filled, so a
@@ -708,6 +723,9 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
   const int64_t zstride = v.n_out * (int64_t)cout_real;
   bool did_split = false;
   constexpr bool kF32 = (sizeof(T) == 4);
+  // channel groups of the reduction (see the kernel): rows wider than 8 chunks (256 channels) are walked in 4-chunk groups
+  static const int gc_env = getenv("LGS_CONV_GC") ? atoi(getenv("LGS_CONV_GC")) : 0;   // tuning knob: 0 = automatic
+  const int gc = gc_env > 0 ? ((gc_env + 3) / 4 * 4) : (nc > 8 ? 4 : nc);
 #define LGS_LAUNCH(RB, NCB, WM, WN, SC, D)                                                                        \
   do {                                                                                                            \
     dim3 grid((unsigned)(v.n_pad / (WM * RB * 32)), (unsigned)((nb_total + WN * NCB - 1) / (WN * NCB)));         \
@@ -716,7 +734,7 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
     hipLaunchKernelGGL((k_conv_gather<T, RB, NCB, WM, WN, SC, D>), grid, dim3(WM *WN * 64), 0, s, v, in, cin_real, nc,    \
                        reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, out, cout_real, did_split ? nullptr : bias, \
                        did_split ? zpartial : out_f32, row_scale, in_bytes, w_bytes, zstride, ClipEpi(),           \
-                       (bn && !did_split) ? *bn : BnEpi());                                                       \
+                       (bn && !did_split) ? *bn : BnEpi(), gc);                                                   \
     if (bn_rows) *bn_rows = did_split ? 0 : (int)grid.x;                                                          \
   } while (0)
   switch (cfg.id) {
@@ -727,7 +745,7 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
     case 4: LGS_LAUNCH(1, 1, 2, 1, (kF32 ? 2 : 4), (kF32 ? 4 : 8)); break;
     case 6: LGS_LAUNCH(1, 7, 4, 1, (kF32 ? 1 : 2), (kF32 ? 3 : 4)); break;
     case 7: LGS_LAUNCH(1, 4, 4, 1, 2, 4); break;
-    case 15: LGS_LAUNCH(2, 4, 4, 2, 2, 2); break;
+    case 15: LGS_LAUNCH(2, 4, 4, 2, 2, 3); break;
     case 8: LGS_LAUNCH(1, 2, 4, 1, 4, 6); break;
     case 9: LGS_LAUNCH(1, 2, 2, 2, 4, 6); break;
     case 10: LGS_LAUNCH(1, 2, 2, 1, 4, 6); break;
@@ -913,7 +931,7 @@ int clip_loss_forward_t(const void *feat, int64_t n, int c, const float *anchors
 #define LGS_CLIP(NCB, SC, D)                                                                                              \
   hipLaunchKernelGGL((k_conv_gather<T, 1, NCB, 4, 1, SC, D, 1>), grid, dim3(256), 0, s, v, f, c, nc,                      \
                      reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, (T *)nullptr, na, (const float *)nullptr, sim, \
-                     (const float *)nullptr, (unsigned)in_bytes64, (unsigned)w_bytes64, (int64_t)0, ce, BnEpi())
+                     (const float *)nullptr, (unsigned)in_bytes64, (unsigned)w_bytes64, (int64_t)0, ce, BnEpi(), nc)
   switch (ncb) {
     case 1: LGS_CLIP(1, (kF32 ? 4 : 8), (kF32 ? 4 : 8)); break;
     case 2: LGS_CLIP(2, (kF32 ? 2 : 4), (kF32 ? 3 : 4)); break;
