@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LGS_ABI_VERSION 3
+#define LGS_ABI_VERSION 4
 
 enum lgs_dtype { LGS_F32 = 0, LGS_BF16 = 1 };
 
@@ -102,7 +102,12 @@ int lgs_kmap_export(lgs_kmap *km, int32_t *k, int32_t *in_row, int32_t *out_row,
  * `transposed` = 0: forward direction of the map (in rows -> out rows);
  *                1: the transposed convolution (map's out rows -> map's in rows).
  * `weight` is always the module's own parameter [K,Cin,Cout] (float32), Cin/Cout being THIS
- * op's input/output channels.  `workspace` must hold lgs_conv_workspace_bytes(...) bytes. */
+ * op's input/output channels.  `workspace` must hold lgs_conv_workspace_bytes(...) bytes.
+ * Zero-copy ME.cat (/root/reference/models/res16unet.py:237,247,257,267): both inputs of a concat are written straight
+ * into the concat buffer (lgs_bn_forward's y_row_stride), so the SKIP half is afterwards a column slice of a wider
+ * row-major tensor; its readers take a row stride: lgs_conv_forward / lgs_conv_wgrad `in_row_stride` (the strided conv that
+ * consumes the skip tensor; bf16 only for wgrad) and lgs_bn_backward `y_row_stride` (the ReLU mask of the norm that
+ * produced it).  Rows must stay 16-byte aligned. */
 int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype, int op /*0 fwd,1 dgrad,2 wgrad*/);
 
 /* Packed weight images.  The conv kernels read the weights in MFMA fragment order (bf16 / fp32, padded to the tile
@@ -133,13 +138,13 @@ int lgs_pack_weights_batch(const lgs_pack_desc *descs_device, int n, int64_t max
 int lgs_conv_bn_partial_rows(const lgs_kmap *km, int transposed, int cout, int dtype);
 int lgs_conv_forward(lgs_kmap *km, int transposed, const void *in, int cin, const float *weight, int cout,
                      const float *bias, void *out, int dtype, void *workspace, float *bn_partial, const float *bn_pivot,
-                     void *packed, int pack_mode, void *stream);
+                     void *packed, int pack_mode, int in_row_stride /* elements; 0 = cin */, void *stream);
 /* grad_in[n_in,cin] from grad_out[n_out,cout] */
 int lgs_conv_dgrad(lgs_kmap *km, int transposed, const void *grad_out, int cout, const float *weight, int cin,
                    void *grad_in, int dtype, void *workspace, void *packed, int pack_mode, void *stream);
 /* grad_weight[K,cin,cout] (float32, overwritten) */
 int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const void *grad_out, int cout,
-                   float *grad_weight, int dtype, void *workspace, void *stream);
+                   float *grad_weight, int dtype, void *workspace, int in_row_stride /* elements; 0 = cin */, void *stream);
 
 /* ---- fused batch-norm / ReLU / residual ------------------------------------------------------
  * replaces ME.MinkowskiBatchNorm (.bn = nn.BatchNorm1d over all rows) + MinkowskiReLU + `out += residual`
@@ -156,7 +161,8 @@ int lgs_bn_forward(const void *x, int64_t n, int c, const float *gamma, const fl
                    float momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked,
                    const void *residual, int relu, void *y, float *stats, int dtype, void *workspace,
                    const float *conv_partials /* lgs_conv_forward's bn_partial or NULL */, int conv_partial_rows,
-                   const float *pivot /* the bn_pivot that conv call was given */, void *stream);
+                   const float *pivot /* the bn_pivot that conv call was given */, int64_t y_row_stride /* elements; 0 = c */,
+                   void *stream);
 /* Backward of the fused op.  x = forward input, stats = the forward's mean/invstd.
  * relu: 0 = none; 1 = ReLU mask taken from the forward OUTPUT y (required when a residual was added);
  *       2 = mask recomputed from x as (xhat*gamma + beta > 0), y may be NULL (one tensor read fewer).
@@ -165,7 +171,8 @@ int lgs_bn_forward(const void *x, int64_t n, int c, const float *gamma, const fl
  * of ME.cat (res16unet.py:233-262) is exactly that, and reading it in place saves a copy of the whole slice. */
 int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t dy_row_stride, int64_t n, int c,
                     const float *gamma, const float *beta, const float *stats, int relu, void *dx, void *dresidual,
-                    float *dgamma, float *dbeta, int dtype, void *workspace, void *stream);
+                    float *dgamma, float *dbeta, int dtype, void *workspace, int64_t y_row_stride /* of y; 0 = c */,
+                    void *stream);
 
 /* The same op in halves, so that data-parallel training can exchange the statistics between ranks in the middle
  * (ME.MinkowskiSyncBatchNorm, /root/reference/main.py:122-123) with one small collective per direction and NO host-side

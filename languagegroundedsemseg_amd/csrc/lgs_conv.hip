@@ -191,7 +191,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
                                                              float *__restrict__ out_f32_arg,
                                                              const float *__restrict__ row_scale,
                                                              unsigned in_bytes, unsigned w_bytes, int64_t zstride,
-                                                             ClipEpi ce, BnEpi be, int gc) {
+                                                             ClipEpi ce, BnEpi be, int gc, int in_ld) {
   static_assert(EPI == 0 || (RB == 1 && WN == 1), "the CLIP epilogue owns whole rows: one row block, all columns per wave");
   // SC = 32-channel chunks per weight SLAB: the weights of (offset, slab) are staged in LDS once per workgroup
   // and one barrier separates slabs, while the gathered feature fragments stream chunk by chunk through a
@@ -296,7 +296,9 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   constexpr unsigned kOOB = 0xfffff000u;   // > any descriptor size accepted by the host wrapper, no wrap with small immediates
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(in), 0, (int)in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(wp), 0, (int)w_bytes, 0x00020000);
-  const unsigned row_bytes = (unsigned)cin_real * (unsigned)sizeof(T);
+  // in_ld = row stride of the gathered tensor in elements (> cin_real when it is a column slice of a wider buffer, e.g.
+  // the skip half of a zero-copy ME.cat)
+  const unsigned row_bytes = (unsigned)in_ld * (unsigned)sizeof(T);
   const bool ch_tail = (cin_real & 31) != 0;   // kernel-uniform: only then a chunk can run past the row
   auto issue = [&](u32x4 (&F)[RB][LD], uint32_t &act) __attribute__((always_inline)) {
     act = 0;
@@ -707,10 +709,10 @@ template <typename T>
 int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real, int nc, const uint4 *wp,
                   int nb_total, int ncp, int nbp, int K, T *out, int cout_real, const float *bias, hipStream_t s,
                   float *out_f32 = nullptr, const float *row_scale = nullptr, float *zpartial = nullptr,
-                  const BnEpi *bn = nullptr, int *bn_rows = nullptr) {
+                  const BnEpi *bn = nullptr, int *bn_rows = nullptr, int in_ld = 0) {
   if (v.n_pad == 0) return 0;
   constexpr int LDc = Tr<T>::LD;
-  const uint64_t in_bytes64 = (uint64_t)v.n_in * (uint64_t)cin_real * sizeof(T);
+  const uint64_t in_bytes64 = (uint64_t)v.n_in * (uint64_t)(in_ld > 0 ? in_ld : cin_real) * sizeof(T);
   const uint64_t w_bytes64 = (uint64_t)K * ncp * nbp * LDc * 64 * 16;
   LGS_REQUIRE(in_bytes64 < 0xfffff000ull && w_bytes64 < 0xfffff000ull,
               "sparse conv: a feature or weight tensor of 4 GiB or more is beyond the 32-bit buffer-descriptor path");
@@ -734,7 +736,7 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
     hipLaunchKernelGGL((k_conv_gather<T, RB, NCB, WM, WN, SC, D>), grid, dim3(WM *WN * 64), 0, s, v, in, cin_real, nc,    \
                        reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, out, cout_real, did_split ? nullptr : bias, \
                        did_split ? zpartial : out_f32, row_scale, in_bytes, w_bytes, zstride, ClipEpi(),           \
-                       (bn && !did_split) ? *bn : BnEpi(), gc);                                                   \
+                       (bn && !did_split) ? *bn : BnEpi(), gc, in_ld > 0 ? in_ld : cin_real);                     \
     if (bn_rows) *bn_rows = did_split ? 0 : (int)grid.x;                                                          \
   } while (0)
   switch (cfg.id) {
@@ -778,8 +780,10 @@ int bn_partial_rows_t(const View &v, int K, int o_real) {
 template <typename T>
 int conv_gather_op(const View &v, const void *in_v, int g_real, const float *weight, int K, int cin_w, int cout_w,
                    int transposed_w, int o_real, const float *bias, void *out_v, void *workspace, hipStream_t s,
-                   int w_o_real = -1, const BnEpi *bn = nullptr, void *packed_ext = nullptr, int pack_mode = 0) {
+                   int w_o_real = -1, const BnEpi *bn = nullptr, void *packed_ext = nullptr, int pack_mode = 0, int in_ld = 0) {
   if (w_o_real < 0) w_o_real = o_real;
+  LGS_REQUIRE(in_ld == 0 || in_ld == g_real || (g_real % Tr<T>::EPL == 0 && o_real % 4 == 0 && in_ld > g_real && (in_ld * (int)sizeof(T)) % 16 == 0),
+              "sparse conv: a strided input needs 16-byte aligned rows and channel counts on the 16-byte grid");
   constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
   const int g_pad = pad32(g_real), nc = g_pad / 32, nb_total = pad32(o_real) / 32;
   char *ws = reinterpret_cast<char *>(workspace);
@@ -836,7 +840,7 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
     zpartial = reinterpret_cast<float *>(ws + wbytes + ((g_real % EPL != 0) ? align256(v.n_in * (int64_t)g_pad * (int64_t)sizeof(T)) : 0));
   int rows = 0;
   int rc = launch_gather<T>(v, cfg, in, g_stride, nc, wp, nb_total, ncp, nbp, K, reinterpret_cast<T *>(out_v), o_real, bias, s,
-                            nullptr, nullptr, zpartial, bn, &rows);
+                            nullptr, nullptr, zpartial, bn, &rows, (in_ld > g_real && g_stride == g_real) ? in_ld : 0);
   if (rc) return rc;
   LGS_REQUIRE(!(bn && bn->partial) || rows == bn_partial_rows_t<T>(v, K, o_real),
               "conv forward: BatchNorm statistics rows differ from lgs_conv_bn_partial_rows (internal error)");
@@ -931,7 +935,7 @@ int clip_loss_forward_t(const void *feat, int64_t n, int c, const float *anchors
 #define LGS_CLIP(NCB, SC, D)                                                                                              \
   hipLaunchKernelGGL((k_conv_gather<T, 1, NCB, 4, 1, SC, D, 1>), grid, dim3(256), 0, s, v, f, c, nc,                      \
                      reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, (T *)nullptr, na, (const float *)nullptr, sim, \
-                     (const float *)nullptr, (unsigned)in_bytes64, (unsigned)w_bytes64, (int64_t)0, ce, BnEpi(), nc)
+                     (const float *)nullptr, (unsigned)in_bytes64, (unsigned)w_bytes64, (int64_t)0, ce, BnEpi(), nc, c)
   switch (ncb) {
     case 1: LGS_CLIP(1, (kF32 ? 4 : 8), (kF32 ? 4 : 8)); break;
     case 2: LGS_CLIP(2, (kF32 ? 2 : 4), (kF32 ? 3 : 4)); break;
@@ -1008,7 +1012,7 @@ int lgs_pack_weights_batch(const lgs_pack_desc *descs_device, int n, int64_t max
 
 int lgs_conv_forward(lgs_kmap *km, int transposed, const void *in, int cin, const float *weight, int cout,
                      const float *bias, void *out, int dtype, void *workspace, float *bn_partial, const float *bn_pivot,
-                     void *packed, int pack_mode, void *stream) {
+                     void *packed, int pack_mode, int in_row_stride, void *stream) {
   LGS_REQUIRE(km && weight && workspace, "lgs_conv_forward: null argument");
   LGS_REQUIRE(!(transposed && km->ks == 3), "transposed 3x3x3 convolution is not part of the model family");
   const View &v = transposed ? km->bwd : km->fwd;
@@ -1019,8 +1023,8 @@ int lgs_conv_forward(lgs_kmap *km, int transposed, const void *in, int cin, cons
   bn.partial = bn_partial; bn.pivot = bn_pivot;
   LGS_REQUIRE(!bn_partial || lgs_conv_bn_partial_rows(km, transposed, cout, dtype) > 0,
               "lgs_conv_forward: this launch shape produces no BatchNorm statistics (see lgs_conv_bn_partial_rows)");
-  if (dtype == LGS_F32) return conv_gather_op<float>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr, packed, pack_mode);
-  if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr, packed, pack_mode);
+  if (dtype == LGS_F32) return conv_gather_op<float>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr, packed, pack_mode, in_row_stride);
+  if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr, packed, pack_mode, in_row_stride);
   LGS_REQUIRE(false, "lgs_conv_forward: unknown dtype");
 }
 

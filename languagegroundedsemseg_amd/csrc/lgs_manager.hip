@@ -332,8 +332,14 @@ struct lgs_manager {
   hipStream_t last_stream = nullptr;
   std::vector<CoordMap> maps;
   std::vector<lgs_kmap *> kmaps;
-  std::vector<void *> allocs;
+  std::vector<void *> allocs;      // pool allocations (no arena yet, or the arena was too small)
   int *d_err = nullptr;
+  // arena: one device block per manager, bump-allocated (see "arena" below)
+  char *arena = nullptr;
+  size_t arena_cap = 0, arena_used = 0, arena_peak = 0;
+  struct Blk { size_t off, size; bool freed; };
+  std::vector<Blk> blks;           // live arena blocks in allocation order (a stack: freed blocks on top are popped)
+  size_t pool_live = 0, pool_peak = 0;
 };
 
 namespace {
@@ -365,28 +371,110 @@ int ensure_pool(int device) {
   LGS_HIP(hipMemPoolCreate(&pool, &props));
   uint64_t thr = UINT64_MAX;
   LGS_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr));
+  // blocks freed on a user stream (lgs_manager_destroy) are handed to the map stream only once that free has completed:
+  // the allocator must not buy reuse with a stream dependency on the compute stream's tail
+  int off = 0;
+  (void)hipMemPoolSetAttribute(pool, hipMemPoolReuseAllowInternalDependencies, &off);
   g_pool[device] = pool;
   return 0;
 }
-inline hipError_t pool_alloc(lgs_manager *m, void **q, size_t bytes, hipStream_t s);
+// ---- arena.  A manager makes ~150 device allocations per step; as stream-ordered pool calls each of them (and each
+// free when the manager dies) is a marker packet in a HIP stream, and freeing a manager cost ~3 ms of stream time per
+// step.  Instead every manager owns ONE block, bump-allocated on the host: allocation and release are pointer
+// arithmetic; temporaries are released as a stack (a freed block is reclaimed once everything above it is freed too --
+// all users of the arena run on the map stream, in order).  Blocks are recycled through a per-device FIFO: when a manager
+// dies its block is stamped with one event per user stream and queued; a new manager takes the OLDEST queued block (its
+// users finished a step ago, so the wait on its events is already satisfied) or, while fewer than two are queued,
+// allocates a new one sized to the largest need seen so far.  Steady state: three blocks in rotation, no allocator
+// call at all.  Whatever does not fit (first step, growing scenes) falls back to the private stream-ordered pool.
+struct ArenaBlock { char *base; size_t cap; std::vector<hipEvent_t> ready; };
+std::vector<ArenaBlock> g_arenas[64];   // FIFO of released blocks per device
+size_t g_arena_need[64] = {0};          // largest (arena peak + pool peak) any manager of this device has needed
 
-template <typename T>
-int dalloc(lgs_manager *m, T **p, int64_t count, hipStream_t s) {
-  void *q = nullptr;
-  size_t bytes = sizeof(T) * (size_t)(count > 0 ? count : 1);
-  LGS_HIP(pool_alloc(m, &q, bytes, s));
-  m->allocs.push_back(q);
-  *p = reinterpret_cast<T *>(q);
-  return 0;
-}
 inline hipError_t pool_alloc(lgs_manager *m, void **q, size_t bytes, hipStream_t s) {
   return hipMallocFromPoolAsync(q, bytes, m->pool, s);
 }
+int raw_alloc(lgs_manager *m, void **p, size_t bytes, hipStream_t s) {
+  bytes = (bytes + 255) / 256 * 256;
+  if (m->arena && m->arena_used + bytes <= m->arena_cap) {
+    *p = m->arena + m->arena_used;
+    m->blks.push_back({m->arena_used, bytes, false});
+    m->arena_used += bytes;
+    if (m->arena_used > m->arena_peak) m->arena_peak = m->arena_used;
+    return 0;
+  }
+  void *q = nullptr;
+  LGS_HIP(pool_alloc(m, &q, bytes, s));
+  m->allocs.push_back(q);
+  m->pool_live += bytes;
+  if (m->pool_live > m->pool_peak) m->pool_peak = m->pool_live;
+  *p = q;
+  return 0;
+}
+template <typename T>
+int dalloc(lgs_manager *m, T **p, int64_t count, hipStream_t s) {
+  void *q = nullptr;
+  if (raw_alloc(m, &q, sizeof(T) * (size_t)(count > 0 ? count : 1), s)) return 1;
+  *p = reinterpret_cast<T *>(q);
+  return 0;
+}
 int dfree_now(lgs_manager *m, void *q, hipStream_t s) {  // temp buffer: release early
+  char *c = reinterpret_cast<char *>(q);
+  if (m->arena && c >= m->arena && c < m->arena + m->arena_cap) {
+    const size_t off = (size_t)(c - m->arena);
+    for (size_t i = m->blks.size(); i-- > 0;)
+      if (m->blks[i].off == off) { m->blks[i].freed = true; break; }
+    while (!m->blks.empty() && m->blks.back().freed) { m->arena_used = m->blks.back().off; m->blks.pop_back(); }
+    return 0;
+  }
   for (size_t i = 0; i < m->allocs.size(); ++i)
     if (m->allocs[i] == q) { m->allocs[i] = m->allocs.back(); m->allocs.pop_back(); break; }
   LGS_HIP(hipFreeAsync(q, s));
   return 0;
+}
+// take a recycled block (or a new one) for a fresh manager; the map stream waits for the block's previous users
+int arena_acquire(lgs_manager *m) {
+  const int dev = m->device;
+  const size_t need = g_arena_need[dev];
+  if (need == 0) return 0;                       // first manager of the device: measure through the pool
+  std::vector<ArenaBlock> &q = g_arenas[dev];
+  // never the most recently released block (its users -- the previous step's backward -- are still running)
+  for (size_t i = 0; q.size() >= 2 && i + 1 < q.size(); ++i) {
+    if (q[i].cap >= need) {
+      ArenaBlock b = q[i];
+      q.erase(q.begin() + (long)i);
+      for (hipEvent_t e : b.ready) { (void)hipStreamWaitEvent(m->ms, e, 0); (void)hipEventDestroy(e); }
+      m->arena = b.base; m->arena_cap = b.cap;
+      return 0;
+    }
+    if (i == 0 && q.size() >= 4) {               // an undersized block at the head of a long queue: retire it
+      for (hipEvent_t e : q[0].ready) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); }
+      (void)hipFree(q[0].base);
+      q.erase(q.begin());
+      i = (size_t)-1;
+    }
+  }
+  const size_t cap = (need + need / 4 + (2u << 20)) / (2u << 20) * (2u << 20);
+  void *p = nullptr;
+  if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return 0; }   // no block: this manager uses the pool
+  m->arena = reinterpret_cast<char *>(p); m->arena_cap = cap;
+  return 0;
+}
+void arena_release(lgs_manager *m) {
+  const size_t need = m->arena_peak + m->pool_peak;
+  if (need > g_arena_need[m->device]) g_arena_need[m->device] = need;
+  if (!m->arena) return;
+  ArenaBlock b{m->arena, m->arena_cap, {}};
+  std::vector<hipStream_t> streams = m->users;
+  streams.push_back(m->ms);
+  for (hipStream_t u : streams) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
+      if (hipEventRecord(e, u) == hipSuccess) b.ready.push_back(e); else (void)hipEventDestroy(e);
+    }
+  }
+  g_arenas[m->device].push_back(b);
+  m->arena = nullptr;
 }
 void add_user(lgs_manager *m, hipStream_t caller) {
   for (hipStream_t u : m->users)
@@ -429,9 +517,9 @@ int scan_incl(lgs_manager *m, const int32_t *in, int32_t *out, int64_t n, hipStr
   size_t tb = 0;
   LGS_HIP(rocprim::inclusive_scan(nullptr, tb, in, out, (size_t)n, rocprim::plus<int32_t>(), s));
   void *tmp = nullptr;
-  LGS_HIP(pool_alloc(m, &tmp, tb ? tb : 16, s));
+  if (raw_alloc(m, &tmp, tb ? tb : 16, s)) return 1;
   LGS_HIP(rocprim::inclusive_scan(tmp, tb, in, out, (size_t)n, rocprim::plus<int32_t>(), s));
-  LGS_HIP(hipFreeAsync(tmp, s));
+  if (dfree_now(m, tmp, s)) return 1;
   return 0;
 }
 
@@ -466,6 +554,7 @@ int lgs_manager_create(int device, lgs_manager **out) {
   m->ms = g_map_stream[device];
   LGS_HIP(hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming));
   LGS_HIP(hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming));
+  arena_acquire(m);
   *out = m;
   return 0;
 }
@@ -473,11 +562,20 @@ int lgs_manager_create(int device, lgs_manager **out) {
 int lgs_manager_destroy(lgs_manager *m) {
   if (!m) return 0;
   DeviceGuard guard(m->device);
-  // every stream that read the maps must be done with them before the (stream-ordered) frees
-  for (hipStream_t u : m->users) {
-    if (hipEventRecord(m->ev_in, u) == hipSuccess) (void)hipStreamWaitEvent(m->ms, m->ev_in, 0);
+  // Every stream that read the maps must be done with them before the (stream-ordered) frees.  The frees are queued on
+  // one of the USER streams (after joining the others and the manager's last map work), not on the map stream: making the
+  // map stream wait for the users -- i.e. for the end of this step's backward -- would hold back the map construction of
+  // the NEXT step, which is queued on that stream and is meant to run during this backward (measured: +3.5 ms per step).
+  hipStream_t fs = m->users.empty() ? m->ms : m->users.back();
+  if (!m->users.empty()) {
+    for (hipStream_t u : m->users) {
+      if (u == fs) continue;
+      if (hipEventRecord(m->ev_in, u) == hipSuccess) (void)hipStreamWaitEvent(fs, m->ev_in, 0);
+    }
+    (void)hipStreamWaitEvent(fs, m->ev_ready, 0);   // the manager's own last map work (as recorded by its last publish)
   }
-  for (void *p : m->allocs) (void)hipFreeAsync(p, m->ms);
+  for (void *p : m->allocs) (void)hipFreeAsync(p, fs);   // pool fallbacks only (none in the steady state)
+  arena_release(m);                                      // the block goes back to the device's FIFO, stamped per user stream
   for (lgs_kmap *k : m->kmaps) delete k;
   (void)hipEventDestroy(m->ev_ready);
   (void)hipEventDestroy(m->ev_in);
@@ -513,9 +611,9 @@ int lgs_manager_insert(lgs_manager *m, const int32_t *coords, int64_t n, int64_t
     size_t tb = 0;
     LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, skeys, vals, svals, (size_t)n, 0, 64, s));
     void *tmp = nullptr;
-    LGS_HIP(pool_alloc(m, &tmp, tb ? tb : 16, s));
+    if (raw_alloc(m, &tmp, tb ? tb : 16, s)) return 1;
     LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, keys, skeys, vals, svals, (size_t)n, 0, 64, s));
-    LGS_HIP(hipFreeAsync(tmp, s));
+    if (dfree_now(m, tmp, s)) return 1;
   }
   hipLaunchKernelGGL(k_heads, nblk(n), 256, 0, s, skeys, n, ~0ull, head);
   hipLaunchKernelGGL(k_mark_first, nblk(n), 256, 0, s, svals, head, n, is_first);
@@ -650,9 +748,9 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
         size_t tb = 0;
         LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, 64, s));
         void *tmp = nullptr;
-        LGS_HIP(pool_alloc(m, &tmp, tb ? tb : 16, s));
+        if (raw_alloc(m, &tmp, tb ? tb : 16, s)) return 1;
         LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, 64, s));
-        LGS_HIP(hipFreeAsync(tmp, s));
+        if (dfree_now(m, tmp, s)) return 1;
       }
       hipLaunchKernelGGL(k_permute_map3, (unsigned)(ci.n_pad / 256), 256, 0, s, nbr_tmp, pmask, perm, ci.order, ci.n, ci.n_pad,
                          nbr, orow, mask);
@@ -692,9 +790,9 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
         size_t tb = 0;
         LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, kk, kks, pp, pps, (size_t)n, 0, 3, s));
         void *tmp = nullptr;
-        LGS_HIP(pool_alloc(m, &tmp, tb ? tb : 16, s));
+        if (raw_alloc(m, &tmp, tb ? tb : 16, s)) return 1;
         LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, kk, kks, pp, pps, (size_t)n, 0, 3, s));
-        LGS_HIP(hipFreeAsync(tmp, s));
+        if (dfree_now(m, tmp, s)) return 1;
       }
       hipLaunchKernelGGL(k_group_offsets, 1, 64, 0, s, cnt, goff, gsrc);
       hipLaunchKernelGGL(k_fill_i32, nblk(gp), 256, 0, s, g_nbr, gp, -1);
@@ -727,7 +825,7 @@ int lgs_kmap_export(lgs_kmap *km, int32_t *ek, int32_t *ein, int32_t *eout, void
   if (begin_from_caller(m, caller)) return 1;   // the output buffers were allocated on the caller's stream
   const View &v = km->fwd;
   int32_t *cnt;
-  LGS_HIP(pool_alloc(m, (void **)&cnt, sizeof(int32_t), s));
+  if (raw_alloc(m, (void **)&cnt, sizeof(int32_t), s)) return 1;
   LGS_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), s));
   if (v.n_pad > 0) {
     if (ek) hipLaunchKernelGGL(k_view_export, nblk(v.n_pad), 256, 0, s, v, cnt, ek, ein, eout);
@@ -736,7 +834,7 @@ int lgs_kmap_export(lgs_kmap *km, int32_t *ek, int32_t *ein, int32_t *eout, void
   int32_t h = 0;
   LGS_HIP(hipMemcpyAsync(&h, cnt, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   LGS_HIP(hipStreamSynchronize(s));
-  LGS_HIP(hipFreeAsync(cnt, s));
+  if (dfree_now(m, cnt, s)) return 1;
   *mcount = h;
   return publish(m, caller, true);
 }

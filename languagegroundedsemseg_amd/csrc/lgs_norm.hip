@@ -62,7 +62,7 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy,
                                                    const float *__restrict__ stats, const float *__restrict__ gamma,
                                                    const float *__restrict__ beta, int64_t n, int c, int relu,
-                                                   int64_t rows_per_block, float *__restrict__ scratch, int64_t dy_ld) {
+                                                   int64_t rows_per_block, float *__restrict__ scratch, int64_t dy_ld, int64_t y_ld) {
   constexpr int W = Vec<T>::W;
   const int G = c / W;              // channel groups per row
   const int RL = kNT / G;           // rows in flight per block iteration (G <= 256)
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, cons
         Vec<T>::load(x + o, xv[u]);
         if (MODE == 1) {
           Vec<T>::load(dy + (r + u * RL) * dy_ld + cg * W, gv[u]);
-          if (relu == 1) Vec<T>::load(y + o, yv[u]);
+          if (relu == 1) Vec<T>::load(y + (r + u * RL) * y_ld + cg * W, yv[u]);
         }
       }
 #pragma unroll
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kNT) void k_colreduce(const T *__restrict__ x, cons
       Vec<T>::load(x + o, xv);
       if (MODE == 1) {
         Vec<T>::load(dy + r * dy_ld + cg * W, gv);
-        if (relu == 1) Vec<T>::load(y + o, yv);
+        if (relu == 1) Vec<T>::load(y + r * y_ld + cg * W, yv);
       }
       accumulate(xv, gv, yv);
     }
@@ -279,7 +279,8 @@ __global__ void k_sync_combine(const float *__restrict__ all_stats, int world, i
 template <typename T>
 __global__ __launch_bounds__(kNT) void k_bn_apply(const T *__restrict__ x, const T *__restrict__ res, int64_t n, int c,
                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                  const float *__restrict__ stats, int relu, T *__restrict__ y) {
+                                                  const float *__restrict__ stats, int relu, T *__restrict__ y, int64_t y_ld) {
+  // y_ld = row stride of the output (elements): > c when y is a column slice of a wider buffer (zero-copy ME.cat)
   constexpr int W = Vec<T>::W;
   const int G = c / W, RL = kNT / G;
   const int cg = threadIdx.x % G, rl = threadIdx.x / G;
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(kNT) void k_bn_apply(const T *__restrict__ x, const
       if (res) o += ra[k];
       xa[k] = (relu && o < 0.f) ? 0.f : o;
     }
-    Vec<T>::store(y + r * c + cg * W, xa);
+    Vec<T>::store(y + r * y_ld + cg * W, xa);
     if (two) {
 #pragma unroll
       for (int k = 0; k < W; ++k) {
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(kNT) void k_bn_apply(const T *__restrict__ x, const
         if (res) o += rb[k];
         xb[k] = (relu && o < 0.f) ? 0.f : o;
       }
-      Vec<T>::store(y + r2 * c + cg * W, xb);
+      Vec<T>::store(y + r2 * y_ld + cg * W, xb);
     }
   }
 }
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(kNT) void k_bn_bwd_apply(const T *__restrict__ x, c
                                                       const float *__restrict__ beta,
                                                       const float *__restrict__ stats, const float *__restrict__ sums,
                                                       float inv_n, int relu, T *__restrict__ dx, T *__restrict__ dres,
-                                                      int64_t dy_ld, const float *__restrict__ inv_n_dev) {
+                                                      int64_t dy_ld, const float *__restrict__ inv_n_dev, int64_t y_ld) {
   constexpr int W = Vec<T>::W;
   const int G = c / W, RL = kNT / G;
   const int cg = threadIdx.x % G, rl = threadIdx.x / G;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(kNT) void k_bn_bwd_apply(const T *__restrict__ x, c
     Vec<T>::load(dy + r * dy_ld + cg * W, gv);
     if (relu == 1) {
       float yv[W];
-      Vec<T>::load(y + o, yv);
+      Vec<T>::load(y + r * y_ld + cg * W, yv);
 #pragma unroll
       for (int k = 0; k < W; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
     } else if (relu == 2) {
@@ -392,7 +393,7 @@ int stats_partials(const T *x, int64_t n, int c, const float *partials, int part
   int64_t rpb;
   const int nb = reduce_blocks(n, &rpb);
   hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, n, c, 0,
-                     rpb, scratch, (int64_t)c);
+                     rpb, scratch, (int64_t)c, (int64_t)c);
   *nb_out = nb;
   return 0;
 }
@@ -400,7 +401,7 @@ int stats_partials(const T *x, int64_t n, int c, const float *partials, int part
 template <typename T>
 int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const float *beta, float eps, float momentum,
                  float *rm, float *rv, long long *nbt, const void *res, int relu, void *yv, float *stats, void *workspace,
-                 hipStream_t s, const float *partials, int partial_rows, const float *pivot) {
+                 hipStream_t s, const float *partials, int partial_rows, const float *pivot, int64_t y_ld) {
   constexpr int W = Vec<T>::W;
   LGS_REQUIRE(c % W == 0 && c / W <= kNT && c <= 2048, "lgs_bn_forward: channel count unsupported");
   int nb = 0;
@@ -413,7 +414,7 @@ int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const flo
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
     hipLaunchKernelGGL((k_bn_apply<T>), grid, kNT, 0, s, x, reinterpret_cast<const T *>(res), n, c, gamma, beta, stats, relu,
-                       reinterpret_cast<T *>(yv));
+                       reinterpret_cast<T *>(yv), y_ld);
   }
   LGS_HIP(hipGetLastError());
   return 0;
@@ -422,7 +423,7 @@ int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const flo
 template <typename T>
 int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *gamma, const float *beta,
                   const float *stats, int relu, void *dxv, void *dresv, float *dgamma, float *dbeta, void *workspace,
-                  hipStream_t s, int64_t dy_ld) {
+                  hipStream_t s, int64_t dy_ld, int64_t y_ld) {
   constexpr int W = Vec<T>::W;
   LGS_REQUIRE(c % W == 0 && c / W <= kNT && c <= 2048, "lgs_bn_backward: channel count unsupported");
   int64_t rpb;
@@ -430,13 +431,13 @@ int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, in
   float *scratch = reinterpret_cast<float *>(workspace);
   float *sums = scratch + (size_t)2 * c * nb;
   const T *x = reinterpret_cast<const T *>(xv), *y = reinterpret_cast<const T *>(yv), *dy = reinterpret_cast<const T *>(dyv);
-  hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, x, y, dy, stats, gamma, beta, n, c, relu, rpb, scratch, dy_ld);
+  hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, x, y, dy, stats, gamma, beta, n, c, relu, rpb, scratch, dy_ld, y_ld);
   hipLaunchKernelGGL(k_fold_bwd, (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, nb, c, dgamma, dbeta, sums);
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
     hipLaunchKernelGGL((k_bn_bwd_apply<T>), grid, kNT, 0, s, x, y, dy, n, c, gamma, beta, stats, sums, n > 0 ? 1.f / (float)n : 0.f, relu, reinterpret_cast<T *>(dxv),
-                       reinterpret_cast<T *>(dresv), dy_ld, (const float *)nullptr);
+                       reinterpret_cast<T *>(dresv), dy_ld, (const float *)nullptr, y_ld);
   }
   LGS_HIP(hipGetLastError());
   return 0;
@@ -465,7 +466,7 @@ int bn_apply_t(const void *xv, int64_t n, int c, const float *gamma, const float
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
     hipLaunchKernelGGL((k_bn_apply<T>), grid, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(res), n, c,
-                       gamma, beta, stats, relu, reinterpret_cast<T *>(yv));
+                       gamma, beta, stats, relu, reinterpret_cast<T *>(yv), (int64_t)c);
   }
   LGS_HIP(hipGetLastError());
   return 0;
@@ -480,7 +481,7 @@ int bn_bwd_reduce_t(const void *xv, const void *yv, const void *dyv, int64_t n, 
   float *scratch = reinterpret_cast<float *>(workspace);
   float *tmp = scratch + (size_t)2 * c * nb;  // dgamma/dbeta land here when the caller does not want them
   hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
-                     reinterpret_cast<const T *>(dyv), stats, gamma, beta, n, c, relu, rpb, scratch, (int64_t)c);
+                     reinterpret_cast<const T *>(dyv), stats, gamma, beta, n, c, relu, rpb, scratch, (int64_t)c, (int64_t)c);
   hipLaunchKernelGGL(k_fold_bwd, (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, nb, c, dgamma ? dgamma : tmp + c, dbeta ? dbeta : tmp, sums);
   LGS_HIP(hipGetLastError());
   return 0;
@@ -496,7 +497,7 @@ int bn_bwd_apply_t(const void *xv, const void *yv, const void *dyv, int64_t n, i
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
     hipLaunchKernelGGL((k_bn_bwd_apply<T>), grid, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
                        reinterpret_cast<const T *>(dyv), n, c, gamma, beta, stats, sums, inv_n_total, relu, reinterpret_cast<T *>(dxv),
-                       reinterpret_cast<T *>(dresv), (int64_t)c, inv_n_dev);
+                       reinterpret_cast<T *>(dresv), (int64_t)c, inv_n_dev, (int64_t)c);
   }
   LGS_HIP(hipGetLastError());
   return 0;
@@ -561,17 +562,20 @@ int64_t lgs_bn_workspace_bytes(int64_t n, int c) {
 int lgs_bn_forward(const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps, float momentum,
                    float *running_mean, float *running_var, int64_t *num_batches_tracked, const void *residual, int relu,
                    void *y, float *stats, int dtype, void *workspace, const float *conv_partials, int conv_partial_rows,
-                   const float *pivot, void *stream) {
+                   const float *pivot, int64_t y_row_stride, void *stream) {
   LGS_REQUIRE(x && y && gamma && beta && stats && workspace, "lgs_bn_forward: null argument");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == LGS_F32) return bn_forward_t<float>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), residual, relu, y, stats, workspace, s, conv_partials, conv_partial_rows, pivot);
-  if (dtype == LGS_BF16) return bn_forward_t<bf16_t>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), residual, relu, y, stats, workspace, s, conv_partials, conv_partial_rows, pivot);
+  const int64_t y_ld = y_row_stride > 0 ? y_row_stride : c;
+  LGS_REQUIRE(y_ld >= c && y_ld % (dtype == LGS_BF16 ? 8 : 4) == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0,
+              "lgs_bn_forward: y rows must start 16-byte aligned (row stride a multiple of 16 bytes)");
+  if (dtype == LGS_F32) return bn_forward_t<float>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), residual, relu, y, stats, workspace, s, conv_partials, conv_partial_rows, pivot, y_ld);
+  if (dtype == LGS_BF16) return bn_forward_t<bf16_t>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), residual, relu, y, stats, workspace, s, conv_partials, conv_partial_rows, pivot, y_ld);
   LGS_REQUIRE(false, "lgs_bn_forward: unknown dtype");
 }
 
 int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t dy_row_stride, int64_t n, int c, const float *gamma,
                     const float *beta, const float *stats, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta,
-                    int dtype, void *workspace, void *stream) {
+                    int dtype, void *workspace, int64_t y_row_stride, void *stream) {
   LGS_REQUIRE(x && dy && dx && gamma && stats && dgamma && dbeta && workspace, "lgs_bn_backward: null argument");
   const int64_t dy_ld = dy_row_stride > 0 ? dy_row_stride : c;
   LGS_REQUIRE(dy_ld >= c && dy_ld % (dtype == LGS_BF16 ? 8 : 4) == 0 &&
@@ -580,8 +584,11 @@ int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t dy_row
   LGS_REQUIRE(relu != 1 || y, "lgs_bn_backward: relu mode 1 needs the forward output");
   LGS_REQUIRE(relu != 2 || beta, "lgs_bn_backward: relu mode 2 needs beta");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == LGS_F32) return bn_backward_t<float>(x, y, dy, n, c, gamma, beta, stats, relu, dx, dresidual, dgamma, dbeta, workspace, s, dy_ld);
-  if (dtype == LGS_BF16) return bn_backward_t<bf16_t>(x, y, dy, n, c, gamma, beta, stats, relu, dx, dresidual, dgamma, dbeta, workspace, s, dy_ld);
+  const int64_t y_ld = y_row_stride > 0 ? y_row_stride : c;
+  LGS_REQUIRE(!y || (y_ld >= c && y_ld % (dtype == LGS_BF16 ? 8 : 4) == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0),
+              "lgs_bn_backward: y rows must start 16-byte aligned (row stride a multiple of 16 bytes)");
+  if (dtype == LGS_F32) return bn_backward_t<float>(x, y, dy, n, c, gamma, beta, stats, relu, dx, dresidual, dgamma, dbeta, workspace, s, dy_ld, y_ld);
+  if (dtype == LGS_BF16) return bn_backward_t<bf16_t>(x, y, dy, n, c, gamma, beta, stats, relu, dx, dresidual, dgamma, dbeta, workspace, s, dy_ld, y_ld);
   LGS_REQUIRE(false, "lgs_bn_backward: unknown dtype");
 }
 

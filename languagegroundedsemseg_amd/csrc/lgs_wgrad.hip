@@ -462,6 +462,7 @@ struct PsArgs {
   const bf16_t *G;      // gathered operand  [rows][cg_real]  (rows addressed through v.nbr)
   const bf16_t *S;      // stationary operand [rows][cs_real] (rows addressed through v.out_row / identity)
   int cg_real, cs_real, cg_pad, cs_pad, n_cg, n_cs;
+  int g_ld, s_ld;       // row strides (elements) of the two operands: > channels for a column slice of a wider buffer
   int n_lanes, chunks_per_lane, n_chunks, xcd_map;
   float *partial;       // [n_lanes][K][cg_pad][cs_pad]
   unsigned g_bytes, s_bytes, nbr_bytes, orow_bytes;
@@ -509,7 +510,7 @@ __device__ __forceinline__ void ps_wave(const PsArgs &a, char *smem, const int w
   const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(v.out_row ? v.out_row : v.nbr), 0,
                                                                         (int)(v.out_row ? a.orow_bytes : 0u), 0x00020000);
   const bool has_orow = v.out_row != nullptr;
-  const unsigned g_row_b = (unsigned)a.cg_real * 2u, s_row_b = (unsigned)a.cs_real * 2u;
+  const unsigned g_row_b = (unsigned)a.g_ld * 2u, s_row_b = (unsigned)a.s_ld * 2u;
   // gather: lane -> (row lane/4 of the 16-position group, 16-byte piece lane%4 of the 64-byte channel slice)
   const int g_row = lane >> 2;
   const unsigned g_ch = (cg0 + (lane & 3) * 8 + 8 <= a.cg_real) ? (unsigned)(cg0 + (lane & 3) * 8) * 2u : kOOB;
@@ -987,18 +988,21 @@ int launch_wgrad_ps(const PsArgs &a, const PsPlan &p, hipStream_t s) {
 // 2^3 view); transposed = 0: gathered operand = in (rows of v's input side), stationary = gout;  transposed = 1 (the
 // transposed conv that reuses the strided conv's map): gathered = gout (fine rows), stationary = in (coarse rows).
 int conv_wgrad_ps(const View &v, int transposed, const bf16_t *in, int cin, const bf16_t *go, int cout, float *gw, void *workspace,
-                  hipStream_t s, bool *done) {
+                  hipStream_t s, bool *done, int in_ld) {
   *done = false;
   if (!ps_enabled()) return 0;
   const int cg = transposed ? cout : cin, cs = transposed ? cin : cout;
   const PsPlan p = ps_plan(v, cg, cs);
   if (!p.ok) return 0;
   const int64_t g_rows = v.n_in, s_rows = v.n_out;
-  const uint64_t g_b = (uint64_t)g_rows * cg * 2, s_b = (uint64_t)s_rows * cs * 2, n_b = (uint64_t)v.KS * v.n_pad * 4, o_b = (uint64_t)v.n_pad * 4;
+  const int g_ld = transposed ? cg : (in_ld > 0 ? in_ld : cg), s_ld = transposed ? (in_ld > 0 ? in_ld : cs) : cs;
+  if ((g_ld * 2) % 16 != 0 || (s_ld * 2) % 16 != 0) return 0;
+  const uint64_t g_b = (uint64_t)g_rows * g_ld * 2, s_b = (uint64_t)s_rows * s_ld * 2, n_b = (uint64_t)v.KS * v.n_pad * 4, o_b = (uint64_t)v.n_pad * 4;
   if (!(g_b < 0xfffff000ull && s_b < 0xfffff000ull && n_b < 0xfffff000ull)) return 0;   // beyond the 32-bit descriptor path
   PsArgs a;
   a.v = v; a.v.mirror = 0;
   a.G = transposed ? go : in; a.S = transposed ? in : go;
+  a.g_ld = g_ld; a.s_ld = s_ld;
   a.cg_real = cg; a.cs_real = cs; a.cg_pad = p.cg_pad; a.cs_pad = p.cs_pad; a.n_cg = p.n_cg; a.n_cs = p.n_cs;
   a.n_lanes = p.n_lanes; a.chunks_per_lane = p.cpl; a.n_chunks = p.n_chunks; a.xcd_map = p.xcd_map;
   a.partial = reinterpret_cast<float *>(workspace);
@@ -1092,7 +1096,7 @@ using namespace lgs;
 extern "C" {
 
 int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const void *grad_out, int cout,
-                   float *grad_weight, int dtype, void *workspace, void *stream) {
+                   float *grad_weight, int dtype, void *workspace, int in_row_stride, void *stream) {
   LGS_REQUIRE(km && grad_weight && workspace, "lgs_conv_wgrad: null argument");
   LGS_REQUIRE(!(transposed && km->ks == 3), "transposed 3x3x3 convolution is not part of the model family");
   const View &v = transposed ? km->bwd : km->fwd;  // same view as the forward
@@ -1103,14 +1107,16 @@ int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const 
     LGS_HIP(hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)km->K * cin * cout, s));
     return 0;
   }
+  LGS_REQUIRE(dtype == LGS_BF16 || in_row_stride == 0 || in_row_stride == cin, "lgs_conv_wgrad: strided input needs bf16");
   if (dtype == LGS_F32) return conv_wgrad_f32path<float>(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
   if (dtype == LGS_BF16) {
     if (km->fwd.n_pad > 0 && (km->ks == 3 || km->ks == 2)) {
       bool done = false;
       int rc = conv_wgrad_ps(km->fwd, transposed, reinterpret_cast<const bf16_t *>(in), cin, reinterpret_cast<const bf16_t *>(grad_out),
-                             cout, grad_weight, workspace, s, &done);
+                             cout, grad_weight, workspace, s, &done, in_row_stride);
       if (rc || done) return rc;
     }
+    LGS_REQUIRE(in_row_stride == 0 || in_row_stride == cin, "lgs_conv_wgrad: a strided input is only supported by the position-stationary bf16 kernel");
     if (cout % 8 == 0) return conv_wgrad_bf16(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
     return conv_wgrad_f32path<bf16_t>(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
   }

@@ -70,7 +70,7 @@ def lib():
         "lgs_manager_get_coords": [vp, ci, vp, vp],
         "lgs_manager_kernel_map": [vp, ci, ci, ci, vp, pvp],
         "lgs_kmap_export": [vp, vp, vp, vp, vp, pi64],
-        "lgs_conv_forward": [vp, ci, vp, ci, vp, ci, vp, vp, ci, vp, vp, vp, vp, ci, vp],
+        "lgs_conv_forward": [vp, ci, vp, ci, vp, ci, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp],
         "lgs_conv_pack_desc": [vp, ci, ci, ci, ci, ci, ctypes.POINTER(PackDesc)],
         "lgs_pack_weights_batch": [vp, ci, i64, vp],
         "lgs_conv_bn_partial_rows": [vp, ci, ci, ci],
@@ -79,9 +79,9 @@ def lib():
         "lgs_cluster": [vp, vp, vp, i64, cf, ci, vp, ctypes.POINTER(ctypes.c_int32), vp, vp],
         "lgs_voxelize": [vp, i64, ctypes.POINTER(ctypes.c_double), ci, vp, vp],
         "lgs_label_vote": [vp, i64, vp, vp, i64, i64, vp, vp],
-        "lgs_conv_wgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp],
-        "lgs_bn_forward": [vp, i64, ci, vp, vp, cf, cf, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, vp, vp],
-        "lgs_bn_backward": [vp, vp, vp, i64, i64, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp],
+        "lgs_conv_wgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp],
+        "lgs_bn_forward": [vp, i64, ci, vp, vp, cf, cf, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, vp, i64, vp],
+        "lgs_bn_backward": [vp, vp, vp, i64, i64, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, i64, vp],
         "lgs_bn_stats": [vp, i64, ci, vp, ci, vp, vp, ci, vp, vp],
         "lgs_bn_apply": [vp, i64, ci, vp, vp, vp, vp, ci, vp, ci, vp],
         "lgs_bn_backward_reduce": [vp, vp, vp, i64, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp],
@@ -106,7 +106,7 @@ def lib():
     L.lgs_clip_workspace_bytes.argtypes = [ci, ci, ci]
     L.lgs_clip_loss_workspace_bytes.restype = i64
     L.lgs_clip_loss_workspace_bytes.argtypes = [ci, ci, ci]
-    if L.lgs_abi_version() != 3:
+    if L.lgs_abi_version() != 4:
         raise RuntimeError("liblgs_engine.so ABI version mismatch")
     _lib = L
     return L

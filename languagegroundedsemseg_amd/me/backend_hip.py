@@ -6,6 +6,7 @@ raises RuntimeError.
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -44,6 +45,16 @@ def get_packed():
     if _PACKED is None:
         _PACKED = PackedWeights()
     return _PACKED
+
+
+def _row_strided(t, c):
+    """row stride (elements) if `t` [n, c] is a column slice of a wider row-major tensor the kernels can read in place
+    (16-byte aligned rows), else None"""
+    if t.dim() == 2 and t.shape[1] == c and t.stride(1) == 1 and t.stride(0) > c:
+        e = t.element_size()
+        if (t.stride(0) * e) % 16 == 0 and t.data_ptr() % 16 == 0:
+            return t.stride(0)
+    return None
 
 
 def _ws(nbytes, device):
@@ -139,9 +150,12 @@ class HipKernelMap:
         produce them) -> (out, (partials [rows, 2, cout], pivot) | None)"""
         _require_dev(x, "features")
         L = engine.lib()
-        x = x.contiguous()
         w = weight.detach().reshape(self.K, -1, weight.shape[-1]).contiguous().float()
         cin, cout = w.shape[1], w.shape[2]
+        # the skip half of a zero-copy ME.cat is a column slice of the concat buffer: gathered in place through a row stride
+        ld = _row_strided(x, cin) if (cin % (8 if x.dtype == torch.bfloat16 else 4) == 0 and cout % 4 == 0) else None
+        if ld is None:
+            x = x.contiguous()
         n_in, n_out = self._rows(transposed)
         assert x.shape[0] == n_in and x.shape[1] == cin, (x.shape, n_in, cin)
         dt = _dtype_code(x)
@@ -157,7 +171,7 @@ class HipKernelMap:
             piv = bn_pivot if part is not None else None
             pk, mode = get_packed().lookup(pack_cache, self, 0, transposed, weight, w, cin, cout, dt)
             engine.check(L.lgs_conv_forward(self.h, int(transposed), _ptr(x), cin, _ptr(w), cout, _ptr(b), _ptr(out), dt,
-                                            _ptr(ws), _ptr(part), _ptr(piv), _ptr(pk), int(mode), _stream()))
+                                            _ptr(ws), _ptr(part), _ptr(piv), _ptr(pk), int(mode), int(ld or 0), _stream()))
         if want_bn_stats:
             return out, ((part, piv) if part is not None else None)
         return out
@@ -181,8 +195,12 @@ class HipKernelMap:
     def conv_wgrad(self, x, gout, transposed, out=None):
         """-> grad_weight [K,cin,cout] fp32; written straight into `out` (e.g. a view of a gradient bucket) if given"""
         L = engine.lib()
-        x, gout = x.contiguous(), gout.contiguous()
+        gout = gout.contiguous()
         cin, cout = x.shape[1], gout.shape[1]
+        # strided input (see conv_forward): only the position-stationary bf16 kernel reads it in place
+        ld = _row_strided(x, cin) if (x.dtype == torch.bfloat16 and self.ks in (2, 3) and cin % 8 == 0 and cout % 8 == 0) else None
+        if ld is None:
+            x = x.contiguous()
         dt = _dtype_code(x)
         assert gout.dtype == x.dtype
         with torch.cuda.device(x.device):
@@ -193,7 +211,7 @@ class HipKernelMap:
                 gw = torch.empty((self.K, cin, cout), dtype=torch.float32, device=x.device)
             ws = _ws(L.lgs_conv_workspace_bytes(self.h, cin, cout, dt, 2), x.device)
             engine.check(L.lgs_conv_wgrad(self.h, int(transposed), _ptr(x), cin, _ptr(gout), cout, _ptr(gw), dt, _ptr(ws),
-                                          _stream()))
+                                          int(ld or 0), _stream()))
         return gw
 
 
@@ -208,15 +226,22 @@ class HipManager:
         h = _vp(None)
         engine.check(engine.lib().lgs_manager_create(self.device.index, ctypes.byref(h)))
         self.h = h
+        self._pid = os.getpid()
         self._sizes = {}
-        self._kmaps = {}
+        # kernel-map handles are held WEAKLY here (they hold the manager strongly: autograd contexts keep a map -- and
+        # through it the manager -- alive until backward has run): no reference cycle, so the manager and its device
+        # memory are released by reference counting the moment the step's tensors and graph are gone, with or without
+        # the cyclic garbage collector (bench.py disables it inside the timed region)
+        self._kmaps = weakref.WeakValueDictionary()
         self._coords = {}
 
     def __del__(self):
         try:
-            if getattr(self, "h", None):
+            # never touch HIP from a forked child (multiprocessing helpers inherit live Python objects: destroying the
+            # parent's manager there segfaults)
+            if getattr(self, "h", None) and getattr(self, "_pid", None) == os.getpid():
                 engine.lib().lgs_manager_destroy(self.h)
-                self.h = None
+            self.h = None
         except Exception:
             pass
 
@@ -264,17 +289,21 @@ class HipManager:
 
     def kernel_map(self, in_key, out_key, ks):
         k = (in_key, out_key, ks)
-        if k not in self._kmaps:
-            h = _vp(None)
+        km = self._kmaps.get(k)
+        if km is None:
+            h = _vp(None)     # the engine caches the map itself: a second request returns the same handle at no cost
             with torch.cuda.device(self.device):
                 engine.check(engine.lib().lgs_manager_kernel_map(self.h, in_key, out_key, ks, _stream(), ctypes.byref(h)))
-            self._kmaps[k] = HipKernelMap(self, h, in_key, out_key, ks)
-        return self._kmaps[k]
+            km = HipKernelMap(self, h, in_key, out_key, ks)
+            self._kmaps[k] = km
+        return km
 
 
 class HipBackend:
     name = "hip"
     bn_counts_batches = True    # lgs_bn_forward increments num_batches_tracked itself
+    # lgs_bn_forward can write its output into a column slice of a wider buffer (zero-copy ME.cat; LGS_NO_ZERO_COPY_CAT=1: A/B knob)
+    bn_out_into = os.environ.get("LGS_NO_ZERO_COPY_CAT") is None
     # lgs_conv_forward can emit the following BatchNorm's statistics from its epilogue -- measured SLOWER in the step (31.5 vs 30.9 ms: the epilogue work on every conv costs more than the skipped column reduction saves), so off unless LGS_CONV_BN_STATS=1
     conv_bn_stats = os.environ.get("LGS_CONV_BN_STATS") == "1"
 
@@ -297,23 +326,32 @@ class HipBackend:
 
     # ---- fused BN(+residual)(+ReLU): lgs_bn_forward / lgs_bn_backward
     def bn_forward(self, x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, num_batches_tracked=None,
-                   conv_stats=None):
-        """conv_stats = (partials, pivot) from conv_forward(want_bn_stats=True): the statistics pass over x is skipped"""
+                   conv_stats=None, out_into=None):
+        """conv_stats = (partials, pivot) from conv_forward(want_bn_stats=True): the statistics pass over x is skipped.
+        out_into = (buffer [n, C_total], column offset): y is written straight into that column slice (zero-copy ME.cat)
+        and returned as a strided view of the buffer."""
         _require_dev(x, "features")
         L = engine.lib()
         x = x.contiguous()
         n, c = x.shape
         dt = _dtype_code(x)
         part, piv = conv_stats if conv_stats is not None else (None, None)
+        y_ld = 0
         with torch.cuda.device(x.device):
-            y = torch.empty_like(x)
+            if out_into is not None:
+                buf, off = out_into
+                y = buf[:, off:off + c]
+                y_ld = buf.stride(0)
+                assert buf.dtype == x.dtype and buf.shape[0] == n and (y_ld * x.element_size()) % 16 == 0 and y.data_ptr() % 16 == 0
+            else:
+                y = torch.empty_like(x)
             stats = torch.empty(2 * c, dtype=torch.float32, device=x.device)
             res = residual.contiguous() if residual is not None else None
             ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
             engine.check(L.lgs_bn_forward(_ptr(x), n, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
                                           _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(res), int(relu), _ptr(y),
                                           _ptr(stats), dt, _ptr(ws), _ptr(part), int(part.shape[0]) if part is not None else 0,
-                                          _ptr(piv), _stream()))
+                                          _ptr(piv), int(y_ld), _stream()))
         return y, stats
 
     def bn_backward(self, x, y, dy, gamma, beta, stats, relu, want_residual, dgamma_out=None, dbeta_out=None):
@@ -329,14 +367,19 @@ class HipBackend:
         else:
             dy = dy.contiguous()
             dy_ld = c
+        y_ld = 0
+        if y is not None:
+            y_ld = _row_strided(y, c) or 0
+            if y_ld == 0:
+                y = y.contiguous()
         with torch.cuda.device(x.device):
-            dx = torch.empty_like(x)
-            dres = torch.empty_like(x) if want_residual else None
+            dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+            dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_residual else None
             dgamma = dgamma_out if dgamma_out is not None else torch.empty(c, dtype=torch.float32, device=x.device)
             dbeta = dbeta_out if dbeta_out is not None else torch.empty(c, dtype=torch.float32, device=x.device)
             ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
             engine.check(L.lgs_bn_backward(_ptr(x), _ptr(y), _ptr(dy), int(dy_ld), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), int(relu), _ptr(dx),
-                                           _ptr(dres), _ptr(dgamma), _ptr(dbeta), dt, _ptr(ws), _stream()))
+                                           _ptr(dres), _ptr(dgamma), _ptr(dbeta), dt, _ptr(ws), int(y_ld), _stream()))
         return dx, dres, dgamma, dbeta
 
     # ---- the same op in halves (SyncBN: statistics are exchanged between ranks in the middle)

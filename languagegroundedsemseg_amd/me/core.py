@@ -327,4 +327,24 @@ def cat(*sparse_tensors):
     first = sparse_tensors[0]
     for s in sparse_tensors[1:]:
         first._check(s)
+    if len(sparse_tensors) == 2:
+        a, b = (getattr(t, "_cat_slot", None) for t in sparse_tensors)
+        # zero-copy: both halves were written straight into one [N, C1 + C2] buffer by their norms (me.modules)
+        if (a is not None and b is not None and a.buf is b.buf and a.off == 0 and b.off == a.width
+                and a.width + b.width == a.buf.shape[1] and sparse_tensors[0].F.data_ptr() == a.buf.data_ptr()):
+            return first._like(_CatViewFunction.apply(sparse_tensors[0].F, sparse_tensors[1].F, a))
     return first._like(torch.cat([s.F for s in sparse_tensors], dim=1))
+
+
+class _CatViewFunction(torch.autograd.Function):
+    """ME.cat of two tensors that already live side by side in one buffer: forward returns the buffer, backward hands
+    each input its column slice of the gradient (read in place by the consumers' row-stride support)."""
+
+    @staticmethod
+    def forward(ctx, a, b, slot):
+        ctx.c1 = a.shape[1]
+        return slot.buf.view(slot.buf.shape)      # a fresh tensor object over the same storage (not an input)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.c1], g[:, ctx.c1:], None

@@ -234,10 +234,14 @@ class FusedBatchNormFunction(torch.autograd.Function):
     """y = relu?(BN(x) (+ residual)) with batch statistics, one engine call each way."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, backend, nbt=None, conv_stats=None):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, backend, nbt=None, conv_stats=None,
+                out_into=None):
         ctx.gparam = gamma if isinstance(gamma, torch.nn.Parameter) else None
         ctx.bparam = beta if isinstance(beta, torch.nn.Parameter) else None
-        if conv_stats is not None:
+        if out_into is not None:       # _CatSlot: y goes straight into a column slice of the concat buffer (not a tensor input)
+            y, stats = backend.bn_forward(x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, nbt,
+                                          conv_stats=conv_stats, out_into=(out_into.buf, out_into.off))
+        elif conv_stats is not None:
             y, stats = backend.bn_forward(x, gamma, beta, eps, momentum, running_mean, running_var, residual, relu, nbt,
                                           conv_stats=conv_stats)
         elif nbt is not None:
@@ -266,8 +270,16 @@ class FusedBatchNormFunction(torch.autograd.Function):
         dx, dres, dgamma, dbeta = ctx.backend.bn_backward(x, y, dy, gamma, beta, stats, ctx.relu_mode,
                                                           ctx.has_res and ctx.needs_input_grad[3], gview, bview)
         if gview is not None:
-            return dx, gview, bview, dres, None, None, None, None, None, None, None, None
-        return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), dres, None, None, None, None, None, None, None, None
+            return dx, gview, bview, dres, None, None, None, None, None, None, None, None, None
+        return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), dres, None, None, None, None, None, None, None, None, None
+
+
+class _CatSlot:
+    """where a norm writes its output for a zero-copy ME.cat: column offset `off` of the [N, C_total] concat buffer `buf`
+    (a plain Python object on purpose: autograd must not see the buffer as a tensor input of the norm)"""
+
+    def __init__(self, buf, off, width):
+        self.buf, self.off, self.width = buf, off, width
 
 
 class EvalBatchNormFunction(torch.autograd.Function):
@@ -304,9 +316,14 @@ class MinkowskiBatchNorm(nn.Module):
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
                                  track_running_stats=track_running_stats)
 
-    def forward(self, input, relu=False, residual=None):
+    def forward(self, input, relu=False, residual=None, cat_up=0, cat_into=None):
         """`relu` / `residual` are extensions the build's own models use to fuse the whole
-        BN -> (+residual) -> ReLU chain into one kernel; reference code calls forward(input)."""
+        BN -> (+residual) -> ReLU chain into one kernel; reference code calls forward(input).
+        Zero-copy ME.cat(up, skip) (res16unet.py:237,247,257,267): the norm that produces the SKIP tensor is called with
+        cat_up = channels of the future `up` half: it allocates the [N, cat_up + C] concat buffer and writes its output into
+        the right-hand columns; the norm that produces `up` is called with cat_into = that skip tensor and writes into the
+        left-hand columns; ME.cat then returns the buffer itself.  Both are hints: paths that cannot honour them (eval
+        mode, SyncBN, CPU oracle backend) return ordinary tensors and ME.cat copies as before."""
         bn = self.bn
         backend = get_backend()
         x = input.F
@@ -322,7 +339,23 @@ class MinkowskiBatchNorm(nn.Module):
             cs = getattr(input, "_bn_stats", None)
             if cs is not None and (cs[1] is not None) != (rm is not None):
                 cs = None                                  # pivot convention mismatch (cannot happen for the conv's own bn)
-            y = FusedBatchNormFunction.apply(x, bn.weight, bn.bias, res, rm, rv, bn.eps, bn.momentum, relu, backend, nbt, cs)
+            slot = None
+            c = x.shape[1]
+            al = 8 if x.dtype == torch.bfloat16 else 4
+            if getattr(backend, "bn_out_into", False) and x.is_cuda and type(self) is MinkowskiBatchNorm:
+                if cat_up > 0 and cat_up % al == 0 and c % al == 0:
+                    buf = torch.empty((x.shape[0], cat_up + c), dtype=x.dtype, device=x.device)
+                    slot = _CatSlot(buf, cat_up, c)
+                elif cat_into is not None:
+                    other = getattr(cat_into, "_cat_slot", None)
+                    if (other is not None and other.off == c and other.buf.shape[0] == x.shape[0] and other.buf.dtype == x.dtype
+                            and not getattr(other, "taken", False)):
+                        slot = _CatSlot(other.buf, 0, c)
+                        other.taken = True
+            y = FusedBatchNormFunction.apply(x, bn.weight, bn.bias, res, rm, rv, bn.eps, bn.momentum, relu, backend, nbt, cs, slot)
+            out = SparseTensor(y, coordinate_map_key=input.coordinate_map_key, coordinate_manager=input.coordinate_manager)
+            out._cat_slot = slot
+            return out
         elif hasattr(backend, "bn_apply") and bn.affine and bn.track_running_stats and x.is_cuda:
             # eval mode on the engine too (inference / validation passes, BN frozen during fine-tuning)
             with torch.no_grad():
@@ -353,7 +386,8 @@ class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
         super().__init__(num_features, eps, momentum, affine, track_running_stats)
         self.process_group = process_group
 
-    def forward(self, input, relu=False, residual=None):
+    def forward(self, input, relu=False, residual=None, cat_up=0, cat_into=None):
+        # cat_up / cat_into (zero-copy ME.cat hints) are ignored here: ME.cat then copies, as it does for any ordinary tensor
         import torch.distributed as dist
         if not (self.training and dist.is_available() and dist.is_initialized()
                 and (dist.get_world_size(self.process_group) > 1 or MinkowskiSyncBatchNorm.force_sync)):

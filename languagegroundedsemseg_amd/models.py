@@ -40,12 +40,13 @@ class BasicBlock(nn.Module):
         self.relu = ME.MinkowskiReLU(inplace=True)
         self.downsample = downsample
         self.inplanes, self.planes, self.final_relu = inplanes, planes, final_relu
+        self.cat_up = 0          # > 0: this block's output is a skip tensor; channels of the `up` half it will be concatenated with
 
     def forward(self, x):
         out = self.norm1(self.conv1(x, bn=self.norm1), relu=True)
         out = self.conv2(out, bn=self.norm2)
         residual = x if self.downsample is None else self.downsample[1](self.downsample[0](x, bn=self.downsample[1]))
-        return self.norm2(out, relu=self.final_relu, residual=residual)
+        return self.norm2(out, relu=self.final_relu, residual=residual, cat_up=self.cat_up)
 
 
 class Res16UNet(ME.MinkowskiNetwork):
@@ -82,6 +83,9 @@ class Res16UNet(ME.MinkowskiNetwork):
         self.final = _conv(P[7], out_channels, 1, bias=True, D=D)
         self.relu = ME.MinkowskiReLU(inplace=True)
         self.repr_only = False
+        # zero-copy ME.cat: the last block of block1..3 (and bn0) produce the skip tensors of convtr6 / 5 / 4 (and 7)
+        self.block1[-1].cat_up, self.block2[-1].cat_up, self.block3[-1].cat_up = P[6], P[5], P[4]
+        self._cat_up0 = P[7]
 
     def _make_layer(self, planes, blocks, bn_momentum, no_final_relu=False):
         downsample = None
@@ -102,15 +106,15 @@ class Res16UNet(ME.MinkowskiNetwork):
 
     def trunk(self, x):
         # conv(x, bn=norm): the conv epilogue hands the norm its batch statistics (me.modules.MinkowskiConvolutionBase.forward)
-        out_p1 = self.bn0(self.conv0p1s1(x, bn=self.bn0), relu=True)
+        out_p1 = self.bn0(self.conv0p1s1(x, bn=self.bn0), relu=True, cat_up=self._cat_up0)
         out_b1p2 = self.block1(self.bn1(self.conv1p1s2(out_p1, bn=self.bn1), relu=True))
         out_b2p4 = self.block2(self.bn2(self.conv2p2s2(out_b1p2, bn=self.bn2), relu=True))
         out_b3p8 = self.block3(self.bn3(self.conv3p4s2(out_b2p4, bn=self.bn3), relu=True))
         out = self.block4(self.bn4(self.conv4p8s2(out_b3p8, bn=self.bn4), relu=True))
-        out = self.block5(ME.cat(self.bntr4(self.convtr4p16s2(out, bn=self.bntr4), relu=True), out_b3p8))
-        out = self.block6(ME.cat(self.bntr5(self.convtr5p8s2(out, bn=self.bntr5), relu=True), out_b2p4))
-        out = self.block7(ME.cat(self.bntr6(self.convtr6p4s2(out, bn=self.bntr6), relu=True), out_b1p2))
-        out = self.block8(ME.cat(self.bntr7(self.convtr7p2s2(out, bn=self.bntr7), relu=True), out_p1))
+        out = self.block5(ME.cat(self.bntr4(self.convtr4p16s2(out, bn=self.bntr4), relu=True, cat_into=out_b3p8), out_b3p8))
+        out = self.block6(ME.cat(self.bntr5(self.convtr5p8s2(out, bn=self.bntr5), relu=True, cat_into=out_b2p4), out_b2p4))
+        out = self.block7(ME.cat(self.bntr6(self.convtr6p4s2(out, bn=self.bntr6), relu=True, cat_into=out_b1p2), out_b1p2))
+        out = self.block8(ME.cat(self.bntr7(self.convtr7p2s2(out, bn=self.bntr7), relu=True, cat_into=out_p1), out_p1))
         return out
 
     def forward(self, x):

@@ -445,3 +445,41 @@ def test_eval_mode_batchnorm_on_the_engine_matches_torch(dtype, tol):
         if with_res:
             assert rel_l2(r.grad.float().cpu().numpy(), r2.grad.cpu().numpy()) < tol
         assert rel_l2(gw0.cpu().numpy(), bn.bn.weight.grad.cpu().numpy()) < tol and rel_l2(gb0.cpu().numpy(), bn.bn.bias.grad.cpu().numpy()) < tol
+
+
+# ------------------------------------------------------------------------------------------- zero-copy ME.cat
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_zero_copy_cat_equals_the_copying_cat(dtype):
+    """both halves of ME.cat(up, skip) are written straight into the concat buffer by their norms; the skip half is then
+    a column slice that the strided conv, its weight gradient and the norm's backward read through a row stride: logits
+    and every gradient must be bit-identical to the torch.cat path"""
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    be = ME.get_backend()
+    coords, feats, _ = make_batch([0, 1], voxel=0.05, n_target=8000)
+    c, f = torch.from_numpy(coords).to(DEV), torch.from_numpy(feats).to(DEV).to(dtype)
+    lab = torch.from_numpy(np.random.default_rng(0).integers(-1, 20, coords.shape[0]).astype(np.int64)).to(DEV)
+    res = []
+    calls = {"cat": 0}
+    orig_cat = torch.cat
+
+    def counting_cat(*a, **k):
+        calls["cat"] += 1
+        return orig_cat(*a, **k)
+    for zero_copy in (True, False):
+        be.bn_out_into = zero_copy
+        try:
+            m = deterministic_init(load_model("Res16UNet14A")(3, 20, Cfg()), 42).to(DEV).train()
+            calls["cat"] = 0
+            torch.cat = counting_cat
+            try:
+                logits, fmap = m(ME.SparseTensor(f, c))
+            finally:
+                torch.cat = orig_cat
+            assert calls["cat"] == (0 if zero_copy else 4), calls
+            torch.nn.functional.cross_entropy(logits.F.float(), lab, ignore_index=-1).backward()
+            res.append((logits.F.detach().float().cpu(), {k: p.grad.detach().float().cpu() for k, p in m.named_parameters()}))
+        finally:
+            be.bn_out_into = True
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
