@@ -341,6 +341,10 @@ def main():
     # ---- data: scenes shard over ranks (rank r owns seeds r*S .. r*S+S-1); resident in HBM before timing
     seeds = [rank * args.scenes + i for i in range(args.scenes)]
     coords_np, feats_np, labels_np = make_batch(seeds, voxel=0.02, n_target=args.voxels)
+    if os.environ.get("LGS_BENCH_SORT") == "1":   # experiment only: spatially sorted input rows (the headline keeps the dataset's arbitrary order)
+        from languagegroundedsemseg_amd.synthetic import morton_order
+        perm = morton_order(coords_np)
+        coords_np, feats_np, labels_np = coords_np[perm], feats_np[perm], labels_np[perm]
     coords = torch.from_numpy(coords_np).to(device)
     feats = torch.from_numpy(feats_np).to(device)
     labels = torch.from_numpy(labels_np).to(device)

@@ -81,3 +81,16 @@ def make_batch(seeds, voxel=0.02, n_target=150000, shift_seed=None, **kw):
 def text_anchors(num_labels=200, dim=512, seed=1234):
     """stand-in for clip_feats_scannet_200.pkl (lib/datasets/prior_info.py:25-28): T ~ N(0,1)^{200 x 512}"""
     return np.random.default_rng(seed).standard_normal((num_labels, dim)).astype(np.float32)
+
+
+def morton_order(coords):
+    """permutation that sorts collated coords [N,4] = (batch, x, y, z) batch-major, then by the 3-D Morton code of the
+    voxel (experiments on input row order; the engine accepts any order)"""
+    c = coords[:, 1:].astype(np.int64)
+    c = c - c.min(0, keepdims=True)
+    key = np.zeros(c.shape[0], np.uint64)
+    for bit in range(20):
+        for a in range(3):
+            key |= ((c[:, a].astype(np.uint64) >> np.uint64(bit)) & np.uint64(1)) << np.uint64(3 * bit + a)
+    key |= coords[:, 0].astype(np.uint64) << np.uint64(60)
+    return np.argsort(key, kind="stable")

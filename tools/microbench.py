@@ -31,6 +31,11 @@ def timeit(fn, iters=5, warm=2):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     coords, feats, labels = make_batch(list(range(B)), n_target=150000, shift_seed=0)
+    if os.environ.get("LGS_MB_SORT") == "1":   # experiment: spatially sorted input rows instead of the dataset's arbitrary order
+        from languagegroundedsemseg_amd.synthetic import morton_order
+        perm = morton_order(coords)
+        coords, feats, labels = coords[perm], feats[perm], labels[perm]
+        print("input rows in Morton order")
     c = torch.from_numpy(coords).to(DEV)
     n = coords.shape[0]
     print("voxels", n)
