@@ -663,7 +663,11 @@ GatherCfg gather_cfg(const View &v, int nb_total) {
     if (nb_total == 3 || (nb_total % 3 == 0 && nb_total % 4 != 0)) return {2, kF32 ? 2 : 4, 3, 256};
     // wide outputs (>= 256 channels, e.g. the 512-d CLIP representation model): 256 positions x 256 channels per
     // 8-wave workgroup -- every staged weight fragment serves two row blocks and the rows are gathered half as often
-    if (!kF32 && nb_total % 8 == 0) return {15, 2, 8, 256};
+    // (id 16: eight waves of 32 positions x 256 channels -- no two waves gather the same rows; id 15, the earlier 4 x 2
+    // wave layout with 64 x 128 per wave, stays selectable: LGS_WIDE_CFG=15.  512->512 at L0: 12.0 vs 12.2 ms, 256->256
+    // at L1: 1.00 vs 1.06 ms)
+    static const int wide_cfg = getenv("LGS_WIDE_CFG") ? atoi(getenv("LGS_WIDE_CFG")) : 16;   // tuning knob
+    if (!kF32 && nb_total % 8 == 0) return {wide_cfg == 15 ? 15 : 16, 2, 8, 256};
     if (!kF32) return {7, 2, 4, 128};   // bf16: 128-position tiles, 4 column blocks per wave at 3 waves/SIMD
     return {3, kF32 ? 1 : 2, 4, 256};
   }
@@ -748,6 +752,7 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
     case 6: LGS_LAUNCH(1, 7, 4, 1, (kF32 ? 1 : 2), (kF32 ? 3 : 4)); break;
     case 7: LGS_LAUNCH(1, 4, 4, 1, 2, 4); break;
     case 15: LGS_LAUNCH(2, 4, 4, 2, 2, 3); break;
+    case 16: LGS_LAUNCH(1, 8, 8, 1, 2, 4); break;
     case 8: LGS_LAUNCH(1, 2, 4, 1, 4, 6); break;
     case 9: LGS_LAUNCH(1, 2, 2, 2, 4, 6); break;
     case 10: LGS_LAUNCH(1, 2, 2, 1, 4, 6); break;

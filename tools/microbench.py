@@ -256,7 +256,35 @@ def wgrad():
     print("sum over a step (stand-alone launches): %.2f ms" % tot)
 
 
+def wide():
+    """the wide-channel launches of the CLIP pretrain model (Res16UNet34D, BASELINE configs[2]) on the 8-scene maps"""
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    coords, feats, labels = make_batch(list(range(B)), n_target=150000, shift_seed=0)
+    c = torch.from_numpy(coords).to(DEV)
+    x = ME.SparseTensor(torch.zeros(coords.shape[0], 3, device=DEV), c)
+    m = x.coordinate_manager
+    keys = [x.coordinate_map_key]
+    for lvl in range(2):
+        keys.append(m.stride(keys[-1], 2))
+    for lvl, cin, cout in ((0, 512, 512), (0, 640, 512), (1, 256, 256), (1, 512, 256), (2, 256, 256)):
+        km = m.kernel_map_handle(keys[lvl], keys[lvl], 3)
+        n = m.size(keys[lvl])
+        M = km.export()[0].shape[0]
+        f = torch.randn(n, cin, device=DEV).bfloat16()
+        g = torch.randn(n, cout, device=DEV).bfloat16()
+        w = torch.randn(27, cin, cout, device=DEV) * 0.02
+        tf = timeit(lambda: km.conv_forward(f, w, None, False), 3, 1)
+        td = timeit(lambda: km.conv_dgrad(g, w, False), 3, 1)
+        tw = timeit(lambda: km.conv_wgrad(f, g, False), 3, 1)
+        flop = 2.0 * M * cin * cout
+        print("L%d 3^3 %3d->%3d rows %7d pairs %8d  fwd %.3f ms (%.0f TF = %.1f %% of 2.5 PF)  dgrad %.3f ms (%.0f TF)  wgrad %.3f ms (%.0f TF)" % (
+            lvl, cin, cout, n, M, tf, flop / tf / 1e9, flop / tf / 1e9 / 25, td, flop / td / 1e9, tw, flop / tw / 1e9))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "wide":
+        wide()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "wgrad":
         wgrad()
         sys.exit(0)

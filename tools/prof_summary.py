@@ -2,7 +2,7 @@
 (kernel template instance, launch grid, workgroup): a template instance serves several layer shapes, the grid tells them
 apart (k_conv_gather: grid.x = positions / tile rows, grid.y = output-channel tiles, grid.z = 3 for the slot split), so
 the dominant launch shape's average duration can be read off directly.
-    python tools/prof_summary.py gpurun_out/prof/x_results.db [steps] > profiles/rNN_kernel_stats.txt"""
+    python tools/prof_summary.py gpurun_out/prof/x_results.db <profiled steps = warmup + timed> > profiles/rNN_kernel_stats.txt"""
 import re
 import sqlite3
 import sys
