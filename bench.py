@@ -142,6 +142,14 @@ def build(device, dtype, n_classes=200, model_name="Res16UNet34C"):
 
 _DATA_STREAM = {}
 _CLIP = None   # set by main() for --workload clip
+_PHASES = [] if os.environ.get("LGS_BENCH_PHASES") == "1" else None   # diagnostics: per-step phase events on the compute stream
+
+
+def _mark(tag):
+    if _PHASES is not None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        _PHASES.append((tag, e, time.perf_counter()))
 
 
 def train_step(model, ddp, opt, coords, feats, labels, dtype, step_idx, shift=True):
@@ -166,15 +174,20 @@ def train_step(model, ddp, opt, coords, feats, labels, dtype, step_idx, shift=Tr
     for t in (c, f, sinput.F):
         t.record_stream(main)
     ddp.zero_grad()
+    _mark("start")
     if _CLIP is not None:   # --workload clip (BASELINE configs[2]): representation model + CLIP text-anchor loss
         out = model(sinput)
         loss, _, _ = _CLIP["crit"](out.F, labels, _CLIP["anchors"])
     else:
         logits, _ = model(sinput)
         loss = fused_cross_entropy(logits.F, labels, ignore_index=-1)
+    _mark("forward")
     loss.backward()
+    _mark("backward")       # compute stream done with backward; the weight-gradient stream may still be busy
     ddp.finalize()
+    _mark("finalize")       # joined the weight-gradient stream (+ gradient all-reduce when N > 1)
     opt.step()
+    _mark("optimizer")
     return loss
 
 
@@ -410,6 +423,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if _PHASES is not None and rank == 0:
+        ev = _PHASES[-5 * args.steps:]
+        acc, host = {}, {}
+        for j in range(args.steps):
+            blk = ev[5 * j:5 * j + 5]
+            for a, b in zip(blk[:-1], blk[1:]):
+                acc[b[0]] = acc.get(b[0], 0.0) + a[1].elapsed_time(b[1])
+                host[b[0]] = host.get(b[0], 0.0) + (b[2] - a[2]) * 1e3
+        log("phases (ms per step, compute stream): " + ", ".join("%s %.2f" % (k, v / args.steps) for k, v in acc.items()))
+        log("phases (ms per step, host enqueue time): " + ", ".join("%s %.2f" % (k, v / args.steps) for k, v in host.items()))
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     nv = torch.tensor([float(n_vox)], dtype=torch.float64, device=device)
     if world > 1:
