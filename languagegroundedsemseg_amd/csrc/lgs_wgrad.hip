@@ -904,7 +904,15 @@ inline PsPlan ps_plan(const View &v, int cg, int cs) {
   p.cg_pad = pad32(cg); p.cs_pad = pad32(cs);
   const int nbs = p.cs_pad / 32;
   p.noff = v.K == 27 ? 4 : 1;
-  if (v.K == 27) p.ncs = nbs == 1 ? 1 : (nbs % 3 == 0 ? 3 : (nbs % 2 == 0 ? 2 : 3));     // <= 3: 4 offsets x 3 blocks = 192 accumulators
+  // K = 27: <= 3 blocks (4 offsets x 3 blocks = 192 accumulators).  Every stationary slice re-gathers all neighbour rows, and
+  // gather instructions are what a wide-channel launch is made of (PMC at 512 x 512: 83 M vector-memory instructions
+  // for 68 M MFMAs): from 8 blocks on, 3-block slices are used even when the last one is partly padding (16 blocks:
+  // 6 slices instead of 8, 12 % padded MFMAs)
+  static const bool wide3 = getenv("LGS_PS_WIDE3") == nullptr || atoi(getenv("LGS_PS_WIDE3")) != 0;   // tuning knob
+  // (512 -> 512 at L0: 18.7 -> 15.0 ms, 640 -> 512: 33.3 -> 19.3 ms; at 8 blocks only when the slices exceed an XCD's CUs
+  // anyway -- 256 x 256 keeps its 32 XCD-local two-block slices: 1.21 vs 1.34 ms at L1)
+  const bool three = nbs % 3 == 0 || (wide3 && (nbs >= 12 || (nbs >= 8 && (p.cg_pad / 32) * ((nbs + 2) / 3) > 32)));
+  if (v.K == 27) p.ncs = nbs == 1 ? 1 : (three ? 3 : (nbs % 2 == 0 ? 2 : 3));
   else p.ncs = nbs <= 4 ? nbs : (nbs % 4 == 0 ? 4 : (nbs % 3 == 0 ? 3 : 4));
   p.n_cg = p.cg_pad / 32;
   p.n_cs = (nbs + p.ncs - 1) / p.ncs;
@@ -918,6 +926,10 @@ inline PsPlan ps_plan(const View &v, int cg, int cs) {
   p.xcd_map = n_sl <= per_xcd ? 1 : 0;
   int lanes = p.xcd_map ? 8 * (per_xcd / n_sl) : (8 * per_xcd) / n_sl;
   if (lanes < 1) lanes = 1;
+  // more slices than an XCD has CUs: workgroups go out in plain order, so make their number a whole multiple of the
+  // chip (96 slices x 2 lanes would leave a quarter of the CUs idle; x 8 lanes = three full rounds)
+  if (!p.xcd_map && wide3)
+    while ((lanes * n_sl) % (8 * per_xcd) != 0 && lanes < 16) ++lanes;
   if (lanes > p.n_chunks) lanes = p.n_chunks;
   p.cpl = (p.n_chunks + lanes - 1) / lanes;
   p.n_lanes = (p.n_chunks + p.cpl - 1) / p.cpl;         // every lane owns at least one chunk
