@@ -2,6 +2,11 @@
 //   mode 0  the MFMA operand layout: lane (vx = l % 32, h = l / 32) reads 16 B of row vx -> the 4 lanes of a quad touch
 //           4 different rows (what k_conv_gather did up to round 2)
 //   mode 1  row-contiguous: lane l reads segment l % 4 of row l / 4 -> a quad covers 64 contiguous bytes of ONE row
+//   mode 2/3  the same rows through global_load (missing neighbours -> row 0 / predicated off)
+//   mode 4  reference point: coalesced 1 KB loads from a 32 KB (L1-resident) region
+//   mode 5/6  8 / 4 bytes per lane instead of 16
+// usage: gather_probe.bin <channels> <1 = rows in spatial order, 0 = random> <KB of LDS per workgroup: 70 -> 2 workgroups
+//        per CU, 1 -> registers decide> <0 = ~half of the 27 neighbours present, 1 = all, 2 = a quarter in whole 64-row groups>
 // Same bytes per wave instruction (1 KB), same rows, same number of instructions; 8 waves / CU like the conv kernel
 // (dynamic LDS limits the occupancy).  Prints ms per pass and GB/s of gathered (non-missing) bytes.
 #include <hip/hip_runtime.h>
@@ -53,7 +58,6 @@ __global__ void __launch_bounds__(256) k_gather(const uint16_t *in, int64_t in_b
           else if (MODE == 4) f[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(((k * 3 + c) * 4 + j) & 31) * 1024u + lane * 16u, 0, 0);   // coalesced, 32 KB region
           else if (MODE == 5) { auto t2 = __builtin_amdgcn_raw_buffer_load_b64(rs, base[j] == kOOB ? kOOB : base[j] + c * 64, 0, 0); f[j] = u32x4{t2[0], t2[1], 0, 0}; }
           else if (MODE == 6) { f[j] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(rs, base[j] == kOOB ? kOOB : base[j] + c * 64, 0, 0), 0, 0, 0}; }
-          else if (MODE == 7) f[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, kOOB, 0, 0);   // every lane out of range
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc ^= f[j];
@@ -95,10 +99,10 @@ int main(int argc, char **argv) {
   const unsigned grid = (unsigned)(n_pad / 256);
   const size_t lds = (argc > 3 ? atoi(argv[3]) : 70) * 1024;   // 70 KB: 2 workgroups per CU
   typedef void (*kern_t)(const uint16_t *, int64_t, const int32_t *, int64_t, int, int, uint32_t *);
-  kern_t kerns[8] = {k_gather<0>, k_gather<1>, k_gather<2>, k_gather<3>, k_gather<4>, k_gather<5>, k_gather<6>, k_gather<7>};
-  const char *names[8] = {"buffer b128, MFMA lane layout", "buffer b128, row-contiguous quads", "global b128, missing -> row 0", "global b128, predicated",
-                          "buffer b128 coalesced 32 KB region", "buffer b64 gather", "buffer b32 gather", "buffer b128 all lanes out of range"};
-  for (int mode = 0; mode < 8; ++mode) {
+  kern_t kerns[7] = {k_gather<0>, k_gather<1>, k_gather<2>, k_gather<3>, k_gather<4>, k_gather<5>, k_gather<6>};
+  const char *names[7] = {"buffer b128, MFMA lane layout", "buffer b128, row-contiguous quads", "global b128, missing -> row 0", "global b128, predicated",
+                          "buffer b128 coalesced 32 KB region", "buffer b64 gather", "buffer b32 gather"};
+  for (int mode = 0; mode < 7; ++mode) {
     CK(hipFuncSetAttribute((const void *)kerns[mode], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipEventRecord(e0));
