@@ -457,11 +457,6 @@ constexpr int kPsChunk = 128;
 __constant__ int8_t kPsOff27[8][4] = {{13, 0, 2, -1},  {4, 10, 6, -1},  {12, 14, 8, -1},  {16, 22, 18, -1},
                                       {1, 3, 5, 20},   {7, 9, 11, 24},  {15, 17, 19, 26}, {21, 23, 25, -1}};
 
-// Wide stationary slices (4 blocks = 128 channels): a wave can hold only two offsets' accumulators (2 x 4 x 16), so the 27
-// offsets go out as TWO launches of 16 + 11 offsets (KIND 271 / 272) that write disjoint offsets of the same partial slabs.
-__constant__ int8_t kPsOff27A[8][2] = {{13, 0}, {2, 4}, {10, 6}, {12, 14}, {8, 16}, {22, 18}, {1, 3}, {5, 20}};
-__constant__ int8_t kPsOff27B[8][2] = {{7, 9}, {11, 24}, {15, 17}, {19, -1}, {26, -1}, {21, -1}, {23, -1}, {25, -1}};
-
 struct PsArgs {
   View v;
   const bf16_t *G;      // gathered operand  [rows][cg_real]  (rows addressed through v.nbr)
@@ -769,17 +764,6 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_ps(PsArgs a) {
       const int koff[3] = {kPsOff27[wave][0], kPsOff27[wave][1], kPsOff27[wave][2]};
       ps_wave<3, NCS>(a, smem, wave_off, koff, wlane, cg0, cs0, wave, lane);
     }
-  } else if constexpr (KIND == 271) {
-    const int koff[2] = {kPsOff27A[wave][0], kPsOff27A[wave][1]};
-    ps_wave<2, NCS>(a, smem, S_BYTES + wave * ps_wave_lds(2), koff, wlane, cg0, cs0, wave, lane);
-  } else if constexpr (KIND == 272) {
-    if (wave < 3) {
-      const int koff[2] = {kPsOff27B[wave][0], kPsOff27B[wave][1]};
-      ps_wave<2, NCS>(a, smem, S_BYTES + wave * ps_wave_lds(2), koff, wlane, cg0, cs0, wave, lane);
-    } else {
-      const int koff[1] = {kPsOff27B[wave][0]};
-      ps_wave<1, NCS>(a, smem, S_BYTES + 3 * ps_wave_lds(2) + (wave - 3) * ps_wave_lds(1), koff, wlane, cg0, cs0, wave, lane);
-    }
   } else {
     const int koff[1] = {wave};
     ps_wave<1, NCS>(a, smem, S_BYTES + wave * ps_wave_lds(1), koff, wlane, cg0, cs0, wave, lane);
@@ -912,7 +896,6 @@ struct PsPlan {
   int noff = 0, ncs = 0;
   int cg_pad = 0, cs_pad = 0, n_cg = 0, n_cs = 0, n_lanes = 0, cpl = 0, n_chunks = 0, xcd_map = 1;
   int64_t partial_bytes = 0;
-  bool split2 = false;     // K = 27, 4-block stationary slices: two launches of 16 + 11 offsets
 };
 inline PsPlan ps_plan(const View &v, int cg, int cs) {
   PsPlan p;
@@ -930,10 +913,6 @@ inline PsPlan ps_plan(const View &v, int cg, int cs) {
   // anyway -- 256 x 256 keeps its 32 XCD-local two-block slices: 1.21 vs 1.34 ms at L1)
   const bool three = nbs % 3 == 0 || (wide3 && (nbs >= 12 || (nbs >= 8 && (p.cg_pad / 32) * ((nbs + 2) / 3) > 32)));
   if (v.K == 27) p.ncs = nbs == 1 ? 1 : (three ? 3 : (nbs % 2 == 0 ? 2 : 3));
-  // from 384 stationary channels on: 4-block slices in two launches (each slice gathers every neighbour row once, and
-  // gathers are what the launch consists of -- 512 x 512: 6 three-block slices -> 4 four-block slices)
-  static const bool split_on = getenv("LGS_PS_SPLIT2") == nullptr || atoi(getenv("LGS_PS_SPLIT2")) != 0;   // tuning knob
-  if (v.K == 27 && wide3 && split_on && nbs >= 12 && nbs % 4 == 0) { p.ncs = 4; p.split2 = true; }
   else p.ncs = nbs <= 4 ? nbs : (nbs % 4 == 0 ? 4 : (nbs % 3 == 0 ? 3 : 4));
   p.n_cg = p.cg_pad / 32;
   p.n_cs = (nbs + p.ncs - 1) / p.ncs;
@@ -1005,8 +984,7 @@ int launch_wgrad_bf16(const View &v, const WgradPlan &p, const bf16_t *in, int c
 template <int KIND, int NCS>
 int launch_wgrad_ps(const PsArgs &a, const PsPlan &p, hipStream_t s) {
   constexpr int SGB = tile_stride(32 * NCS);
-  constexpr int LDS = 2 * kPsChunk * SGB + (KIND == 27 ? 5 * ps_wave_lds(3) + 3 * ps_wave_lds(4) : KIND == 271 ? 8 * ps_wave_lds(2)
-                                            : KIND == 272 ? 3 * ps_wave_lds(2) + 5 * ps_wave_lds(1) : 8 * ps_wave_lds(1));
+  constexpr int LDS = 2 * kPsChunk * SGB + (KIND == 27 ? 5 * ps_wave_lds(3) + 3 * ps_wave_lds(4) : 8 * ps_wave_lds(1));
   static_assert(LDS <= 160 * 1024, "k_wgrad_ps: LDS budget of one CU");
   static bool attr_set = false;
   if (!attr_set) {
@@ -1042,10 +1020,7 @@ int conv_wgrad_ps(const View &v, int transposed, const bf16_t *in, int cin, cons
   a.partial = reinterpret_cast<float *>(workspace);
   a.g_bytes = (unsigned)g_b; a.s_bytes = (unsigned)s_b; a.nbr_bytes = (unsigned)n_b; a.orow_bytes = (unsigned)o_b;
   int rc = 0;
-  if (p.split2) {
-    rc = launch_wgrad_ps<271, 4>(a, p, s);
-    if (!rc) rc = launch_wgrad_ps<272, 4>(a, p, s);
-  } else if (p.noff == 4) {
+  if (p.noff == 4) {
     if (p.ncs == 1) rc = launch_wgrad_ps<27, 1>(a, p, s);
     else if (p.ncs == 2) rc = launch_wgrad_ps<27, 2>(a, p, s);
     else rc = launch_wgrad_ps<27, 3>(a, p, s);
