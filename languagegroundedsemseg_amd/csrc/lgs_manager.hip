@@ -185,11 +185,11 @@ __global__ void k_build_map3(const uint64_t *skeys, int64_t n, int64_t n_pad, in
 // positions (spatially compact -> the gathered rows stay L2-resident) the positions are re-ordered by their
 // 27-bit presence mask, so a 32-row MFMA block meets far fewer distinct (block, offset) combinations
 // (measured on the synthetic rooms: zero-padded MFMA work 1.83x -> 1.31x of the real pairs).
-constexpr int kMaskWindow = 4096;
-__global__ void k_mask_sort_keys(const uint32_t *pmask, int64_t n, int64_t n_pad, uint64_t *keys, int32_t *vals) {
+constexpr int kMaskWindow = 16384;
+__global__ void k_mask_sort_keys(const uint32_t *pmask, int64_t n, int64_t n_pad, int window, uint64_t *keys, int32_t *vals) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pad) return;
-  keys[p] = p < n ? (((uint64_t)(p / kMaskWindow)) << 32) | pmask[p] : ~0ull;
+  keys[p] = p < n ? (((uint64_t)(p / window)) << 32) | pmask[p] : ~0ull;
   vals[p] = (int32_t)p;
 }
 __global__ void k_permute_map3(const int32_t *nbr_tmp, const uint32_t *pmask, const int32_t *perm, const int32_t *order,
@@ -743,7 +743,8 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
         return 1;
       hipLaunchKernelGGL(k_build_map3, (unsigned)(ci.n_pad / 256), 256, 0, s, ci.skeys, ci.n, ci.n_pad, ci.ts, ci.hkeys,
                          ci.hvals, (uint64_t)(ci.hcap - 1), nbr_tmp, pmask);
-      hipLaunchKernelGGL(k_mask_sort_keys, (unsigned)(ci.n_pad / 256), 256, 0, s, pmask, ci.n, ci.n_pad, keys, vals);
+      static const int window = getenv("LGS_MASK_WINDOW") ? atoi(getenv("LGS_MASK_WINDOW")) : kMaskWindow;   // tuning knob
+      hipLaunchKernelGGL(k_mask_sort_keys, (unsigned)(ci.n_pad / 256), 256, 0, s, pmask, ci.n, ci.n_pad, window, keys, vals);
       {
         size_t tb = 0;
         LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, 64, s));
