@@ -219,6 +219,11 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   }
   const int64_t pos_wg = tile * TM;
   const int64_t pos_w = pos_wg + (int64_t)wm * RB * 32;
+  // Eight-wave tiles (one 32-row block per wave) INTERLEAVE the tile's rows over the waves (row i -> wave i % 8): the
+  // rows are sorted by neighbourhood shape, so contiguous blocks would leave whole waves without work at an offset while
+  // the others run their MFMAs, and everybody meets at the next slab barrier.
+  constexpr bool ILV = (WM == 8 && RB == 1 && EPI == 0);
+  auto row_of = [&](int rb) __attribute__((always_inline)) { return ILV ? vx * WM + wm : wm * RB * 32 + rb * 32 + vx; };
   const int nb_wg = blockIdx.y * WB;  // first cout block of the workgroup
   const int nb_w = nb_wg + wn * NCB;  // first cout block of this wave
 
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     ichunk = gbase;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-      const int r = wm * RB * 32 + rb * 32 + vx;
+      const int r = row_of(rb);
       const int64_t p = pos_wg + r;
       idx_i[rb] = v.nbr ? l_idx[islot * TM + r] : (p < v.n_in ? (int32_t)p : -1);
     }
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   // ---- epilogue: lane (voxel vx, half h) owns channels nb*32 + 8q + 4h + {0..3}
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
-    int64_t p = pos_w + rb * 32 + vx;
+    int64_t p = pos_wg + row_of(rb);
     int32_t orow = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
     if (orow < 0) continue;
     T *dst = out + (int64_t)orow * cout_real;
@@ -582,7 +587,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
       for (int j = 0; j < V; ++j) vst[j] = 0.f;
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
-        const int64_t p = pos_w + rb * 32 + vx;
+        const int64_t p = pos_wg + row_of(rb);
         const int32_t orow = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
         const bool live = orow >= 0;
 #pragma unroll
