@@ -164,12 +164,17 @@ def test_res16unet34d_clip_step_vs_oracle(size):
     print("34D bf16 %s: loss %.6f vs %.6f, feature rel-L2 %.3e" % (size, b[0], o[0], e))
     errs, tot = grad_report(b[2], o[2], "34D bf16 HIP vs fp32 oracle, " + size)
     # gradients: against the bf16-storage oracle's own deviation (see the note above the 34C tests)
-    ob = on_oracle(lambda: clip_step(coords, feats, labels, anchors, neg, "cpu", torch.bfloat16), "c" if size == "fixture" else "torch")
-    berrs, btot = grad_report(ob[2], o[2], "34D bf16-storage ORACLE vs fp32 oracle (noise floor), " + size)
-    eb = rel_l2(ob[1], o[1])
-    print("34D bf16-storage oracle: feature rel-L2 %.3e" % eb)
+    if size == "fixture":
+        ob = on_oracle(lambda: clip_step(coords, feats, labels, anchors, neg, "cpu", torch.bfloat16), "c")
+        berrs, btot = grad_report(ob[2], o[2], "34D bf16-storage ORACLE vs fp32 oracle (noise floor), " + size)
+        eb = rel_l2(ob[1], o[1])
+        print("34D bf16-storage oracle: feature rel-L2 %.3e" % eb)
+    else:
+        # the 512-channel CPU oracle on 70 k voxels takes ~70 s per pass: the noise floor of this scene / seed is pinned to
+        # the values that pass measured (round 2: gradient rel-L2 0.335, feature rel-L2 3.7e-2) instead of re-run
+        btot, eb = 0.335, 3.7e-2
     assert abs(b[0] - o[0]) < 5e-3                           # measured 1.6e-4
-    assert e < 6e-2 and e < 1.5 * eb + 5e-3                  # measured 3.3e-2
+    assert e < 6e-2 and e < 1.5 * eb + 5e-3                  # measured 3.3e-2 / 4.3e-2
     assert tot < 1.25 * btot + 0.02
 
 
