@@ -268,11 +268,13 @@ def test_bf16_mfma_paths_all_tile_shapes(cin, cout, ks, st):
         assert rel_err(a, b) < 2e-2, n
 
 
-@pytest.mark.parametrize("cin,cout", [(96, 96), (128, 96), (32, 32), (32, 64), (64, 256)])
+@pytest.mark.parametrize("cin,cout", [(96, 96), (128, 96), (32, 32), (32, 64), (64, 256), (256, 512), (512, 256)])
 def test_bf16_conv_on_a_large_map(cin, cout):
     """maps of >= 65536 positions take the 'big' tile configurations of k_conv_gather and the one-offset-per-wave
     schedule of k_wgrad_bf16; reading y.C while kernels are still queued must not disturb them (the coordinate export
-    once wrote into a just-released conv workspace from the map stream)"""
+    once wrote into a just-released conv workspace from the map stream).  256 -> 512 and 512 -> 256 are the wide-channel
+    shapes of Res16UNet34D: eight-wave interleaved conv tiles with two column tiles, and the weight gradient's three-block
+    stationary slices with a partly padded last slice (16 blocks -> 6 slices; 8 blocks x 16 gathered slices -> 3 slices)"""
     from languagegroundedsemseg_amd.synthetic import make_batch
     coords, _, _ = make_batch([3], voxel=0.02, n_target=80000)
     assert coords.shape[0] >= 66000
