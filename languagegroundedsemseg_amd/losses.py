@@ -119,6 +119,11 @@ class ContrastiveLanguageLoss(nn.Module):
         self.ignore_label, self.reduction = ignore_label, reduction
         self.uniform_sampling = uniform_sampling      # config.clip_uniform_sampling (ContrastiveLanguageLoss.py:138-141)
 
+    @classmethod
+    def from_config(cls, config, num_labels, reduction="mean", feature_dim=512):
+        """the reference's constructor arguments (ContrastiveLanguageLoss.py:22) -> ReferenceContrastiveLanguageLoss"""
+        return ReferenceContrastiveLanguageLoss(config, num_labels, reduction=reduction, feature_dim=feature_dim)
+
     def sample_negatives(self, labels, generator=None):
         """K negative classes per voxel, on the device, no host sync.
         uniform_sampling=True : uniform over all other classes (clip_candidates minus own, :139)
@@ -184,6 +189,62 @@ class ContrastiveLanguageLoss(nn.Module):
         if return_pred:
             out = out + (pred,)
         return out
+
+
+class ReferenceContrastiveLanguageLoss(ContrastiveLanguageLoss):
+    """Drop-in for the reference class, same constructor and call signature:
+        /root/reference/lib/losses/ContrastiveLanguageLoss.py:22   __init__(config, num_labels, temperature, base_temperature,
+                                                                           reduction, feature_dim)
+        /root/reference/lib/losses/ContrastiveLanguageLoss.py:97   forward(features, labels, anchor_feats, preds=None)
+                                                                   -> (loss, pos_loss, neg_loss)
+    as built by pl_RepresentationTrainer.py:45 (`ContrastiveLanguageLoss(self.config, num_labels=..., reduction=...)`) and
+    called at :216 (`criterion(soutput.F, target, anchor_feats=anchor_feats)`).  The one-line swap is the import at
+    pl_RepresentationTrainer.py:8.  It reads the same config fields (ignore_label,
+    num_negative_samples with -1 = all labels, contrast_pos_thresh / contrast_neg_thresh / contrast_neg_weight,
+    clip_uniform_sampling, representation_distance_type) and keeps the attributes the trainer touches
+    (`augment_categories`, :46; `confusion_hist` buffer).  The arithmetic is the engine's fused kernel
+    (lgs_clip_loss_forward / lgs_clip_loss_backward); negatives are drawn on the device instead of the reference's
+    per-class np.random.choice inside a joblib thread pool (whose draw order is not reproducible even with a seed).
+    Category + attribute labels ([N, 2], :149-178) select the anchor (category, attribute) as the positive and plain
+    category anchors as negatives, like the reference; its latent augmentation (a pretrained AttributeFittingModel that is
+    not part of the hot path) is not reproduced and raises if configured."""
+
+    def __init__(self, config, num_labels, temperature=0.07, base_temperature=0.07, reduction="mean", feature_dim=512):
+        k = int(getattr(config, "num_negative_samples", 3))
+        if k <= -1:
+            k = num_labels                                            # :35-38
+        dist_type = getattr(config, "representation_distance_type", "cos")
+        if dist_type != "cos":
+            raise NotImplementedError("representation_distance_type=%r: the engine implements the reference's default 'cos' "
+                                      "distance (config.py:159); l1 / l2 are not part of the measured path" % (dist_type,))
+        super().__init__(num_labels=num_labels, num_negative_samples=k,
+                         pos_thresh=float(getattr(config, "contrast_pos_thresh", 0.0)),
+                         neg_thresh=float(getattr(config, "contrast_neg_thresh", 0.6)),
+                         neg_weight=float(getattr(config, "contrast_neg_weight", 1.0)),
+                         ignore_label=int(getattr(config, "ignore_label", -1)), reduction=reduction,
+                         uniform_sampling=bool(getattr(config, "clip_uniform_sampling", True)))
+        self.config = config
+        self.temperature, self.base_temperature, self.feature_dim = temperature, base_temperature, feature_dim
+        self.num_negative_samples = k
+        self.register_buffer("confusion_hist", torch.zeros((num_labels, num_labels)).long())
+        self.augment_categories = torch.empty(0)
+
+    def forward(self, features, labels, anchor_feats, preds=None, neg_indices=None):
+        if labels.dim() == 2:                                        # (category, attribute) targets, :149-181
+            if getattr(self.config, "instance_augmentation", None) == "latent":
+                raise NotImplementedError("latent instance augmentation (ContrastiveLanguageLoss.py:160-165) needs the pretrained "
+                                          "AttributeFittingModel; it is outside the engine's hot path")
+            if anchor_feats.dim() != 3:
+                raise ValueError("[N, 2] labels need [num_labels, num_attributes, C] anchors")
+            A = anchor_feats.shape[1]
+            cat, att = labels[:, 0].long(), labels[:, 1].long()
+            if neg_indices is None:
+                neg_indices = self.sample_negatives(cat)
+            valid = cat != self.ignore_label
+            flat_lab = torch.where(valid, cat.clamp_min(0) * A + att, torch.full_like(cat, self.ignore_label))
+            out = super().forward(features, flat_lab, anchor_feats.reshape(-1, anchor_feats.shape[-1]), neg_indices=neg_indices * A)
+            return out[:3]
+        return super().forward(features, labels, anchor_feats, neg_indices=neg_indices)[:3]
 
 
 def sample_categories_for_balancing(loss, targets, frequency_organized_cats, head_ratio, common_ratio, ignore_label=-1,

@@ -28,6 +28,71 @@ def test_library_exports_every_declared_symbol():
     assert engine.lib().lgs_abi_version() == 4
 
 
+def declared_prototypes():
+    """-> {name: (return kind, [param kinds])} parsed from the header; kinds: ptr / int / i64 / f32 / f64"""
+    txt = open(os.path.join(ROOT, "include", "lgs_engine.h")).read()
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", " ", txt)
+
+    def kind(decl):
+        decl = decl.strip()
+        if "*" in decl:
+            return "ptr"
+        base = re.sub(r"\b(const|unsigned|signed)\b", " ", decl).split()
+        assert base, decl
+        t = base[0]
+        return {"int": "int", "int64_t": "i64", "float": "f32", "double": "f64", "int32_t": "int"}[t]
+
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ \t\n\*]*?)\b(lgs_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", txt):
+        ret, name, params = m.group(1), m.group(2), m.group(3).strip()
+        ret = re.split(r"[;{}]", ret)[-1]
+        if "typedef" in ret or "struct" in ret:
+            continue
+        plist = [] if params in ("", "void") else [kind(x) for x in params.split(",")]
+        protos[name] = (kind(ret), plist)
+    return protos
+
+
+def _ctype_kind(t):
+    if t is None:
+        return "void"
+    if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or issubclass(t, ctypes._Pointer):
+        return "ptr"
+    return {ctypes.c_int: "int", ctypes.c_int64: "i64", ctypes.c_float: "f32", ctypes.c_double: "f64", ctypes.c_int32: "int"}[t]
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """arity and argument classes (pointer / int / int64 / float) of every binding in engine.py against the C prototypes:
+    a drifted argtype (e.g. an `int` row stride bound as int64) passes garbage in the upper register half silently"""
+    from languagegroundedsemseg_amd import engine
+    L = engine.lib()
+    protos = declared_prototypes()
+    assert sorted(protos) == declared_symbols(), "prototype parser missed a declaration"
+    for name, (ret, params) in protos.items():
+        f = getattr(L, name)
+        assert f.argtypes is not None, "engine.py binds %s without argtypes" % name
+        got = [_ctype_kind(t) for t in f.argtypes]
+        assert got == params, "%s: engine.py argtypes %s != header %s" % (name, got, params)
+        assert _ctype_kind(f.restype) == ret, "%s: restype %s != header %s" % (name, _ctype_kind(f.restype), ret)
+
+
+def test_integration_stub_signatures_match_the_header():
+    """the ctypes stub printed in INTEGRATION.md is held to the same check (it once declared an int as int64)"""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    protos = declared_prototypes()
+    names = {"vp": "ptr", "i64": "i64", "ci": "int", "cf": "f32"}
+    found = 0
+    for m in re.finditer(r"L\.(lgs_[a-z0-9_]+)\.argtypes\s*=\s*\[([^\]]*)\]", txt):
+        name, args = m.group(1), m.group(2)
+        kinds = []
+        for a in [x.strip() for x in args.split(",") if x.strip()]:
+            kinds.append("ptr" if a.startswith("ctypes.POINTER") else names[a])
+        assert kinds == protos[name][1], "INTEGRATION.md stub of %s: %s != header %s" % (name, kinds, protos[name][1])
+        found += 1
+    assert found >= 5
+
+
 def test_error_reporting_without_gpu():
     from languagegroundedsemseg_amd import engine
     L = engine.lib()
