@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LGS_ABI_VERSION 4
+#define LGS_ABI_VERSION 5
 
 enum lgs_dtype { LGS_F32 = 0, LGS_BF16 = 1 };
 
@@ -145,6 +145,10 @@ int lgs_conv_dgrad(lgs_kmap *km, int transposed, const void *grad_out, int cout,
 /* grad_weight[K,cin,cout] (float32, overwritten) */
 int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const void *grad_out, int cout,
                    float *grad_weight, int dtype, void *workspace, int in_row_stride /* elements; 0 = cin */, void *stream);
+/* 1 if lgs_conv_wgrad can read `in` through `in_row_stride` for this shape (only the position-stationary bf16 kernel does;
+ * it declines e.g. for >= 4 GiB at the wider stride, odd channel counts, or when forced off), else 0: the caller then
+ * passes a contiguous copy.  The Python host asks before every strided weight gradient instead of letting the call fail. */
+int lgs_conv_wgrad_supports_stride(const lgs_kmap *km, int transposed, int cin, int cout, int dtype, int in_row_stride);
 
 /* ---- fused batch-norm / ReLU / residual ------------------------------------------------------
  * replaces ME.MinkowskiBatchNorm (.bn = nn.BatchNorm1d over all rows) + MinkowskiReLU + `out += residual`

@@ -1107,6 +1107,20 @@ using namespace lgs;
 
 extern "C" {
 
+int lgs_conv_wgrad_supports_stride(const lgs_kmap *km, int transposed, int cin, int cout, int dtype, int in_row_stride) {
+  // mirrors the conditions under which conv_wgrad_ps accepts the call (it is the only weight-gradient kernel that reads a
+  // column slice of a wider row-major tensor in place)
+  if (!km || dtype != LGS_BF16 || !(km->ks == 3 || km->ks == 2) || km->fwd.n_pad == 0 || !ps_enabled()) return 0;
+  if (transposed && km->ks == 3) return 0;
+  if (in_row_stride <= 0 || in_row_stride == cin) return 1;
+  const int cg = transposed ? cout : cin, cs = transposed ? cin : cout;
+  const PsPlan p = ps_plan(km->fwd, cg, cs);
+  if (!p.ok || (in_row_stride * 2) % 16 != 0) return 0;
+  const View &v = km->fwd;
+  const uint64_t rows = transposed ? (uint64_t)v.n_out : (uint64_t)v.n_in;
+  return rows * (uint64_t)in_row_stride * 2 < 0xfffff000ull ? 1 : 0;
+}
+
 int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const void *grad_out, int cout,
                    float *grad_weight, int dtype, void *workspace, int in_row_stride, void *stream) {
   LGS_REQUIRE(km && grad_weight && workspace, "lgs_conv_wgrad: null argument");

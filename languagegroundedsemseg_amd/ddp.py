@@ -14,12 +14,27 @@ overlapped with the rest of backward; finalize() waits once before the optimiser
 import torch
 import torch.distributed as dist
 
+_TIMING = {"on": False}
+_SYNCBN_EVENTS = []      # (start, end) HIP events around SyncBN collectives while BucketedDDP.enable_timing() is active
+
+
+def _timed_collective(fn, tensor_is_cuda):
+    """run one blocking SyncBN collective; with timing on, bracket it with events on the compute stream"""
+    if _TIMING["on"] and tensor_is_cuda:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        _SYNCBN_EVENTS.append((a, b))
+    else:
+        fn()
+
 
 class BucketedDDP:
     """force_collectives=True issues the all-reduces even with a world of one rank (used by the single-GPU RCCL test:
     the collective path, its stream ordering and the bucket views are then the ones an 8-GPU run executes)."""
 
-    def __init__(self, module, bucket_mb=32.0, process_group=None, force_collectives=False):
+    def __init__(self, module, bucket_mb=32.0, process_group=None, force_collectives=False, allreduce="ring"):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -40,22 +55,39 @@ class BucketedDDP:
         if cur:
             self._make_bucket(cur)
         self._handles = []
+        self._next = 0                  # first bucket whose collective has not been issued this step
+        self._step = 0                  # bumped by zero_grad(): wgrad events of earlier steps are never waited on
+        self.allreduce = allreduce      # "ring": dist.all_reduce per bucket; "rs_ag": reduce-scatter + all-gather on the flat bucket
+        self.timing = None              # set by enable_timing(): HIP events around collectives / waits (bench.py --gpus N)
         if self.reduce:
             for p in params:
                 dist.broadcast(p.data, src=0, group=self.group)
             for b in module.buffers():
                 if b.dtype.is_floating_point:
                     dist.broadcast(b.data, src=0, group=self.group)
+            # the broadcast wrote through `.data`: packed weight images made by a warm-up forward are stale now
+            from .me.core import get_backend
+            be = get_backend()
+            if hasattr(be, "invalidate_packed_weights"):
+                be.invalidate_packed_weights()
 
     def _make_bucket(self, params):
         n = sum(p.numel() for p in params)
-        flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+        # padded so that the reduce-scatter / all-gather halves ("rs_ag") split evenly and stay 16-byte aligned per rank
+        # layout: [gradients | one "used" flag per parameter | padding].  The flags ride along in the same collective: after
+        # the reduction flag > 0 <=> SOME rank produced a gradient for that parameter this step, which is what the optimiser
+        # must key on (a parameter unused on this rank but used on another still has to move identically everywhere)
+        q = 4 * max(self.world, 1)
+        flat = torch.zeros((n + len(params) + q - 1) // q * q, dtype=torch.float32, device=params[0].device)
         off = 0
-        bucket = {"flat": flat, "params": params, "pending": len(params), "n": len(params), "views": [], "launched": False}
+        bucket = {"flat": flat, "params": params, "pending": len(params), "n": len(params), "views": [], "launched": False,
+                  "flag_off": n, "grad_elems": n}
+        flat[n:n + len(params)] = 1.0
         for p in params:
             # the engine's backward kernels write gradients straight into this slot (me.modules.grad_slot_view);
             # any other producer falls back to autograd's own accumulation into the same memory
             p._lgs_grad_slot = (flat, off, tuple(p.shape))
+            p._lgs_ddp = self
             bucket["views"].append((p, off))
             off += p.numel()
             if self.reduce:
@@ -80,11 +112,20 @@ class BucketedDDP:
                 return
             bucket["pending"] -= 1
             if bucket["pending"] == 0:
-                self._launch(bucket)
+                self._launch_ready()
             elif bucket["pending"] < 0:
                 raise RuntimeError("BucketedDDP: a gradient arrived after its bucket was reduced -- call zero_grad() before "
                                    "every backward, or wrap all but the last micro-batch of an accumulation in no_sync()")
         return fn
+
+    def _launch_ready(self):
+        """Collectives are issued in FIXED bucket order on every rank: bucket i goes out only once buckets 0..i-1 have.
+        Ranks whose sets of unused parameters differ (a data-dependent loss branch -- the reference runs
+        find_unused_parameters=True for that reason) would otherwise launch bucket k from a hook on one rank and from
+        finalize() on another: mismatched all-reduce sequences hang RCCL or silently mix buckets."""
+        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def _collect(self, bucket):
         """Every parameter's gradient must live in its slot of the flat bucket before the bucket is reduced / handed to
@@ -99,17 +140,90 @@ class BucketedDDP:
                 bucket["flat"][off:off + p.numel()].copy_(g.reshape(-1))
                 p.grad = bucket["flat"][off:off + p.numel()].view_as(p)
 
+    def _wait_bucket_wgrads(self, bucket):
+        """order the current stream after the side-stream weight gradients of THIS bucket only (one event per conv
+        parameter, recorded behind its wgrad kernels by MinkowskiConvolutionFunction.backward): a bucket that is ready
+        early must not wait for weight gradients of later layers that merely sit in front of it in the side stream's
+        queue -- nor for the whole stream, as a stream-wide join does"""
+        if not bucket["flat"].is_cuda:
+            return
+        cur = torch.cuda.current_stream()
+        last = None
+        for p, _ in bucket["views"]:
+            ev = getattr(p, "_lgs_wgrad_event", None)
+            if ev is not None and getattr(p, "_lgs_wgrad_step", -1) == self._step:
+                # the side stream runs in order: the event recorded LAST covers the earlier ones
+                if last is None or p._lgs_wgrad_seq > last[0]:
+                    last = (p._lgs_wgrad_seq, ev)
+        if last is not None:
+            cur.wait_event(last[1])
+
     def _launch(self, bucket):
-        self._join_side()
+        self._wait_bucket_wgrads(bucket)
         self._collect(bucket)
         bucket["launched"] = True
+        flat = bucket["flat"]
+        # "used" flags: all ones unless this rank produced no gradient for a parameter (then the bucket was not launched
+        # from a hook but flushed by finalize(), so this host-side test is rare and never on the overlapped path)
+        fo = bucket["flag_off"]
+        for i, (p, _) in enumerate(bucket["views"]):
+            if p.grad is None:
+                flat[fo + i] = 0.0
         if self.world > 1:
-            bucket["flat"].div_(self.world)
-        self._handles.append(dist.all_reduce(bucket["flat"], group=self.group, async_op=True))
+            flat.div_(self.world)
+        t = self.timing
+        if t is not None and flat.is_cuda:
+            e = torch.cuda.Event(enable_timing=True); e.record(); t["launch_ev"].append(e)
+        if self.allreduce == "rs_ag":
+            # reduce-scatter + all-gather on the flat bucket (padded to a multiple of the world size): every rank reduces
+            # 1/W of the bucket and the two halves move (W-1)/W of the bytes each over ALL peers' links at once, instead of
+            # one ring's per-link rate (SURVEY section 5: 38 MB per link vs 265 MB over one)
+            W = self.world
+            chunk = flat.numel() // W
+            r = dist.get_rank(self.group)
+            mine = flat[r * chunk:(r + 1) * chunk]
+            if dist.get_backend(self.group) == "nccl":
+                dist.reduce_scatter_tensor(mine, flat, group=self.group, async_op=True)          # in place: out = in + r * chunk
+                self._handles.append(dist.all_gather_into_tensor(flat, mine, group=self.group, async_op=True))
+            else:
+                # gloo (CPU / single-GPU dry runs of the N>1 logic) has neither collective: W rooted reduces + an all-gather
+                # exercise the same partitioning
+                for j in range(W):
+                    dist.reduce(flat[j * chunk:(j + 1) * chunk], dst=dist.get_global_rank(self.group, j) if self.group is not None else j,
+                                group=self.group)
+                parts = [torch.empty_like(mine) for _ in range(W)]
+                dist.all_gather(parts, mine.clone(), group=self.group)
+                for j in range(W):
+                    flat[j * chunk:(j + 1) * chunk].copy_(parts[j])
+        else:
+            self._handles.append(dist.all_reduce(flat, group=self.group, async_op=True))
+
+    def enable_timing(self):
+        """bench.py --gpus N: HIP events on the compute stream around what the data-parallel path adds to a step, so that
+        a first multi-GPU run can be read: `allreduce_wait` = time finalize() stalls the compute stream for bucket
+        collectives that backward did not hide; `syncbn` = compute-stream stalls inside the SyncBN collectives."""
+        self.timing = {"launch_ev": [], "wait": [], "syncbn": _SYNCBN_EVENTS}
+        _SYNCBN_EVENTS.clear()
+        _TIMING["on"] = True
+
+    def timing_summary(self, steps):
+        """-> dict of per-step milliseconds (call after torch.cuda.synchronize())"""
+        t = self.timing
+        if t is None:
+            return None
+        out = {"allreduce_exposed_wait_ms": sum(a.elapsed_time(b) for a, b in t["wait"]) / max(steps, 1),
+               "bucket_collectives_per_step": len(t["launch_ev"]) / max(steps, 1),
+               "syncbn_collective_ms": sum(a.elapsed_time(b) for a, b in t["syncbn"]) / max(steps, 1),
+               "syncbn_collectives_per_step": len(t["syncbn"]) / max(steps, 1)}
+        t["launch_ev"].clear(); t["wait"].clear(); t["syncbn"].clear()
+        return out
 
     def zero_grad(self):
+        self._next = 0
+        self._step += 1
         for b in self.buckets:
             b["flat"].zero_()
+            b["flat"][b["flag_off"]:b["flag_off"] + b["n"]] = 1.0
             b["pending"] = b["n"]
             b["launched"] = False
             for p, _ in b["views"]:
@@ -124,6 +238,9 @@ class BucketedDDP:
 
         def __exit__(self, *exc):
             self.ddp._defer = self.prev
+            # the micro-batches inside the context wrote weight gradients on the side stream; the next backward ACCUMULATES
+            # into the same slots on the main stream (p.grad is set, so grad_slot_view declines): order it behind them
+            self.ddp._join_side()
 
     def no_sync(self):
         """Gradient accumulation (the reference's insseg trainer supports iter_size > 1): backward passes inside the
@@ -133,18 +250,28 @@ class BucketedDDP:
     def finalize(self):
         """call after backward(): waits for the side-stream weight gradients and the in-flight bucket all-reduces
         (and flushes buckets whose parameters received no gradient this step -- the reference runs
-        find_unused_parameters=True).  Buckets that were not launched from a hook are flushed in fixed bucket order, the
-        same on every rank.  Inside no_sync() nothing is reduced."""
+        find_unused_parameters=True).  Collectives go out in fixed bucket order on every rank (_launch_ready): whatever
+        the hooks could not issue yet is issued here, in the same order.  Inside no_sync() nothing is reduced."""
         self._join_side()
         if self.reduce and not self._defer:
-            for b in self.buckets:
-                if not b["launched"]:
-                    self._launch(b)
-            for h in self._handles:
-                h.wait()
+            while self._next < len(self.buckets):
+                self._launch(self.buckets[self._next])
+                self._next += 1
+            t = self.timing
+            if t is not None and self.buckets and self.buckets[0]["flat"].is_cuda:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for h in self._handles:
+                    h.wait()
+                b.record()
+                t["wait"].append((a, b))
+            else:
+                for h in self._handles:
+                    h.wait()
             for b in self.buckets:      # ready for the next backward even if the caller clears grads some other way
                 b["pending"] = b["n"]
                 b["launched"] = False
+            self._next = 0
         else:
             for b in self.buckets:
                 self._collect(b)
@@ -165,7 +292,7 @@ class FlatSGD:
         self.ddp, self.lr, self.momentum, self.dampening, self.weight_decay = ddp, lr, momentum, dampening, weight_decay
         self.state = []
         for b in ddp.buckets:
-            flat_p = torch.empty_like(b["flat"])
+            flat_p = torch.zeros_like(b["flat"])      # (the bucket's padding tail stays zero)
             for p, off in b["views"]:
                 flat_p[off:off + p.numel()].copy_(p.data.reshape(-1))
                 p.data = flat_p[off:off + p.numel()].view_as(p)
@@ -178,25 +305,33 @@ class FlatSGD:
         for b, st in zip(self.ddp.buckets, self.state):
             g = b["flat"]
             # parameters without a gradient this step (grad is None) must not move, not even by weight decay / momentum
-            unused = [(p, off) for p, off in b["views"] if p.grad is None]
+            unused = [(i, p, off) for i, (p, off) in enumerate(b["views"]) if p.grad is None]
             if unused:
                 st["mask"].fill_(1.0)
-                for p, off in unused:
-                    st["mask"][off:off + p.numel()] = 0.0
+                reduced = self.ddp.reduce and self.ddp.world > 1
+                for i, p, off in unused:
+                    if reduced:
+                        # unused HERE; another rank may have used it: the all-reduced "used" flag decides, on the device (no
+                        # host sync), so every rank applies the same update
+                        st["mask"][off:off + p.numel()] = (g[b["flag_off"] + i] > 0).to(torch.float32)
+                    else:
+                        st["mask"][off:off + p.numel()] = 0.0
+            ne = b["grad_elems"]          # the "used" flags and the padding behind the gradients are not parameters
             if fused:   # one kernel per bucket (lgs_sgd_step) instead of four elementwise passes
                 import ctypes
                 from . import engine
                 first = st["buf"] is None
                 if first and self.momentum != 0:
-                    st["buf"] = torch.empty_like(g)
+                    st["buf"] = torch.zeros_like(g)
                 vp = ctypes.c_void_p
                 with torch.cuda.device(g.device):
                     engine.check(engine.lib().lgs_sgd_step(
                         vp(st["p"].data_ptr()), vp(g.data_ptr()), vp(st["buf"].data_ptr()) if st["buf"] is not None else vp(None),
-                        vp(st["mask"].data_ptr()) if unused else vp(None), int(g.numel()), float(self.lr), float(self.momentum),
+                        vp(st["mask"].data_ptr()) if unused else vp(None), int(ne), float(self.lr), float(self.momentum),
                         float(self.dampening), float(self.weight_decay), int(first), vp(torch.cuda.current_stream(g.device).cuda_stream)))
                 continue
             d = g.add(st["p"], alpha=self.weight_decay) if self.weight_decay != 0 else g.clone()
+            d[ne:] = 0.0
             if self.momentum != 0:
                 if st["buf"] is None:
                     st["buf"] = d.clone()
@@ -269,9 +404,9 @@ class _SyncBNFused(torch.autograd.Function):
         local = backend.bn_stats(x, conv_stats) if conv_stats is not None else backend.bn_stats(x)
         allst = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=x.device)
         if dist.get_backend(group) == "nccl":
-            dist.all_gather_into_tensor(allst, local, group=group)
+            _timed_collective(lambda: dist.all_gather_into_tensor(allst, local, group=group), x.is_cuda)
         else:  # gloo (single-GPU dry runs / CPU tests) has no flat all-gather
-            dist.all_gather(list(allst.unbind(0)), local, group=group)
+            _timed_collective(lambda: dist.all_gather(list(allst.unbind(0)), local, group=group), x.is_cuda)
         # one kernel: Chan's combination, running statistics, num_batches_tracked, 1/N (device scalar)
         stats, inv_n = backend.bn_sync_combine(allst, c, eps, momentum, running_mean, running_var, nbt)
         y = backend.bn_apply(x, weight, bias, stats, residual, relu)
@@ -300,7 +435,7 @@ class _SyncBNFused(torch.autograd.Function):
         else:
             dgamma, dbeta = gview, bview
         sums = ctx.backend.bn_backward_reduce(x, yy, dy, weight, bias, stats, ctx.relu_mode, dgamma, dbeta)
-        dist.all_reduce(sums, group=ctx.group)
+        _timed_collective(lambda: dist.all_reduce(sums, group=ctx.group), x.is_cuda)
         dx, dres = ctx.backend.bn_backward_apply(x, yy, dy, weight, bias, stats, sums, inv_n, ctx.relu_mode,
                                                  ctx.has_res and ctx.needs_input_grad[3])
         if gview is not None:

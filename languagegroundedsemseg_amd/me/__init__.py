@@ -19,4 +19,15 @@ from .modules import MinkowskiConvolutionFunction, MinkowskiConvolutionTranspose
 from . import utils  # noqa: E402,F401
 from . import ops as MinkowskiOps  # noqa: E402,F401
 
+
+
+def invalidate_packed_weights():
+    """Extension (not in MinkowskiEngine): call after writing conv weights behind torch's version counters -- `p.data.copy_()`,
+    `dist.broadcast(p.data)`, raw-pointer updates.  reset_parameters(), load_state_dict(), BucketedDDP's initial broadcast
+    and FlatSGD.step() already do."""
+    be = get_backend()
+    if hasattr(be, "invalidate_packed_weights"):
+        be.invalidate_packed_weights()
+
+
 __version__ = "0.5.4"  # API level mirrored

@@ -61,19 +61,45 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+_DESC_FIELDS = [f for f, _ in engine.PackDesc._fields_]
+
+
+class _PackEntry:
+    """one packed weight image: the device buffer, its layout as plain ints (no ctypes pointers: conv modules that own
+    entries stay picklable / deep-copyable) and a WEAK reference to the parameter it was packed from"""
+    __slots__ = ("buf", "desc", "valid", "param_ref", "__weakref__")
+
+    def __init__(self, buf, desc, param):
+        self.buf, self.desc, self.valid, self.param_ref = buf, desc, None, weakref.ref(param)
+
+    def cdesc(self):
+        d = engine.PackDesc()
+        for f in _DESC_FIELDS:
+            setattr(d, f, self.desc[f])
+        return d
+
+
 class PackedWeights:
-    """Registry of packed weight images (lgs_conv_pack_desc / lgs_pack_weights_batch).  Every conv module keeps the
-    images of its own launch shapes (`cache` dict on the module, one per (direction, layout)); an image is valid while
-    (epoch, parameter version, parameter address) are unchanged.  optimiser.step() of FlatSGD -- which updates the
+    """Registry of packed weight images (lgs_conv_pack_desc / lgs_pack_weights_batch).  Every conv module OWNS the
+    images of its launch shapes (`_pack_cache` dict on the module, one entry per (direction, layout)); this registry
+    only holds them weakly, so a model that is dropped frees its images and is no longer re-packed.  An image is valid
+    while (epoch, parameter version, parameter address) are unchanged.  optimiser.step() of FlatSGD -- which updates the
     parameters through the C-ABI, invisible to torch's version counters -- calls repack_all(): ONE launch re-packs every
-    registered image from the updated weights, so the ~125 per-call pack launches of a step disappear."""
+    live image from the updated weights, so the ~125 per-call pack launches of a step disappear.
+    Writes torch's version counter does not see (`p.data.copy_()`, `p.data.uniform_()`, `dist.broadcast(p.data)`, a
+    raw-pointer write through the C-ABI) need invalidate(): reset_parameters(), load_state_dict() and BucketedDDP's
+    initial broadcast call it; any other `.data` write must be followed by ME.invalidate_packed_weights()."""
 
     def __init__(self):
-        self.entries = []
+        self.entries = weakref.WeakSet()
         self.epoch = 0
-        self._table = None          # device copy of the descriptors
+        self._table = None          # (device copy of the descriptors, entry list, max_total)
         self._dirty = True
         self.enabled = os.environ.get("LGS_NO_PACK_CACHE") is None
+
+    def invalidate(self):
+        """every cached image is re-packed from its parameter on next use"""
+        self.epoch += 1
 
     def lookup(self, cache, km, op, transposed, weight, w32, cin, cout, dt):
         """-> (packed buffer or None, pack_mode)"""
@@ -87,39 +113,54 @@ class PackedWeights:
         key = (op, int(transposed), dt, d.ncp, d.nbp, d.K, cin, cout)
         ent = cache.get(key)
         if ent is None:
-            ent = {"buf": torch.empty(int(d.bytes), dtype=torch.uint8, device=w32.device), "desc": d, "valid": None, "param": weight}
-            d.packed = ent["buf"].data_ptr()
+            buf = torch.empty(int(d.bytes), dtype=torch.uint8, device=w32.device)
+            desc = {f: getattr(d, f) for f in _DESC_FIELDS}
+            desc["packed"], desc["weight"] = buf.data_ptr(), w32.data_ptr()
+            ent = _PackEntry(buf, desc, weight)
             cache[key] = ent
-            self.entries.append(ent)
+            self.entries.add(ent)
             self._dirty = True
         stamp = (self.epoch, weight._version, w32.data_ptr())
-        if ent["desc"].weight != w32.data_ptr():
-            ent["desc"].weight = w32.data_ptr()
+        if ent.desc["weight"] != w32.data_ptr():
+            ent.desc["weight"] = w32.data_ptr()
             self._dirty = True
-        if ent["valid"] == stamp:
-            return ent["buf"], 2
-        ent["valid"] = stamp
-        return ent["buf"], 1
+        if ent.valid == stamp:
+            return ent.buf, 2
+        ent.valid = stamp
+        return ent.buf, 1
 
     def repack_all(self):
-        """after the parameters changed behind torch's back (FlatSGD): new epoch, one batched re-pack"""
+        """after the parameters changed behind torch's back (FlatSGD): new epoch, one batched re-pack of the live images"""
         self.epoch += 1
-        live = [e for e in self.entries if e["param"].dtype == torch.float32 and e["param"].is_contiguous()]
-        if not self.enabled or not live:
+        if not self.enabled:
             return
-        if self._dirty or self._table is None or self._table[1] != len(live):
-            for e in live:
-                e["desc"].weight = e["param"].data_ptr()
-            arr = (engine.PackDesc * len(live))(*[e["desc"] for e in live])
+        live = []
+        for e in list(self.entries):
+            p = e.param_ref()
+            if p is not None and p.dtype == torch.float32 and p.is_contiguous() and p.is_cuda:
+                live.append((e, p))
+        if not live:
+            self._table = None
+            return
+        ids = tuple(id(e) for e, _ in live)
+        if self._dirty or self._table is None or self._table[1] != ids or any(e.desc["weight"] != p.data_ptr() for e, p in live):
+            for e, p in live:
+                e.desc["weight"] = p.data_ptr()
+            arr = (engine.PackDesc * len(live))(*[e.cdesc() for e, _ in live])
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
-            self._table = (host.to(live[0]["buf"].device), len(live), max(int(e["desc"].total) for e in live))
+            self._table = (host.to(live[0][0].buf.device), ids, max(int(e.desc["total"]) for e, _ in live))
             self._dirty = False
-        tab, n, max_total = self._table
+        tab, _, max_total = self._table
         with torch.cuda.device(tab.device):
-            engine.check(engine.lib().lgs_pack_weights_batch(_ptr(tab), n, max_total, _stream()))
-        for e in live:
-            p = e["param"]
-            e["valid"] = (self.epoch, p._version, p.data_ptr())
+            engine.check(engine.lib().lgs_pack_weights_batch(_ptr(tab), len(live), max_total, _stream()))
+        for e, p in live:
+            e.valid = (self.epoch, p._version, p.data_ptr())
+
+
+def invalidate_packed_weights():
+    """call after writing conv weights behind torch's version counters (`.data` writes, raw-pointer updates)"""
+    if _PACKED is not None:
+        _PACKED.invalidate()
 
 
 class HipKernelMap:
@@ -199,9 +240,11 @@ class HipKernelMap:
         cin, cout = x.shape[1], gout.shape[1]
         # strided input (see conv_forward): only the position-stationary bf16 kernel reads it in place
         ld = _row_strided(x, cin) if (x.dtype == torch.bfloat16 and self.ks in (2, 3) and cin % 8 == 0 and cout % 8 == 0) else None
+        dt = _dtype_code(x)
+        if ld is not None and not L.lgs_conv_wgrad_supports_stride(self.h, int(transposed), cin, cout, dt, int(ld)):
+            ld = None      # the position-stationary kernel declines this shape: hand the pair-list kernel a contiguous copy
         if ld is None:
             x = x.contiguous()
-        dt = _dtype_code(x)
         assert gout.dtype == x.dtype
         with torch.cuda.device(x.device):
             if out is not None:
@@ -312,6 +355,10 @@ class HipBackend:
 
     def new_manager(self, device):
         return HipManager(device)
+
+    def invalidate_packed_weights(self):
+        """conv weights were written behind torch's version counters (`.data` writes): re-pack on next use"""
+        invalidate_packed_weights()
 
     def weights_updated(self):
         """the optimiser changed the parameters outside autograd: re-pack every cached weight image in one launch"""

@@ -22,6 +22,15 @@ class MinkowskiModuleBase(nn.Module):
     pass
 
 
+_WGRAD_SEQ = [0]     # issue order of the side-stream weight gradients (the stream runs them in this order)
+
+
+def _invalidate_packed():
+    be = get_backend()
+    if hasattr(be, "invalidate_packed_weights"):
+        be.invalidate_packed_weights()
+
+
 class MinkowskiNetwork(nn.Module):
     """models/model.py:4-16 subclasses this and stores D."""
 
@@ -85,6 +94,17 @@ class MinkowskiConvolutionFunction(torch.autograd.Function):
                 side.wait_stream(main)                       # feats / gout are ready
                 with torch.cuda.stream(side):
                     gw = ctx.kmap.conv_wgrad(feats, gout, ctx.transposed, out=view.view(ctx.kmap.K, -1, ctx.kshape[-1]))
+                    # one reusable event per parameter: BucketedDDP waits for exactly the weight gradients of the bucket it
+                    # is about to reduce (ddp._wait_bucket_wgrads), not for the whole side stream
+                    kp = ctx.kparam
+                    ev = getattr(kp, "_lgs_wgrad_event", None)
+                    if ev is None:
+                        ev = kp._lgs_wgrad_event = torch.cuda.Event()
+                    ev.record(side)
+                    _WGRAD_SEQ[0] += 1
+                    kp._lgs_wgrad_seq = _WGRAD_SEQ[0]
+                    owner = getattr(kp, "_lgs_ddp", None)
+                    kp._lgs_wgrad_step = owner._step if owner is not None else -1
                 feats.record_stream(side)
                 gout.record_stream(side)
                 gw = view                                    # consumers wait for the side stream in BucketedDDP
@@ -162,6 +182,14 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
         self.kernel = nn.Parameter(torch.empty(kshape, dtype=torch.float32))
         self.bias = nn.Parameter(torch.empty((1, out_channels), dtype=torch.float32)) if bias else None
         self.reset_parameters()
+        # load_state_dict() copies into `.data` without bumping the parameter's version counter: drop the packed images
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: _invalidate_packed())
+
+    def __getstate__(self):
+        # packed weight images are a device-side cache tied to this process: never pickled / deep-copied with the module
+        state = self.__dict__.copy()
+        state["_pack_cache"] = {}
+        return state
 
     def reset_parameters(self, is_transpose=None):
         is_transpose = self.is_transpose if is_transpose is None else is_transpose
@@ -171,6 +199,7 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
             self.kernel.data.uniform_(-stdv, stdv)
             if self.bias is not None:
                 self.bias.data.uniform_(-stdv, stdv)
+        _invalidate_packed()      # `.data` writes are invisible to the version counter the packed-image cache keys on
 
     def forward(self, input, coordinates=None, bn=None):
         """`bn` (extension used by the build's own models): the MinkowskiBatchNorm this output goes to next.  In training

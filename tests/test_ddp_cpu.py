@@ -197,3 +197,94 @@ def _double_backward_job(rank, world):
 def test_hook_after_reduce_raises():
     """a second backward without zero_grad()/no_sync() would accumulate into a bucket whose all-reduce may be in flight"""
     assert all(run_distributed(_double_backward_job))
+
+
+def _rs_ag_job(rank, world):
+    """the reduce-scatter + all-gather form of the bucket reduction (BucketedDDP(allreduce="rs_ag")): same gradients as
+    the ring all-reduce, buckets padded to a multiple of the world size"""
+    from languagegroundedsemseg_amd.ddp import BucketedDDP, FlatSGD
+    torch.manual_seed(100)
+    net = Net()
+    ddp = BucketedDDP(net, bucket_mb=0.0005, allreduce="rs_ag")
+    assert all(b["flat"].numel() % (4 * world) == 0 for b in ddp.buckets)
+    opt = FlatSGD(ddp, lr=0.05, momentum=0.9, dampening=0.1, weight_decay=1e-2)
+    torch.manual_seed(7)
+    full, target = torch.randn(3, 8, 8), torch.randn(3, 8, 4)
+    for step in range(3):
+        x, y = full[step, rank * 4:(rank + 1) * 4], target[step, rank * 4:(rank + 1) * 4]
+        ddp.zero_grad()
+        ((ddp(x) - y) ** 2).mean().backward()
+        ddp.finalize()
+        opt.step()
+    return torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+
+
+def test_reduce_scatter_all_gather_buckets_match_torch_sgd_on_the_full_batch():
+    p0, p1 = run_distributed(_rs_ag_job)
+    assert torch.equal(p0, p1)
+    torch.manual_seed(100)
+    net = Net()
+    to = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, dampening=0.1, weight_decay=1e-2)
+    torch.manual_seed(7)
+    full, target = torch.randn(3, 8, 8), torch.randn(3, 8, 4)
+    for step in range(3):
+        to.zero_grad(set_to_none=True)
+        ((net(full[step]) - target[step]) ** 2).mean().backward()
+        to.step()
+    ref = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    assert torch.allclose(p0, ref, atol=1e-6)
+
+
+class BranchNet(nn.Module):
+    """a data-dependent branch: rank 0 never uses `b`, rank 1 never uses `c` (why the reference runs
+    find_unused_parameters=True, main.py:193)"""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 8)
+        self.b = nn.Linear(8, 4)
+        self.c = nn.Linear(8, 4)
+        self.d = nn.Linear(8, 8)
+
+    def forward(self, x, use_b):
+        h = torch.relu(self.a(self.d(x)))
+        return self.b(h) if use_b else self.c(h)
+
+
+def _uneven_unused_job(rank, world):
+    from languagegroundedsemseg_amd.ddp import BucketedDDP, FlatSGD
+    torch.manual_seed(5)
+    net = BranchNet()
+    ddp = BucketedDDP(net, bucket_mb=0.0001)          # one bucket per parameter or two: hooks fire in different orders per rank
+    opt = FlatSGD(ddp, lr=0.05, momentum=0.9, dampening=0.1, weight_decay=1e-2)
+    assert len(ddp.buckets) >= 4
+    torch.manual_seed(9)
+    xs = torch.randn(2, 2, 4, 8)
+    for step in range(2):
+        ddp.zero_grad()
+        ddp.module(xs[step, rank], use_b=(rank == 1)).pow(2).mean().backward()
+        ddp.finalize()
+        opt.step()
+    # the reduced bucket slots (a parameter unused on THIS rank keeps .grad = None, its slot still holds the average)
+    slots = torch.cat([b["flat"][:b["grad_elems"]] for b in ddp.buckets])
+    return slots, torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+
+
+def test_ranks_with_different_unused_parameters_reduce_in_the_same_bucket_order():
+    """collectives must be issued in a fixed bucket order on every rank: with per-rank unused sets a hook-order launch
+    would pair bucket k of one rank with bucket j of the other (hang, or silently mixed gradients)"""
+    (g0, p0), (g1, p1) = run_distributed(_uneven_unused_job)
+    assert torch.allclose(g0, g1, atol=1e-7)
+    # a parameter used on only ONE rank moves identically on both (the all-reduced "used" flag drives FlatSGD's mask)
+    assert torch.equal(p0, p1)
+    torch.manual_seed(5)
+    net = BranchNet()
+    to = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, dampening=0.1, weight_decay=1e-2)
+    torch.manual_seed(9)
+    xs = torch.randn(2, 2, 4, 8)
+    for step in range(2):
+        to.zero_grad(set_to_none=True)
+        (0.5 * (net(xs[step, 0], False).pow(2).mean() + net(xs[step, 1], True).pow(2).mean())).backward()
+        to.step()
+    ref = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    assert torch.allclose(p0, ref, atol=1e-6)
