@@ -84,6 +84,18 @@ class ConvLog:
             def f(self, *a, **k):
                 if log.mode is None:
                     return orig(self, *a, **k)
+                if log.mode == "roctx":      # profiling runs (tools/collect_profiles.sh): name the launches of this call by shape
+                    if kind == "wgrad":
+                        nm = "lgs wgrad K=%d %d->%d rows=%d" % (self.K, a[0].shape[1], a[1].shape[1], a[1].shape[0])
+                    elif kind == "fwd":
+                        nm = "lgs conv_fwd K=%d %d->%d rows=%d" % (self.K, a[0].shape[1], a[1].shape[-1], self._rows(a[3])[1])
+                    else:
+                        nm = "lgs conv_dgrad K=%d %d->%d rows=%d" % (self.K, a[0].shape[1], a[1].shape[-2], self._rows(a[2])[0])
+                    log.roctx.roctxRangePushA(nm.encode())
+                    try:
+                        return orig(self, *a, **k)
+                    finally:
+                        log.roctx.roctxRangePop()
                 if kind == "wgrad":
                     cin, cout, n_out = a[0].shape[1], a[1].shape[1], a[1].shape[0]
                 elif kind == "fwd":
@@ -141,22 +153,38 @@ def build(device, dtype, n_classes=200, model_name="Res16UNet34C"):
 
 
 _DATA_STREAM = {}
-_CLIP = None   # set by main() for --workload clip
-_PHASES = [] if os.environ.get("LGS_BENCH_PHASES") == "1" else None   # diagnostics: per-step phase events on the compute stream
+_PHASES = []      # (tag, HIP event on the compute stream, host time) -- five marks per step, drained by phase_summary()
 
 
 def _mark(tag):
-    if _PHASES is not None:
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        _PHASES.append((tag, e, time.perf_counter()))
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    _PHASES.append((tag, e, time.perf_counter()))
 
 
-def train_step(model, ddp, opt, coords, feats, labels, dtype, step_idx, shift=True):
-    """One fine-tune step.  The input side (the trainer's per-step coordinate shift, the feature cast and the
+def phase_summary(steps):
+    """per-step milliseconds between the marks of the last `steps` steps: on the compute stream (HIP events) and on the
+    host (enqueue time).  `finalize` = joining the weight-gradient stream + (N > 1) the exposed part of the bucket
+    all-reduces; call after torch.cuda.synchronize()."""
+    ev = _PHASES[-5 * steps:]
+    acc, host = {}, {}
+    for j in range(steps):
+        blk = ev[5 * j:5 * j + 5]
+        for a, b in zip(blk[:-1], blk[1:]):
+            acc[b[0]] = acc.get(b[0], 0.0) + a[1].elapsed_time(b[1])
+            host[b[0]] = host.get(b[0], 0.0) + (b[2] - a[2]) * 1e3
+    del _PHASES[:]
+    return {"stream_ms": {k: v / steps for k, v in acc.items()}, "host_enqueue_ms": {k: v / steps for k, v in host.items()}}
+
+
+def train_step(model, ddp, opt, coords, feats, labels, dtype, step_idx, shift=True, ctx=None):
+    """One training step.  The input side (the trainer's per-step coordinate shift, the feature cast and the
     SparseTensor construction = coordinate insert) runs on a separate "data" stream, like a DataLoader's copy
     stream: the engine builds all coordinate / kernel maps on the manager's own stream, so the maps of step t+1 are
-    constructed while step t's backward is still running on the compute stream."""
+    constructed while step t's backward is still running on the compute stream.
+    ctx: None = cross-entropy fine-tune (configs[1]); {"kind": "clip", crit, anchors} = CLIP-contrastive pretrain
+    (configs[2], pl_RepresentationTrainer.py:168-264); {"kind": "insseg", inst, centers} = instance-segmentation step
+    (configs[4], downstream/insseg/lib/pl_Trainer.py:245-321: CE + offset-L1 + direction losses)."""
     main = torch.cuda.current_stream()
     dev = coords.device
     ds = _DATA_STREAM.setdefault(dev.index, torch.cuda.Stream(device=dev))
@@ -175,9 +203,15 @@ def train_step(model, ddp, opt, coords, feats, labels, dtype, step_idx, shift=Tr
         t.record_stream(main)
     ddp.zero_grad()
     _mark("start")
-    if _CLIP is not None:   # --workload clip (BASELINE configs[2]): representation model + CLIP text-anchor loss
+    kind = ctx["kind"] if ctx else "ce"
+    if kind == "clip":
         out = model(sinput)
-        loss, _, _ = _CLIP["crit"](out.F, labels, _CLIP["anchors"])
+        loss, _, _ = ctx["crit"](out.F, labels, ctx["anchors"])
+    elif kind == "insseg":
+        from languagegroundedsemseg_amd.losses import instance_offset_losses
+        off, logits, _ = model(sinput)
+        nl, dl = instance_offset_losses(off.F, c[:, 1:], ctx["centers"], ctx["inst"], 0.02)
+        loss = fused_cross_entropy(logits.F, labels, ignore_index=-1) + nl + dl
     else:
         logits, _ = model(sinput)
         loss = fused_cross_entropy(logits.F, labels, ignore_index=-1)
@@ -189,6 +223,20 @@ def train_step(model, ddp, opt, coords, feats, labels, dtype, step_idx, shift=Tr
     opt.step()
     _mark("optimizer")
     return loss
+
+
+def timed_steps(model, ddp, opt, coords, feats, labels, dtype, steps, warmup, ctx=None, base=20000):
+    """`warmup` untimed + `steps` timed steps of a secondary workload -> (ms per step, phases)"""
+    for i in range(warmup):
+        train_step(model, ddp, opt, coords, feats, labels, dtype, base + i, ctx=ctx)
+    torch.cuda.synchronize()
+    del _PHASES[:]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        train_step(model, ddp, opt, coords, feats, labels, dtype, base + 100 + i, ctx=ctx)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dt / steps * 1e3, phase_summary(steps)
 
 
 def cpu_baseline(seconds_budget=30.0, model_name="Res16UNet34C", voxels=150000):
@@ -247,17 +295,17 @@ def pmc_traffic(dom_key, args):
         return None, None
 
 
-def single_scene_line(model, ddp, opt, dtype, device, args, steps=15, warmup=5):
+def single_scene_line(model, ddp, opt, dtype, device, args, ctx=None, steps=15, warmup=5):
     """Secondary line: ONE ~150k-voxel scene per step (the unit SURVEY 8d tabulates).  With ~720 launches on the critical
     path the step is launch / latency bound at this size; reported so the 8-scene headline is not read as per-scene."""
     c_np, f_np, l_np = make_batch([1000], voxel=0.02, n_target=args.voxels)
     c, f, l = torch.from_numpy(c_np).to(device), torch.from_numpy(f_np).to(device), torch.from_numpy(l_np).to(device)
     for i in range(warmup):
-        train_step(model, ddp, opt, c, f, l, dtype, 5000 + i)
+        train_step(model, ddp, opt, c, f, l, dtype, 5000 + i, ctx=ctx)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        train_step(model, ddp, opt, c, f, l, dtype, 6000 + i)
+        train_step(model, ddp, opt, c, f, l, dtype, 6000 + i, ctx=ctx)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"scenes_per_step": 1, "voxels": int(c.shape[0]), "ms_per_step": dt / steps * 1e3, "value": c.shape[0] * steps / dt,
@@ -305,6 +353,169 @@ def host_cores():
         return os.cpu_count() or 1
 
 
+def workload_text(workload, model_name):
+    if workload == "ce":
+        return ("%s 2cm ScanNet200-shaped synthetic scenes, cross-entropy fine-tune step (configs[1]): SparseTensor build + "
+                "fwd + CE(200) + bwd + grad all-reduce + SGD" % model_name)
+    if workload == "clip":
+        return ("%s 2cm synthetic scenes, CLIP-contrastive pretrain step (configs[2]): SparseTensor build + fwd + text-anchor "
+                "contrastive loss (200 anchors, MFMA contraction) + bwd + grad all-reduce + SGD" % model_name)
+    return ("%s 2cm synthetic scenes, instance-segmentation step (configs[4]%s): SparseTensor build + fwd + CE(200) + offset-L1 + "
+            "direction losses + bwd + SGD" % (model_name, ", frozen trunk" if workload == "insseg_frozen" else ""))
+
+
+def make_ctx(workload, model_name, coords, device):
+    """loss-side context of a workload (None = cross-entropy)"""
+    if workload == "clip":
+        from languagegroundedsemseg_amd.losses import ContrastiveLanguageLoss
+        from languagegroundedsemseg_amd.synthetic import text_anchors
+        dim = models.load_model(model_name).PLANES[7]
+        return {"kind": "clip", "crit": ContrastiveLanguageLoss(num_labels=200, num_negative_samples=3),
+                "anchors": torch.from_numpy(text_anchors(200, dim)).to(device)}
+    if workload in ("insseg", "insseg_frozen"):
+        g = torch.Generator().manual_seed(0)
+        n = coords.shape[0]
+        inst = torch.randint(-1, 30, (n,), generator=g).to(device)
+        centers = coords[:, 1:].float() + (torch.randn(n, 3, generator=g) * 20).to(device)
+        return {"kind": "insseg", "inst": inst, "centers": centers, "frozen": workload == "insseg_frozen"}
+    return None
+
+
+def make_trainer(model_name, dtype, device, world, args, ctx):
+    model = build(device, dtype, model_name=model_name)
+    if ctx and ctx["kind"] == "clip":
+        model.representation_only(True)
+    if ctx and ctx["kind"] == "insseg" and ctx["frozen"]:
+        model.freeze_trunk(True)
+    if world > 1 and args.sync_bn:
+        model = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)
+    ddp = BucketedDDP(model, bucket_mb=32.0, allreduce=args.allreduce)
+    opt = FlatSGD(ddp, lr=1e-2, momentum=0.9, dampening=0.1, weight_decay=1e-4)  # same rule as lib/solvers.py's SGD
+    return model, ddp, opt
+
+
+def measure(model, ddp, opt, coords, feats, labels, dtype, steps, warmup, ctx, clog, world, want_roofline, base=0):
+    """`warmup` untimed steps (the last but one is the fully instrumented DISCOVERY step when a ConvLog is given), then
+    exactly `steps` timed steps bracketed by barrier + synchronize on both sides -> dict(dt, loss, disc, step_ms, phases)"""
+    disc = None
+    if clog is not None:
+        clog.rows, clog.mode, clog.only_key = [], None, None
+    for i in range(warmup):   # un-synchronised, like the timed loop: allocator pools reach their pipelined steady state
+        if i == max(0, warmup - 2) and want_roofline:
+            # DISCOVERY step (inside the warm-up, every rank runs it): every conv launch is bracketed by HIP events to rank
+            # the launch shapes and to evaluate the byte model on the real maps; this stretches the step, so its
+            # durations are only used to pick the dominant shape
+            if clog is not None:
+                clog.mode = "all"
+            train_step(model, ddp, opt, coords, feats, labels, dtype, base + i, ctx=ctx)
+            if clog is not None:
+                fam, wg, top = clog.summarize()
+                disc = dict(fam=fam, wg=wg, top=top, rows=list(clog.rows))
+                clog.rows = []
+                clog.mode = "only"              # from here on only the dominant shape's launches are bracketed
+                clog.only_key = top[0][0]
+        else:
+            train_step(model, ddp, opt, coords, feats, labels, dtype, base + i, ctx=ctx)
+    torch.cuda.synchronize()
+    if clog is not None:
+        clog.rows = []                          # keep only the samples of the timed steps
+    if ddp.timing is not None:
+        ddp.timing_summary(1)                   # drop the warm-up's collective events
+    del _PHASES[:]
+    log("warmup done (%d steps)" % warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    marks[0].record()
+    for i in range(steps):
+        loss = train_step(model, ddp, opt, coords, feats, labels, dtype, base + warmup + i, ctx=ctx)
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"dt": dt, "loss": loss, "disc": disc, "phases": phase_summary(steps),
+            "step_ms": [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]}
+
+
+def roofline_report(clog, disc, dtype_name, workload, steps, ms_per_step, n_vox, traffic_pair):
+    """the `roofline` object of the JSON line from a ConvLog's discovery step + its in-step samples of the dominant shape"""
+    clog.mode = None
+    fam, wg, top = disc["fam"], disc["wg"], disc["top"]
+    e = 2 if dtype_name == "bf16" else 4
+    # BN byte model (SURVEY 8d): 3 N C e fwd + 5 N C e bwd per norm layer; every BN follows exactly one conv forward
+    # launch with the same (n_out, cout), except the classifier `final` (fine-tune workload)
+    fwd_rows = [r for r in disc["rows"] if r["kind"] == "fwd"]
+    bn_bytes = sum(8.0 * r["n_out"] * r["cout"] * e for r in (fwd_rows[:-1] if workload == "ce" else fwd_rows))
+    b_alg_step = fam["bytes"] + wg["bytes"] + bn_bytes
+    dom_key, dom_disc = top[0]
+    # the dominant shape's launches sampled INSIDE the timed steps (un-instrumented otherwise)
+    samp = [r for r in clog.rows if r["key"] == dom_key]
+    samp_ms = [r["ev"][0].elapsed_time(r["ev"][1]) for r in samp]
+    n_s = max(len(samp_ms), 1)
+    avg_ms = sum(samp_ms) / n_s
+    alg_bytes = dom_disc["bytes"] / max(dom_disc["n"], 1)
+    flop = dom_disc["flop"] / max(dom_disc["n"], 1)
+    achieved = alg_bytes / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
+    traffic, traffic_src = traffic_pair
+    fam_ach = fam["bytes"] / (fam["ms"] * 1e-3) if fam["ms"] > 0 else 0.0
+    mfma_peak = 2.5e15 if dtype_name == "bf16" else 157.3e12
+    return {
+        "bound": "hbm",
+        "kernel": "k_conv_gather (sparse-conv forward/dgrad implicit GEMM), dominant launch shape: " + dom_key,
+        "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+        "traffic": traffic, "traffic_source": traffic_src,
+        # launches of this shape in ONE step (forward + dgrad launches; the 3^3 96->96 shape of Res16UNet34C: 4 forward + 5
+        # backward ... counted from the discovery step, the same number DESIGN.md quotes)
+        "launches_sampled": len(samp_ms), "launches_per_step": dom_disc["n"], "avg_launch_ms": avg_ms,
+        "min_launch_ms": min(samp_ms) if samp_ms else None, "max_launch_ms": max(samp_ms) if samp_ms else None,
+        "alg_bytes_per_launch": alg_bytes,
+        "mfma_tflops_on_real_pairs": flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
+        "mfma_frac_of_peak_on_real_pairs": flop / (avg_ms * 1e-3) / mfma_peak if avg_ms > 0 else 0.0,
+        "measured": "HIP events on the launching stream around the %d launches of this shape inside the %d timed steps "
+                    "(weight pack ~6 us + kernel); all other launches of the timed steps are un-instrumented" % (len(samp_ms), steps),
+        "discovery_step": {
+            "note": "one fully instrumented warm-up step (every conv launch bracketed: the step is stretched, durations "
+                    "rank the shapes and feed the byte model only)",
+            "family": {"kernel": "k_conv_gather, all %d launches of the step" % fam["n"], "achieved": fam_ach / 1e9,
+                       "frac": fam_ach / HBM_PEAK, "total_ms": fam["ms"], "avg_launch_ms": fam["ms"] / max(fam["n"], 1)},
+            "wgrad": {"kernel": "k_wgrad_ps / k_wgrad_bf16 + reduce, all %d launches (side stream)" % wg["n"],
+                      "achieved": (wg["bytes"] / (wg["ms"] * 1e-3) / 1e9) if wg["ms"] > 0 else 0.0,
+                      "frac": (wg["bytes"] / (wg["ms"] * 1e-3) / HBM_PEAK) if wg["ms"] > 0 else 0.0, "total_ms": wg["ms"]},
+            "top_shapes": [{"shape": k, "launches": g["n"], "ms": g["ms"], "alg_GBps": g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] else 0.0,
+                            "mfma_tflops": g["flop"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] else 0.0}
+                           for k, g in top[:6]]},
+        "step": {"b_alg_bytes": b_alg_step, "b_alg_per_voxel": b_alg_step / n_vox,
+                 "frac_of_hbm_peak": b_alg_step / (ms_per_step * 1e-3) / HBM_PEAK},
+    }
+
+
+def secondary_block(workload, model_name, dtype, coords, feats, labels, device, args, clog, steps, warmup, note):
+    """a few timed steps of another BASELINE configuration on the same resident batch -> dict for the JSON line"""
+    import gc
+    ctx = make_ctx(workload, model_name, coords, device)
+    model, ddp, opt = make_trainer(model_name, dtype, device, 1, args, ctx)
+    res = measure(model, ddp, opt, coords, feats, labels, dtype, steps, warmup, ctx, clog, 1, clog is not None, base=30000)
+    n_vox = int(coords.shape[0])
+    ms = res["dt"] / steps * 1e3
+    dname = "bf16" if dtype == torch.bfloat16 else "fp32"
+    out = {"workload": workload_text("insseg" if workload.startswith("insseg") and not workload.endswith("frozen") else workload, model_name),
+           "note": note, "dtype": dname, "steps": steps, "warmup": warmup, "voxels_per_step": n_vox, "ms_per_step": ms,
+           "value": n_vox * steps / res["dt"], "unit": "voxels/s", "final_loss": float(res["loss"].item()), "phases": res["phases"]}
+    if clog is not None and res["disc"] is not None:
+        out["roofline"] = roofline_report(clog, res["disc"], dname, "clip" if workload == "clip" else ("ce" if workload == "ce" else "insseg"),
+                                          steps, ms, n_vox, (None, None))
+        if workload == "clip":
+            out["roofline"]["mfma"] = clip_mfma_report(out_dim=model.PLANES[7], n=n_vox, dtype=dtype, device=device)
+    del model, ddp, opt, res
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -320,6 +531,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single-scene", action="store_true", help="skip the secondary 1-scene-per-step measurement")
+    ap.add_argument("--roctx", action="store_true", help="profiling runs: wrap every conv / dgrad / wgrad engine call in a ROCTx range "
+                                                       "named by its layer shape (rocprofv3 --marker-trace), no HIP events")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the fp32 / clip (configs[2]) / insseg (configs[4]) blocks of the default line")
+    ap.add_argument("--allreduce", default="ring", choices=["ring", "rs_ag"],
+                    help="gradient-bucket reduction for N > 1: ring = one all-reduce per bucket; rs_ag = reduce-scatter + all-gather "
+                         "on the flat bucket (all xGMI links at once, SURVEY section 5)")
     ap.add_argument("--sync-bn", type=int, default=1, help="convert to MinkowskiSyncBatchNorm when gpus > 1 (main.py:122)")
     ap.add_argument("--compute-priority", type=int, default=0, help="run the compute stream at this HIP stream priority "
                                                                      "(-1 = high: dgrad/BN chain ahead of the side-stream wgrad)")
@@ -364,18 +581,8 @@ def main():
     n_vox = int(coords.shape[0])
     log("data resident: %d voxels in %d scenes" % (n_vox, args.scenes))
 
-    model = build(device, dtype, model_name=args.model)
-    if args.workload == "clip":
-        global _CLIP
-        from languagegroundedsemseg_amd.losses import ContrastiveLanguageLoss
-        from languagegroundedsemseg_amd.synthetic import text_anchors
-        model.representation_only(True)
-        _CLIP = {"crit": ContrastiveLanguageLoss(num_labels=200, num_negative_samples=3),
-                 "anchors": torch.from_numpy(text_anchors(200, model.PLANES[7])).to(device)}
-    if world > 1 and args.sync_bn:
-        model = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)
-    ddp = BucketedDDP(model, bucket_mb=32.0)
-    opt = FlatSGD(ddp, lr=1e-2, momentum=0.9, dampening=0.1, weight_decay=1e-4)  # same rule as lib/solvers.py's SGD
+    ctx = make_ctx(args.workload, args.model, coords, device)
+    model, ddp, opt = make_trainer(args.model, dtype, device, world, args, ctx)
 
     if args.compute_priority != 0:
         hp = torch.cuda.Stream(device=device, priority=args.compute_priority)
@@ -388,51 +595,17 @@ def main():
     if rank == 0 and not args.no_roofline:
         clog = ConvLog()
         clog.patch()
-    disc = None
-    for i in range(args.warmup):   # un-synchronised, like the timed loop: allocator pools reach their pipelined steady state
-        if i == max(0, args.warmup - 2) and not args.no_roofline:
-            # DISCOVERY step (inside the warm-up, every rank runs it): every conv launch is bracketed by HIP events to rank
-            # the launch shapes and to evaluate the byte model on the real maps; this stretches the step, so its
-            # durations are only used to pick the dominant shape
-            if clog is not None:
-                clog.mode = "all"
-            train_step(model, ddp, opt, coords, feats, labels, dtype, i)
-            if clog is not None:
-                fam, wg, top = clog.summarize()
-                disc = dict(fam=fam, wg=wg, top=top, rows=list(clog.rows))
-                clog.rows = []
-                clog.mode = "only"              # from here on only the dominant shape's launches are bracketed
-                clog.only_key = top[0][0]
-        else:
-            train_step(model, ddp, opt, coords, feats, labels, dtype, i)
-    torch.cuda.synchronize()
-    if clog is not None:
-        clog.rows = []                          # keep only the samples of the timed steps
-    log("warmup done (%d steps)" % args.warmup)
+    if args.roctx:
+        import ctypes
+        rl = ConvLog()
+        rl.patch()
+        rl.roctx = ctypes.CDLL("libroctx64.so")
+        rl.roctx.roctxRangePushA.argtypes = [ctypes.c_char_p]
+        rl.mode = "roctx"
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    marks[0].record()
-    for i in range(args.steps):
-        loss = train_step(model, ddp, opt, coords, feats, labels, dtype, args.warmup + i)
-        marks[i + 1].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if _PHASES is not None and rank == 0:
-        ev = _PHASES[-5 * args.steps:]
-        acc, host = {}, {}
-        for j in range(args.steps):
-            blk = ev[5 * j:5 * j + 5]
-            for a, b in zip(blk[:-1], blk[1:]):
-                acc[b[0]] = acc.get(b[0], 0.0) + a[1].elapsed_time(b[1])
-                host[b[0]] = host.get(b[0], 0.0) + (b[2] - a[2]) * 1e3
-        log("phases (ms per step, compute stream): " + ", ".join("%s %.2f" % (k, v / args.steps) for k, v in acc.items()))
-        log("phases (ms per step, host enqueue time): " + ", ".join("%s %.2f" % (k, v / args.steps) for k, v in host.items()))
+        ddp.enable_timing()
+    res = measure(model, ddp, opt, coords, feats, labels, dtype, args.steps, args.warmup, ctx, clog, world, not args.no_roofline)
+    dt, loss = res["dt"], res["loss"]
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     nv = torch.tensor([float(n_vox)], dtype=torch.float64, device=device)
     if world > 1:
@@ -444,74 +617,63 @@ def main():
     value = total_vox * args.steps / dt
     final_loss = float(loss.item())
     log("timed region done: %.2f ms/step, %.3g voxels/s" % (ms_per_step, value))
-    log("per-step ms (compute-stream events): " + " ".join("%.1f" % marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)))
+    log("per-step ms (compute-stream events): " + " ".join("%.1f" % m for m in res["step_ms"]))
+    log("phases (ms per step, compute stream): " + ", ".join("%s %.2f" % kv for kv in res["phases"]["stream_ms"].items()))
+    log("phases (ms per step, host enqueue time): " + ", ".join("%s %.2f" % kv for kv in res["phases"]["host_enqueue_ms"].items()))
 
     out = {
         "metric": "voxels/sec fwd+bwd Res16UNet34C @2cm ScanNet200", "value": value, "unit": "voxels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": ("%s 2cm ScanNet200-shaped synthetic scenes, cross-entropy fine-tune step "
-                                "(configs[1]): SparseTensor build + fwd + CE(200) + bwd + grad all-reduce + SGD" % args.model)
-                               if args.workload == "ce" else
-                               ("%s 2cm synthetic scenes, CLIP-contrastive pretrain step (configs[2]): SparseTensor build + fwd + "
-                                "text-anchor contrastive loss (200 anchors, MFMA contraction) + bwd + grad all-reduce + SGD" % args.model),
+        "config": {"workload": workload_text(args.workload, args.model),
                    "scenes_per_gpu": args.scenes, "voxels_per_gpu": n_vox, "global_voxels": int(total_vox),
                    "parallelism": "dp%d" % world, "sync_bn": bool(world > 1 and args.sync_bn),
+                   "allreduce": args.allreduce,
                    "storage": "bf16 features / fp32 master weights, fp32 accumulate + BN statistics" if args.dtype == "bf16"
                    else "fp32"},
         "final_loss": final_loss,
+        "phases": res["phases"],
     }
+    if world > 1:
+        # one record per rank: where a multi-GPU step spends its time (compute-stream phases, the part of the bucket
+        # all-reduces that backward did not hide, the compute-stream stalls inside SyncBN's small collectives)
+        mine = {"rank": rank, "phases": res["phases"], "ddp": ddp.timing_summary(args.steps), "ms_per_step": res["dt"] / args.steps * 1e3}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        out["per_rank"] = allr
+        out["rccl_ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                             "bucket_collectives_per_step": mine["ddp"]["bucket_collectives_per_step"] if mine["ddp"] else None,
+                             "syncbn_collectives_per_step": mine["ddp"]["syncbn_collectives_per_step"] if mine["ddp"] else None}
 
-    if clog is not None and disc is not None:
-        clog.mode = None
-        fam, wg, top = disc["fam"], disc["wg"], disc["top"]
-        e = 2 if args.dtype == "bf16" else 4
-        # BN byte model: 3 N C e fwd + 5 N C e bwd per norm layer; every BN follows exactly one conv forward
-        # launch with the same (n_out, cout), except the classifier `final` (fine-tune workload)
-        fwd_rows = [r for r in disc["rows"] if r["kind"] == "fwd"]
-        bn_bytes = sum(8.0 * r["n_out"] * r["cout"] * e for r in (fwd_rows[:-1] if args.workload == "ce" else fwd_rows))
-        b_alg_step = fam["bytes"] + wg["bytes"] + bn_bytes
-        dom_key, dom_disc = top[0]
-        # the dominant shape's launches sampled INSIDE the timed steps (un-instrumented otherwise)
-        samp = [r for r in clog.rows if r["key"] == dom_key]
-        samp_ms = [r["ev"][0].elapsed_time(r["ev"][1]) for r in samp]
-        n_s = max(len(samp_ms), 1)
-        avg_ms = sum(samp_ms) / n_s
-        alg_bytes = dom_disc["bytes"] / max(dom_disc["n"], 1)
-        flop = dom_disc["flop"] / max(dom_disc["n"], 1)
-        achieved = alg_bytes / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(dom_key, args)
-        fam_ach = fam["bytes"] / (fam["ms"] * 1e-3) if fam["ms"] > 0 else 0.0
-        out["roofline"] = {
-            "bound": "hbm",
-            "kernel": "k_conv_gather (sparse-conv forward/dgrad implicit GEMM), dominant launch shape: " + dom_key,
-            "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-            "traffic": traffic, "traffic_source": traffic_src,
-            "launches_sampled": len(samp_ms), "launches_per_step": dom_disc["n"], "avg_launch_ms": avg_ms,
-            "min_launch_ms": min(samp_ms) if samp_ms else None, "max_launch_ms": max(samp_ms) if samp_ms else None,
-            "alg_bytes_per_launch": alg_bytes,
-            "mfma_tflops_on_real_pairs": flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
-            "measured": "HIP events on the launching stream around the %d launches of this shape inside the %d timed steps "
-                        "(weight pack ~6 us + kernel); all other launches of the timed steps are un-instrumented" % (len(samp_ms), args.steps),
-            "discovery_step": {
-                "note": "one fully instrumented warm-up step (every conv launch bracketed: the step is stretched, durations "
-                        "rank the shapes and feed the byte model only)",
-                "family": {"kernel": "k_conv_gather, all %d launches of the step" % fam["n"], "achieved": fam_ach / 1e9,
-                           "frac": fam_ach / HBM_PEAK, "total_ms": fam["ms"], "avg_launch_ms": fam["ms"] / max(fam["n"], 1)},
-                "wgrad": {"kernel": "k_wgrad_ps / k_wgrad_bf16 + reduce, all %d launches (side stream)" % wg["n"],
-                          "achieved": (wg["bytes"] / (wg["ms"] * 1e-3) / 1e9) if wg["ms"] > 0 else 0.0,
-                          "frac": (wg["bytes"] / (wg["ms"] * 1e-3) / HBM_PEAK) if wg["ms"] > 0 else 0.0, "total_ms": wg["ms"]},
-                "top_shapes": [{"shape": k, "launches": g["n"], "ms": g["ms"], "alg_GBps": g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] else 0.0}
-                               for k, g in top[:6]]},
-            "step": {"b_alg_bytes": b_alg_step, "b_alg_per_voxel": b_alg_step / n_vox,
-                     "frac_of_hbm_peak": b_alg_step / (ms_per_step * 1e-3) / HBM_PEAK},
-        }
+    if clog is not None and res["disc"] is not None:
+        out["roofline"] = roofline_report(clog, res["disc"], args.dtype, args.workload, args.steps, ms_per_step, n_vox,
+                                          pmc_traffic(res["disc"]["top"][0][0], args))
         if args.workload == "clip":
             out["roofline"]["mfma"] = clip_mfma_report(out_dim=model.PLANES[7], n=n_vox, dtype=dtype, device=device)
     log("roofline pass done")
+    secondary = rank == 0 and world == 1 and not args.no_secondary and args.workload == "ce" and args.dtype == "bf16"
     if rank == 0 and world == 1 and not args.no_single_scene and args.scenes != 1:
-        out["single_scene"] = single_scene_line(model, ddp, opt, dtype, device, args)
+        out["single_scene"] = single_scene_line(model, ddp, opt, dtype, device, args, ctx)
         log("single-scene line done")
+    if secondary:
+        # the other BASELINE configurations, each a few timed steps on the same 8-scene batch, so that their numbers sit in
+        # the driver's record next to the headline instead of in builder-only files
+        del model, ddp, opt
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["fp32"] = secondary_block("ce", "Res16UNet34C", torch.float32, coords, feats, labels, device, args, clog, steps=5, warmup=2,
+                                      note="the parity path (fp32 storage, exact-fp32 MFMA): logits within 1e-3 of the oracle")
+        log("fp32 block done")
+        out["clip"] = secondary_block("clip", "Res16UNet34D", torch.bfloat16, coords, feats, labels, device, args, clog, steps=5, warmup=2,
+                                      note="BASELINE configs[2] (scripts/text_representation_train.sh): Res16UNet34D + fused CLIP text-anchor loss")
+        log("clip block done")
+        out["insseg"] = {
+            "full": secondary_block("insseg", "InsSegRes16UNet34C", torch.bfloat16, coords, feats, labels, device, args, None, steps=5, warmup=2,
+                                    note="downstream/insseg step as the reference runs it (all parameters trained, pl_Trainer.py:81)"),
+            "frozen_trunk": secondary_block("insseg_frozen", "InsSegRes16UNet34C", torch.bfloat16, coords, feats, labels, device, args, None,
+                                            steps=5, warmup=2, note="BASELINE configs[4]: head on frozen pretrained features (eval-mode trunk under "
+                                                                    "no_grad, only offsets_pre / bntr_offset / offsets / final are trained)")}
+        log("insseg block done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model_name=args.model, voxels=args.voxels)
         log("cpu baseline done")

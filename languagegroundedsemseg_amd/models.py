@@ -179,7 +179,14 @@ class Res16UNet34D(Res16UNet34CR):
 
 class _InsSegHead:
     """downstream/insseg head on the same trunk (insseg_models/insseg_res16unet.py:197-199,260-265):
-    offsets = 1x1(C->3, bias)(ReLU(BN(1x1(C->C, bias)(block8 features)))); forward -> (offsets, logits, features)."""
+    offsets = 1x1(C->3, bias)(ReLU(BN(1x1(C->C, bias)(block8 features)))); forward -> (offsets, logits, features).
+
+    freeze_trunk(True) is BASELINE configs[4]'s framing ("instance-seg head on FROZEN pretrained features"; the reference
+    itself optimises all parameters, downstream/insseg/lib/pl_Trainer.py:81): the U-Net trunk stops requiring gradients,
+    its norms use their running statistics (eval mode, whatever .train() is called on the model), and the trunk runs
+    under no_grad -- the step is then trunk forward + head forward/backward (offsets_pre, bntr_offset, offsets, final)."""
+
+    HEAD = ("offsets_pre", "bntr_offset", "offsets", "final")
 
     def _add_head(self, D):
         c = self.PLANES[7]
@@ -187,9 +194,32 @@ class _InsSegHead:
         self.offsets_pre = _conv(c, c, 1, bias=True, D=D)
         self.bntr_offset = ME.MinkowskiBatchNorm(c, momentum=bn_m)
         self.offsets = _conv(c, 3, 1, bias=True, D=D)
+        self.trunk_frozen = False
+
+    def _trunk_modules(self):
+        return [m for n, m in self.named_children() if n not in self.HEAD]
+
+    def freeze_trunk(self, flag=True):
+        self.trunk_frozen = bool(flag)
+        for m in self._trunk_modules():
+            for p in m.parameters():
+                p.requires_grad_(not flag)
+        self.train(self.training)
+        return self
+
+    def train(self, mode=True):
+        super().train(mode)
+        if getattr(self, "trunk_frozen", False):
+            for m in self._trunk_modules():
+                m.eval()                                  # frozen features: running statistics, no updates
+        return self
 
     def forward(self, x, detach=False):
-        out = self.trunk(x)
+        if getattr(self, "trunk_frozen", False):
+            with torch.no_grad():
+                out = self.trunk(x)
+        else:
+            out = self.trunk(x)
         off = self.offsets(self.bntr_offset(self.offsets_pre(out), relu=True))
         return off, self.final(out), out
 

@@ -224,3 +224,54 @@ def test_strided_wgrad_query_and_contiguous_fallback():
     finally:
         bh.engine.lib().lgs_conv_wgrad_supports_stride = orig
     assert torch.equal(g_fb, g_copy)
+
+
+# ------------------------------------------------------------------------------------------- insseg, frozen trunk (configs[4])
+def _insseg_step(device, dtype, coords, feats, labels, inst, centers, frozen):
+    from languagegroundedsemseg_amd.losses import fused_cross_entropy, instance_offset_losses
+    m = deterministic_init(load_model("InsSegRes16UNet14A")(3, 20, Cfg()), 42).to(device)
+    if frozen:
+        m.freeze_trunk(True)
+    m.train()
+    c = torch.from_numpy(coords).to(device)
+    x = ME.SparseTensor(torch.from_numpy(feats).to(device).to(dtype), c)
+    off, logits, _ = m(x)
+    lab = torch.from_numpy(labels).to(device)
+    nl, dl = instance_offset_losses(off.F, c[:, 1:], torch.from_numpy(centers).to(device), torch.from_numpy(inst).to(device), 0.02)
+    ce = (torch.nn.functional.cross_entropy(logits.F.float(), lab, ignore_index=-1) if device == "cpu"
+          else fused_cross_entropy(logits.F, lab, ignore_index=-1))
+    (ce + nl + dl).backward()
+    grads = {k: p.grad.detach().float().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None}
+    frozen_ok = all((p.grad is None) for k, p in m.named_parameters() if k.split(".")[0] not in m.HEAD) if frozen else True
+    return off.F.detach().float().cpu().numpy(), logits.F.detach().float().cpu().numpy(), float(ce.detach() + nl.detach() + dl.detach()), grads, frozen_ok
+
+
+@pytest.mark.parametrize("frozen", [True, False])
+def test_insseg_step_at_size_vs_oracle(frozen):
+    """downstream/insseg/lib/pl_Trainer.py:245-321 (CE + offset-L1 + direction losses on trunk + offset head) on a
+    60 k-voxel scene, fp32 within 1e-3 of the oracle; frozen = BASELINE configs[4]'s head on frozen pretrained features
+    (eval-mode trunk on running statistics under no_grad, only the head gets gradients)"""
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    from test_gpu_parity_r2 import structured_labels
+    coords, feats, _ = make_batch([11], voxel=0.02, n_target=60000)
+    labels = structured_labels(coords)
+    rng = np.random.default_rng(4)
+    inst = rng.integers(-1, 30, coords.shape[0]).astype(np.int64)
+    centers = (coords[:, 1:].astype(np.float32) + rng.normal(0, 20, (coords.shape[0], 3)).astype(np.float32))
+    h = _insseg_step(DEV, torch.float32, coords, feats, labels, inst, centers, frozen)
+    prev = ME.set_backend(OracleBackend("torch"))
+    try:
+        o = _insseg_step("cpu", torch.float32, coords, feats, labels, inst, centers, frozen)
+    finally:
+        ME.set_backend(prev)
+    print("insseg %s: max |d offsets| %.2e, max |d logits| %.2e, loss %.6f vs %.6f" % (
+        "frozen trunk" if frozen else "full", np.abs(h[0] - o[0]).max(), np.abs(h[1] - o[1]).max(), h[2], o[2]))
+    assert h[4] and o[4], "a frozen trunk must not receive gradients"
+    assert np.abs(h[0] - o[0]).max() < 1e-3 and np.abs(h[1] - o[1]).max() < 1e-3 and abs(h[2] - o[2]) < 1e-4
+    assert set(h[3]) == set(o[3]) and (len(h[3]) == 8 if frozen else len(h[3]) > 50)
+    for k in o[3]:
+        assert rel_l2(h[3][k], o[3][k]) < 2e-2, (k, rel_l2(h[3][k], o[3][k]))
+    # bf16 storage of the same step: reported against the fp32 oracle
+    b = _insseg_step(DEV, torch.bfloat16, coords, feats, labels, inst, centers, frozen)
+    print("insseg bf16: offsets rel-L2 %.2e, logits rel-L2 %.2e, loss %.5f" % (rel_l2(b[0], o[0]), rel_l2(b[1], o[1]), b[2]))
+    assert rel_l2(b[1], o[1]) < 5e-2 and abs(b[2] - o[2]) < 2e-2
