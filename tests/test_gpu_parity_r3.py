@@ -87,11 +87,14 @@ def test_bf16_storage_trains_like_fp32_over_30_steps():
     print("max relative deviation from the fp32 oracle curve: HIP fp32 %.3e (step %d), HIP bf16 %.3e (step %d)" % (
         d32.max(), int(d32.argmax()), d16.max(), int(d16.argmax())))
     assert o32[-1] < 0.6 * o32[0], "the objective must actually be optimised (loss %.3f -> %.3f)" % (o32[0], o32[-1])
-    assert d32[:5].max() < 1e-4                       # the first steps are the same arithmetic up to summation order
-    assert d32.max() < 2e-2                           # fp32 trajectories drift apart slowly (ReLU gate flips); measured below
-    assert d16[0] < 5e-3                              # same weights, bf16 activations: the first loss
-    assert d16.max() < 6e-2                           # bf16 band around the fp32 curve
-    assert abs(h16[-5:].mean() - o32[-5:].mean()) < 0.05 * o32[-5:].mean()      # ... and it ends at the same level
+    # measured (MI355X, round 3): HIP fp32 1.4e-7 / 1.1e-6 / 6e-5 at steps 0-2, growing to 6.7e-3 at step 28 (two fp32
+    # implementations with different summation orders drift apart through ReLU gate flips under momentum 0.9);
+    # HIP bf16 <= 1.4e-2 everywhere, 5e-4 at step 1
+    assert d32[:2].max() < 1e-5                       # the first steps are the same arithmetic up to summation order
+    assert d32.max() < 2e-2                           # fp32 band
+    assert d16[0] < 2e-3                              # same weights, bf16 activations: the first loss
+    assert d16.max() < 4e-2                           # bf16 band around the fp32 curve
+    assert abs(h16[-5:].mean() - o32[-5:].mean()) < 0.03 * o32[-5:].mean()      # ... and it ends at the same level
 
 
 # ------------------------------------------------------------------------------------------- reference-signature CLIP loss

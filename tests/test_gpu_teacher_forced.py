@@ -7,7 +7,7 @@ residual, output and output-gradient are captured; then the HIP network runs on 
 module,
   * overwrite the module's input (in place, so zero-copy ME.cat column slices stay slices of the concat buffer) with the
     ORACLE's input,
-  * compare the module's HIP output with the oracle's output (<= 2e-2 rel-L2 per tensor, measured ~3e-3),
+  * compare the module's HIP output with the oracle's output (<= 1e-2 rel-L2 per tensor, measured <= 2.7e-3),
   * in backward overwrite every module-output gradient (in place: the gradient halves of a concat stay column slices)
     with the ORACLE's gradient after comparing what the HIP consumers produced for it,
 so every kernel launch of the step -- conv forward (incl. slot split, strided gathers), fused BN(+residual)(+ReLU) writing
@@ -31,7 +31,7 @@ from oracle.backend import OracleBackend
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TOL = 2e-2
+TOL = 1e-2        # per tensor, rel-L2; measured worst 3.4e-3 (BN-backward dx), conv outputs 2.7e-3, weight gradients 3e-6
 
 
 def rel_l2(a, b):
