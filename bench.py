@@ -599,7 +599,7 @@ def main():
         import ctypes
         rl = ConvLog()
         rl.patch()
-        rl.roctx = ctypes.CDLL("libroctx64.so")
+        rl.roctx = ctypes.CDLL("librocprofiler-sdk-roctx.so")
         rl.roctx.roctxRangePushA.argtypes = [ctypes.c_char_p]
         rl.mode = "roctx"
     if world > 1:

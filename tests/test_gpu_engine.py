@@ -21,7 +21,7 @@ def hip_tensor(feats, coords, dtype=torch.float32):
 
 def test_native_library_loaded():
     from languagegroundedsemseg_amd import engine
-    assert engine.lib().lgs_abi_version() == 4
+    assert engine.lib().lgs_abi_version() == engine.ABI_VERSION
     assert ME.get_backend().name == "hip"
 
 
