@@ -671,7 +671,10 @@ GatherCfg gather_cfg(const View &v, int nb_total) {
     // (id 16: eight waves of 32 positions x 256 channels -- no two waves gather the same rows; id 15, the earlier 4 x 2
     // wave layout with 64 x 128 per wave, stays selectable: LGS_WIDE_CFG=15.  512->512 at L0: 12.0 vs 12.2 ms, 256->256
     // at L1: 1.00 vs 1.06 ms)
-    static const int wide_cfg = getenv("LGS_WIDE_CFG") ? atoi(getenv("LGS_WIDE_CFG")) : 16;   // tuning knob
+    // id 17 (round 3): the 2-D blocked LDS-DMA kernel of lgs_conv_wide.hip; 15 / 16 stay selectable for A/B runs
+    static const int wide_cfg = getenv("LGS_WIDE_CFG") ? atoi(getenv("LGS_WIDE_CFG")) : 17;   // tuning knob
+    if (!kF32 && wide_cfg == 17 && (nb_total % 8 == 0 || nb_total >= 16) && !(v.KS == 1 && v.nbr == nullptr && nb_total < 16))
+      return {17, 2, 8, 256};
     if (!kF32 && nb_total % 8 == 0) return {wide_cfg == 15 ? 15 : 16, 2, 8, 256};
     if (!kF32) return {7, 2, 4, 128};   // bf16: 128-position tiles, 4 column blocks per wave at 3 waves/SIMD
     return {3, kF32 ? 1 : 2, 4, 256};
@@ -748,6 +751,12 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
                        (bn && !did_split) ? *bn : BnEpi(), gc, in_ld > 0 ? in_ld : cin_real);                     \
     if (bn_rows) *bn_rows = did_split ? 0 : (int)grid.x;                                                          \
   } while (0)
+  if (cfg.id == 17) {
+    LGS_REQUIRE(sizeof(T) == 2 && !out_f32 && !row_scale && !(bn && bn->partial), "wide conv: bf16 feature output only (internal error)");
+    if (bn_rows) *bn_rows = 0;
+    return launch_conv_wide(v, in, cin_real, in_ld > 0 ? in_ld : cin_real, wp, nb_total, ncp, nbp, K, out, cout_real, bias,
+                            gc >= nc ? 0 : (gc + 1) / 2, s);
+  }
   switch (cfg.id) {
     case 0: LGS_LAUNCH(2, 1, 4, 1, (kF32 ? 2 : 4), (kF32 ? 3 : 4)); break;
     case 1: LGS_LAUNCH(2, 2, 4, 1, (kF32 ? 2 : 4), (kF32 ? 3 : 4)); break;
@@ -780,6 +789,7 @@ int bn_partial_rows_t(const View &v, int K, int o_real) {
   if (v.n_pad == 0 || o_real % 4 != 0) return 0;
   const int nb_total = pad32(o_real) / 32;
   const GatherCfg cfg = gather_cfg<T>(v, nb_total);
+  if (cfg.id == 17) return 0;        // the wide kernel has no statistics epilogue
   const int64_t gx = v.n_pad / cfg.tm, gy = (nb_total + cfg.wb - 1) / cfg.wb;
   static const bool no_split = getenv("LGS_NO_SPLIT") != nullptr;
   const bool split = sizeof(T) == 2 && !no_split && v.KS > 1 && K == 27 &&

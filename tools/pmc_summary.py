@@ -6,6 +6,7 @@ for f in sorted(glob.glob(sys.argv[1] + '/*/p_counter_collection.csv')):
         k = r['Kernel_Name']
         if 'k_pack' in k or 'reduce' in k: continue
         if 'k_conv_halo' in k: kk = 'k_conv_halo (L0 3^3 96->96 bf16 forward, per launch)'
+        elif 'k_conv_wide' in k: kk = 'k_conv_wide (2-D blocked wide-channel conv of the driver script, per launch)'
         elif 'k_conv_gather' in k: kk = 'k_conv_gather (dominant conv launch of the driver script, per launch)'
         elif 'k_wgrad_bf16' in k: kk = 'k_wgrad_bf16<3,3> (L0 3^3 96->96, per launch)'
         elif 'k_wgrad_ps' in k: kk = 'k_wgrad_ps<27,3> (L0 3^3 96->96, per launch)'
