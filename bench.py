@@ -661,17 +661,17 @@ def main():
         del model, ddp, opt
         gc.collect()
         torch.cuda.empty_cache()
-        out["fp32"] = secondary_block("ce", "Res16UNet34C", torch.float32, coords, feats, labels, device, args, clog, steps=5, warmup=2,
+        out["fp32"] = secondary_block("ce", "Res16UNet34C", torch.float32, coords, feats, labels, device, args, clog, steps=5, warmup=3,
                                       note="the parity path (fp32 storage, exact-fp32 MFMA): logits within 1e-3 of the oracle")
         log("fp32 block done")
-        out["clip"] = secondary_block("clip", "Res16UNet34D", torch.bfloat16, coords, feats, labels, device, args, clog, steps=5, warmup=2,
+        out["clip"] = secondary_block("clip", "Res16UNet34D", torch.bfloat16, coords, feats, labels, device, args, clog, steps=5, warmup=3,
                                       note="BASELINE configs[2] (scripts/text_representation_train.sh): Res16UNet34D + fused CLIP text-anchor loss")
         log("clip block done")
         out["insseg"] = {
-            "full": secondary_block("insseg", "InsSegRes16UNet34C", torch.bfloat16, coords, feats, labels, device, args, None, steps=5, warmup=2,
+            "full": secondary_block("insseg", "InsSegRes16UNet34C", torch.bfloat16, coords, feats, labels, device, args, None, steps=5, warmup=3,
                                     note="downstream/insseg step as the reference runs it (all parameters trained, pl_Trainer.py:81)"),
             "frozen_trunk": secondary_block("insseg_frozen", "InsSegRes16UNet34C", torch.bfloat16, coords, feats, labels, device, args, None,
-                                            steps=5, warmup=2, note="BASELINE configs[4]: head on frozen pretrained features (eval-mode trunk under "
+                                            steps=5, warmup=3, note="BASELINE configs[4]: head on frozen pretrained features (eval-mode trunk under "
                                                                     "no_grad, only offsets_pre / bntr_offset / offsets / final are trained)")}
         log("insseg block done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

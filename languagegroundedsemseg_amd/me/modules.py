@@ -31,6 +31,11 @@ def _invalidate_packed():
         be.invalidate_packed_weights()
 
 
+def _invalidate_packed_hook(module, incompatible_keys):
+    """load_state_dict post-hook (a module-level function: hooks are pickled with the module)"""
+    _invalidate_packed()
+
+
 class MinkowskiNetwork(nn.Module):
     """models/model.py:4-16 subclasses this and stores D."""
 
@@ -183,7 +188,7 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
         self.bias = nn.Parameter(torch.empty((1, out_channels), dtype=torch.float32)) if bias else None
         self.reset_parameters()
         # load_state_dict() copies into `.data` without bumping the parameter's version counter: drop the packed images
-        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: _invalidate_packed())
+        self.register_load_state_dict_post_hook(_invalidate_packed_hook)
 
     def __getstate__(self):
         # packed weight images are a device-side cache tied to this process: never pickled / deep-copied with the module

@@ -180,8 +180,9 @@ def test_models_stay_picklable_and_leave_the_registry_when_dropped():
     gc.collect()
     before = len(get_packed().entries)
     m = deterministic_init(load_model("Res16UNet14A")(3, 20, Cfg()), 42).to(DEV).train()
-    logits, _ = m(ME.SparseTensor(f, c))
+    logits, feats_out = m(ME.SparseTensor(f, c))
     logits.F.float().sum().backward()
+    del feats_out                                                # (a live output keeps the autograd graph, and with it the images)
     assert len(get_packed().entries) > before
     m2 = copy.deepcopy(m)                                        # used to raise: ctypes objects containing pointers
     blob = pickle.dumps(m)
@@ -272,8 +273,13 @@ def test_insseg_step_at_size_vs_oracle(frozen):
     assert h[4] and o[4], "a frozen trunk must not receive gradients"
     assert np.abs(h[0] - o[0]).max() < 1e-3 and np.abs(h[1] - o[1]).max() < 1e-3 and abs(h[2] - o[2]) < 1e-4
     assert set(h[3]) == set(o[3]) and (len(h[3]) == 8 if frozen else len(h[3]) > 50)
+    gscale = max(float(np.abs(o[3][k]).max()) for k in o[3])
     for k in o[3]:
-        assert rel_l2(h[3][k], o[3][k]) < 2e-2, (k, rel_l2(h[3][k], o[3][k]))
+        if float(np.abs(o[3][k]).max()) < 1e-4 * gscale:
+            # e.g. the bias in front of a BatchNorm: its true gradient is zero (the norm removes the mean), both sides hold noise
+            assert float(np.abs(h[3][k] - o[3][k]).max()) < 1e-4 * gscale, k
+        else:
+            assert rel_l2(h[3][k], o[3][k]) < 2e-2, (k, rel_l2(h[3][k], o[3][k]))
     # bf16 storage of the same step: reported against the fp32 oracle
     b = _insseg_step(DEV, torch.bfloat16, coords, feats, labels, inst, centers, frozen)
     print("insseg bf16: offsets rel-L2 %.2e, logits rel-L2 %.2e, loss %.5f" % (rel_l2(b[0], o[0]), rel_l2(b[1], o[1]), b[2]))

@@ -279,6 +279,22 @@ def wide():
         flop = 2.0 * M * cin * cout
         print("L%d 3^3 %3d->%3d rows %7d pairs %8d  fwd %.3f ms (%.0f TF = %.1f %% of 2.5 PF)  dgrad %.3f ms (%.0f TF)  wgrad %.3f ms (%.0f TF)" % (
             lvl, cin, cout, n, M, tf, flop / tf / 1e9, flop / tf / 1e9 / 25, td, flop / td / 1e9, tw, flop / tw / 1e9))
+    # the other wide launches of Res16UNet34D at level 0: 1x1 downsample 544 -> 512, transposed 2^3 256 -> 512 (level 1 -> 0)
+    n0 = m.size(keys[0])
+    km1 = m.kernel_map_handle(keys[0], keys[0], 1)
+    f = torch.randn(n0, 544, device=DEV).bfloat16()
+    g = torch.randn(n0, 512, device=DEV).bfloat16()
+    w = torch.randn(1, 544, 512, device=DEV) * 0.02
+    tf = timeit(lambda: km1.conv_forward(f, w, None, False), 3, 1)
+    td = timeit(lambda: km1.conv_dgrad(g, w, False), 3, 1)
+    print("L0 1x1 544->512 rows %7d  fwd %.3f ms (%.0f TF)  dgrad %.3f ms (%.0f TF)" % (n0, tf, 2.0 * n0 * 544 * 512 / tf / 1e9, td, 2.0 * n0 * 544 * 512 / td / 1e9))
+    km2 = m.kernel_map_handle(keys[0], keys[1], 2)
+    n1 = m.size(keys[1])
+    f = torch.randn(n1, 256, device=DEV).bfloat16()
+    w = torch.randn(8, 256, 512, device=DEV) * 0.02
+    tf = timeit(lambda: km2.conv_forward(f, w, None, True), 3, 1)
+    td = timeit(lambda: km2.conv_dgrad(g, w, True), 3, 1)
+    print("L1->L0 transposed 2^3 256->512 rows %7d  fwd %.3f ms (%.0f TF)  dgrad %.3f ms (%.0f TF)" % (n0, tf, 2.0 * n0 * 256 * 512 / tf / 1e9, td, 2.0 * n0 * 256 * 512 / td / 1e9))
 
 
 if __name__ == "__main__":
