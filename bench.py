@@ -584,6 +584,11 @@ def main():
     ctx = make_ctx(args.workload, args.model, coords, device)
     model, ddp, opt = make_trainer(args.model, dtype, device, world, args, ctx)
 
+    if os.environ.get("LGS_COMPUTE_CUMASK"):      # experiment knob: confine the compute stream to a CU partition
+        from languagegroundedsemseg_amd.me.backend_hip import masked_stream
+        cs = masked_stream(device, [int(w, 16) for w in os.environ["LGS_COMPUTE_CUMASK"].split(",")])
+        cs.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(cs)
     if args.compute_priority != 0:
         hp = torch.cuda.Stream(device=device, priority=args.compute_priority)
         hp.wait_stream(torch.cuda.current_stream())

@@ -342,6 +342,23 @@ class HipManager:
         return km
 
 
+_HIPRT = None
+
+
+def masked_stream(device, words):
+    """torch stream object around a HIP stream created with a CU mask (list of 32-bit words, bit i = CU i enabled)"""
+    global _HIPRT
+    if _HIPRT is None:
+        _HIPRT = ctypes.CDLL("libamdhip64.so")
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    st = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = _HIPRT.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(len(words)), arr)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
+    return torch.cuda.ExternalStream(st.value, device=device)
+
+
 class HipBackend:
     name = "hip"
     bn_counts_batches = True    # lgs_bn_forward increments num_batches_tracked itself
@@ -365,10 +382,17 @@ class HipBackend:
         get_packed().repack_all()
 
     def side_stream(self, device):
-        """second HIP stream per device: weight gradients run here, concurrently with the dgrad / BN chain"""
+        """second HIP stream per device: weight gradients run here, concurrently with the dgrad / BN chain.
+        LGS_WGRAD_CUMASK=<hex words, comma separated, least significant first> (experiment knob): create it with a CU mask
+        (hipExtStreamCreateWithCUMask), so that the position-stationary weight-gradient kernel -- which owns whole CUs --
+        is confined to a partition instead of evicting the compute stream's waves everywhere."""
         key = torch.device(device).index
         if key not in self._side:
-            self._side[key] = torch.cuda.Stream(device=device)
+            mask = os.environ.get("LGS_WGRAD_CUMASK")
+            if mask:
+                self._side[key] = masked_stream(device, [int(w, 16) for w in mask.split(",")])
+            else:
+                self._side[key] = torch.cuda.Stream(device=device)
         return self._side[key]
 
     # ---- fused BN(+residual)(+ReLU): lgs_bn_forward / lgs_bn_backward

@@ -9,6 +9,7 @@ thread), and the shape becomes part of the group key -- roofline.frac of the dom
 table alone (algorithmic bytes of the shape / avg_us).
     python tools/prof_summary.py gpurun_out/prof/x_results.db <profiled steps = warmup + timed> > profiles/rNN_kernel_stats.txt"""
 import bisect
+import json
 import re
 import sqlite3
 import sys
@@ -28,8 +29,16 @@ def main():
     # ---- ROCTx shape ranges (optional): per thread, sorted by start
     marks = {}
     try:
-        for name, tid, st, en in cur.execute("select name, tid, start, end from regions where category like '%MARKER%' and name like 'lgs %'"):
-            marks.setdefault(tid, []).append((st, en, name[4:]))
+        # a ROCTx range is a region of category MARKER_CORE_RANGE_API whose message sits in `extdata` ({"message": "lgs ..."})
+        for name, tid, st, en, ext in cur.execute("select name, tid, start, end, extdata from regions where category like '%MARKER%'"):
+            msg = name
+            if ext and "message" in ext:
+                try:
+                    msg = json.loads(ext).get("message", name)
+                except ValueError:
+                    pass
+            if msg.startswith("lgs "):
+                marks.setdefault(tid, []).append((st, en, msg[4:]))
     except sqlite3.Error:
         marks = {}
     for tid in marks:
