@@ -182,7 +182,12 @@ template <> __device__ inline float sq16<float>(const u32x4 &f, float s) {
 
 // ------------------------------------------------------------------------------------ forward / dgrad
 // Tile: WM x WN waves; each wave owns RB*32 positions x NCB*32 output channels.
-template <typename T, int RB, int NCB, int WM, int WN, int SC, int D, int EPI = 0>
+// PW = true (RB = 1, 3^3 maps): PER-WAVE OFFSET MASKS.  Every wave walks only the offsets at which ITS 32 rows have a neighbour
+// (ballot over the parked gather rows) -- in the tile-wide schedule 45 % of all gather instructions of the level-0 96 -> 96
+// launch were 32-row blocks without a single neighbour, issued as out-of-range loads to keep the schedule static, and the
+// kernel sits on the vector-memory instruction rate.  The weights stay tile-wide: slabs are staged for the offsets of the
+// TILE in the same order by everybody, a wave that has nothing at an offset just takes part in staging and barriers.
+template <typename T, int RB, int NCB, int WM, int WN, int SC, int D, int EPI = 0, bool PW = false>
 __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__restrict__ in, int cin_real, int nc,
                                                              const u32x4 *__restrict__ wp, int nb_total,
                                                              int ncp, int nbp,
@@ -193,6 +198,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
                                                              unsigned in_bytes, unsigned w_bytes, int64_t zstride,
                                                              ClipEpi ce, BnEpi be, int gc, int in_ld) {
   static_assert(EPI == 0 || (RB == 1 && WN == 1), "the CLIP epilogue owns whole rows: one row block, all columns per wave");
+  static_assert(!PW || (RB == 1 && EPI == 0), "per-wave offset masks: one 32-row block per wave");
   // SC = 32-channel chunks per weight SLAB: the weights of (offset, slab) are staged in LDS once per workgroup
   // and one barrier separates slabs, while the gathered feature fragments stream chunk by chunk through a
   // D-deep register ring (loads issued D-1 chunks = several hundred MFMA cycles ahead of their use) that runs
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   // Eight-wave tiles (one 32-row block per wave) INTERLEAVE the tile's rows over the waves (row i -> wave i % 8): the
   // rows are sorted by neighbourhood shape, so contiguous blocks would leave whole waves without work at an offset while
   // the others run their MFMAs, and everybody meets at the next slab barrier.
-  constexpr bool ILV = (WM == 8 && RB == 1 && EPI == 0);
+  constexpr bool ILV = (WM == 8 && RB == 1 && EPI == 0 && !PW);   // (per-wave masks want rows of one neighbourhood shape in one wave)
   auto row_of = [&](int rb) __attribute__((always_inline)) { return ILV ? vx * WM + wm : wm * RB * 32 + rb * 32 + vx; };
   const int nb_wg = blockIdx.y * WB;  // first cout block of the workgroup
   const int nb_w = nb_wg + wn * NCB;  // first cout block of this wave
@@ -273,6 +279,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   // touches every gathered row in sixteen 64-byte pieces per offset and comes back to it ~14 offsets later: the rows of
   // the co-resident tiles plus 14 MB of weights do not fit the XCD's 4 MB L2 (PMC: L2 hit 51 %, 19x the compulsory HBM
   // bytes); with 128-channel groups a row's 256-byte segment serves all offsets back to back.
+  uint32_t fmask = smask;        // offsets the FEATURE side of this wave walks (PW: set below, once the gather rows are parked)
   uint32_t rem = smask;
   int islot = -1, gbase = 0, gend = min(gc, nc), ichunk = gend;  // forces "advance to first slot" on the first call
   int32_t idx_i[RB];
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
       gbase = gend;
       if (gbase >= nc) return false;
       gend = min(gbase + gc, nc);
-      rem = smask;
+      rem = fmask;
     }
     islot = __builtin_ctz(rem);
     rem &= rem - 1;
@@ -392,8 +399,9 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   int buf = 0, cc = 0;       // LDS buffer holding the current slab, chunk index inside it
   int ncs = 0;               // chunks in the current slab
   bool wnext = false;        // is a following slab prefetched in wreg?
-  const int total = __builtin_popcount(smask) * nc;  // chunks of this workgroup
   int issued = 0, computed = 0;
+  int rslot = -1, rslab = -1;   // PW: offset / slab index of the RESIDENT weight slab, and of the prefetched one
+  int pslot = -1, pslab = -1;
   // Prologue: the first weight slab and ALL index loads of the tile are in flight together, one barrier publishes
   // both (a slot-by-slot index copy loop was a chain of ~16 dependent global-load latencies at the head of every
   // workgroup -- a quarter of its lifetime -- and the first weight fetch only started behind it).
@@ -426,10 +434,25 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   if (whave) {
     wstage(0, wreg);
     ncs = min(SC, nc - wslab * SC);
+    rslot = wslot; rslab = wslab;
     wnext = wadvance();
-    if (wnext) wissue(wreg);
+    if (wnext) { pslot = wslot; pslab = wslab; wissue(wreg); }
   }
   __syncthreads();   // indices and the first weight slab are visible
+  if constexpr (PW) {
+    // offsets at which this wave's 32 rows have any neighbour
+    uint32_t wm_ = 0;
+#pragma unroll
+    for (int sl = 0; sl < 27; ++sl) {
+      if ((smask >> sl) & 1u) {
+        const bool ok = l_idx[sl * TM + row_of(0)] >= 0;
+        if (__ballot(ok) != 0ull) wm_ |= 1u << sl;
+      }
+    }
+    fmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)wm_);
+    rem = fmask;
+  }
+  const int total = __builtin_popcount(fmask) * nc;  // chunks of this wave
 #pragma unroll
   for (int d = 0; d < D - 1; ++d) {
     act[d] = 0;
@@ -443,11 +466,61 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     buf ^= 1;
     cc = 0;
     if (wnext) {
-      ncs = min(SC, nc - wslab * SC);
+      ncs = min(SC, nc - pslab * SC);
+      rslot = pslot; rslab = pslab;
       wnext = wadvance();
-      if (wnext) wissue(wreg);
+      if (wnext) { pslot = wslot; pslab = wslab; wissue(wreg); }
+    } else {
+      rslot = -1;
     }
   };
+  if constexpr (PW) {
+    // compute-side iterator of this wave (same sequence as advance(), D - 1 items behind it)
+    uint32_t crem = fmask;
+    int cslot = -1, cgbase = 0, cgend = min(gc, nc), cchunk = cgend;
+    auto cadvance = [&]() __attribute__((always_inline)) {
+      if (++cchunk < cgend) return;
+      if (crem == 0) {
+        cgbase = cgend;
+        if (cgbase >= nc) { cslot = -1; return; }
+        cgend = min(cgbase + gc, nc);
+        crem = fmask;
+      }
+      cslot = __builtin_ctz(crem);
+      crem &= crem - 1;
+      cchunk = cgbase;
+    };
+    if (total > 0) cadvance();
+    // walk the TILE's slabs until the one this wave's next item needs is resident (everybody crosses the same barriers)
+    auto seek = [&]() __attribute__((always_inline)) {
+      while (!(rslot == cslot && (cchunk / SC) == rslab)) slab_end();
+    };
+    while (total - issued >= D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        seek();
+        advance();
+        issue(F[(d + D - 1) % D], act[(d + D - 1) % D]);
+        compute(buf, cchunk - rslab * SC, F[d], act[d]);
+        cadvance();
+      }
+      issued += D;
+      computed += D;
+    }
+    while (computed < total) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if (computed < total) {
+          seek();
+          if (issued < total) { advance(); issue(F[(d + D - 1) % D], act[(d + D - 1) % D]); ++issued; }
+          compute(buf, cchunk - rslab * SC, F[d], act[d]);
+          cadvance();
+          ++computed;
+        }
+      }
+    }
+    while (rslot >= 0) slab_end();     // the tile's remaining slabs: staging duty and barriers only
+  } else {
   // steady state: every sub-step issues one chunk and computes one chunk UNCONDITIONALLY, so the compiler can
   // count outstanding loads (s_waitcnt vmcnt(N), N > 0) instead of draining the queue before every MFMA group
   while (total - issued >= D) {
@@ -472,6 +545,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
         if (++cc == ncs) slab_end();
       }
     }
+  }
   }
 
   if constexpr (EPI == 1) {
@@ -665,6 +739,11 @@ GatherCfg gather_cfg(const View &v, int nb_total) {
     if (nb_total >= 5 && nb_total <= 7 && v.nbr == nullptr) return {6, kF32 ? 1 : 2, 7, 128};
     if (nb_total == 1) return {0, kF32 ? 2 : 4, 1, 256};
     if (nb_total == 2) return {1, kF32 ? 2 : 4, 2, 256};
+    // id 20 (round 3, bf16 3^3 maps, LGS_PW=1): eight waves of 32 positions x 96 channels with PER-WAVE offset masks (no gather
+    // instructions for 32-row blocks without a neighbour).  Parity-green, measured SLOWER than the tile-wide schedule of id 2
+    // (L0 96 -> 96 forward 0.825 vs 0.645 ms stand-alone, step 31.7 vs 29.8 ms), so off by default
+    static const int pw_cfg = getenv("LGS_PW") ? atoi(getenv("LGS_PW")) : 0;   // experiment knob
+    if (!kF32 && pw_cfg && nb_total == 3 && v.KS > 1 && v.nbr != nullptr) return {20, 4, 3, 256};
     if (nb_total == 3 || (nb_total % 3 == 0 && nb_total % 4 != 0)) return {2, kF32 ? 2 : 4, 3, 256};
     // wide outputs (>= 256 channels, e.g. the 512-d CLIP representation model): 256 positions x 256 channels per
     // 8-wave workgroup -- every staged weight fragment serves two row blocks and the rows are gathered half as often
@@ -766,6 +845,15 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
     case 6: LGS_LAUNCH(1, 7, 4, 1, (kF32 ? 1 : 2), (kF32 ? 3 : 4)); break;
     case 7: LGS_LAUNCH(1, 4, 4, 1, 2, 4); break;
     case 15: LGS_LAUNCH(2, 4, 4, 2, 2, 3); break;
+    case 20:
+      if constexpr (!kF32) {
+        dim3 grid((unsigned)(v.n_pad / 256), (unsigned)((nb_total + 2) / 3));
+        hipLaunchKernelGGL((k_conv_gather<T, 1, 3, 8, 1, 4, 6, 0, true>), grid, dim3(512), 0, s, v, in, cin_real, nc,
+                           reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, out, cout_real, bias, out_f32, row_scale, in_bytes,
+                           w_bytes, zstride, ClipEpi(), bn ? *bn : BnEpi(), gc, in_ld > 0 ? in_ld : cin_real);
+        if (bn_rows) *bn_rows = (int)grid.x;
+      }
+      break;
     case 16: LGS_LAUNCH(1, 8, 8, 1, 2, 4); break;
     case 8: LGS_LAUNCH(1, 2, 4, 1, 4, 6); break;
     case 9: LGS_LAUNCH(1, 2, 2, 2, 4, 6); break;
