@@ -16,7 +16,27 @@ _vp = ctypes.c_void_p
 
 
 def _stream():
-    return _vp(torch.cuda.current_stream().cuda_stream)
+    """raw handle of torch's current HIP stream on the current device (one C call: torch.cuda.current_stream() builds a
+    Stream object and resolves the device twice, ~14 us of host time per engine call)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOGUARD = _NoGuard()
+
+
+def _dev(device):
+    """device guard that only switches when the tensor's device is not the current one (the usual case: one process per GPU)"""
+    if device.index is None or device.index == torch._C._cuda_getDevice():
+        return _NOGUARD
+    return torch.cuda.device(device)
 
 
 def _ptr(t):
@@ -57,8 +77,20 @@ def _row_strided(t, c):
     return None
 
 
+_WS = {}
+
+
 def _ws(nbytes, device):
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    """Scratch of one engine call: ONE grow-only buffer per (device, current stream).  Every use is confined to the launches
+    of a single call, and calls on one stream run in order, so the next call may overwrite it; weight gradients on the side
+    stream get their own.  (A fresh torch.empty per call cost ~7 us of allocator time, ~250 times per step.)"""
+    key = (device.index, torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch._C._cuda_getDevice()))
+    t = _WS.get(key)
+    nbytes = int(nbytes)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes + nbytes // 4, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = t
+    return t
 
 
 _DESC_FIELDS = [f for f, _ in engine.PackDesc._fields_]
@@ -151,7 +183,7 @@ class PackedWeights:
             self._table = (host.to(live[0][0].buf.device), ids, max(int(e.desc["total"]) for e, _ in live))
             self._dirty = False
         tab, _, max_total = self._table
-        with torch.cuda.device(tab.device):
+        with _dev(tab.device):
             engine.check(engine.lib().lgs_pack_weights_batch(_ptr(tab), len(live), max_total, _stream()))
         for e, p in live:
             e.valid = (self.epoch, p._version, p.data_ptr())
@@ -171,7 +203,7 @@ class HipKernelMap:
     def export(self):
         L = engine.lib()
         m = ctypes.c_int64(0)
-        with torch.cuda.device(self.mgr.device):
+        with _dev(self.mgr.device):
             engine.check(L.lgs_kmap_export(self.h, None, None, None, _stream(), ctypes.byref(m)))
             n = m.value
             k = torch.empty(n, dtype=torch.int32, device=self.mgr.device)
@@ -201,7 +233,7 @@ class HipKernelMap:
         assert x.shape[0] == n_in and x.shape[1] == cin, (x.shape, n_in, cin)
         dt = _dtype_code(x)
         part = None
-        with torch.cuda.device(x.device):
+        with _dev(x.device):
             out = torch.empty((n_out, cout), dtype=x.dtype, device=x.device)
             ws = _ws(L.lgs_conv_workspace_bytes(self.h, cin, cout, dt, 0), x.device)
             b = bias.detach().reshape(-1).contiguous().float() if bias is not None else None
@@ -225,7 +257,7 @@ class HipKernelMap:
         n_in, n_out = self._rows(transposed)
         assert gout.shape[0] == n_out and gout.shape[1] == cout
         dt = _dtype_code(gout)
-        with torch.cuda.device(gout.device):
+        with _dev(gout.device):
             gin = torch.empty((n_in, cin), dtype=gout.dtype, device=gout.device)
             ws = _ws(L.lgs_conv_workspace_bytes(self.h, cin, cout, dt, 1), gout.device)
             pk, mode = get_packed().lookup(pack_cache, self, 1, transposed, weight, w, cin, cout, dt)
@@ -246,7 +278,7 @@ class HipKernelMap:
         if ld is None:
             x = x.contiguous()
         assert gout.dtype == x.dtype
-        with torch.cuda.device(x.device):
+        with _dev(x.device):
             if out is not None:
                 assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == self.K * cin * cout
                 gw = out
@@ -294,7 +326,7 @@ class HipManager:
         coords = coords.to(torch.int32).contiguous()
         n = coords.shape[0]
         key, nu = ctypes.c_int(0), ctypes.c_int64(0)
-        with torch.cuda.device(self.device):
+        with _dev(self.device):
             ui = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
             inv = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
             engine.check(L.lgs_manager_insert(self.h, _ptr(coords), n, _ptr(ui), _ptr(inv), _stream(), ctypes.byref(key),
@@ -305,7 +337,7 @@ class HipManager:
     def stride2(self, key):
         L = engine.lib()
         ok, n = ctypes.c_int(0), ctypes.c_int64(0)
-        with torch.cuda.device(self.device):
+        with _dev(self.device):
             engine.check(L.lgs_manager_stride2(self.h, key, _stream(), ctypes.byref(ok), ctypes.byref(n)))
         self._sizes[ok.value] = (n.value, self._sizes[key][1] * 2)
         return ok.value
@@ -324,7 +356,7 @@ class HipManager:
     def coords(self, key):
         if key not in self._coords:
             n = self.map_size(key)
-            with torch.cuda.device(self.device):
+            with _dev(self.device):
                 c = torch.empty((n, 4), dtype=torch.int32, device=self.device)
                 engine.check(engine.lib().lgs_manager_get_coords(self.h, key, _ptr(c), _stream()))
             self._coords[key] = c
@@ -335,7 +367,7 @@ class HipManager:
         km = self._kmaps.get(k)
         if km is None:
             h = _vp(None)     # the engine caches the map itself: a second request returns the same handle at no cost
-            with torch.cuda.device(self.device):
+            with _dev(self.device):
                 engine.check(engine.lib().lgs_manager_kernel_map(self.h, in_key, out_key, ks, _stream(), ctypes.byref(h)))
             km = HipKernelMap(self, h, in_key, out_key, ks)
             self._kmaps[k] = km
@@ -352,7 +384,7 @@ def masked_stream(device, words):
         _HIPRT = ctypes.CDLL("libamdhip64.so")
     arr = (ctypes.c_uint32 * len(words))(*words)
     st = ctypes.c_void_p()
-    with torch.cuda.device(device):
+    with _dev(device):
         rc = _HIPRT.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(len(words)), arr)
     if rc != 0:
         raise RuntimeError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
@@ -408,7 +440,7 @@ class HipBackend:
         dt = _dtype_code(x)
         part, piv = conv_stats if conv_stats is not None else (None, None)
         y_ld = 0
-        with torch.cuda.device(x.device):
+        with _dev(x.device):
             if out_into is not None:
                 buf, off = out_into
                 y = buf[:, off:off + c]
@@ -443,7 +475,7 @@ class HipBackend:
             y_ld = _row_strided(y, c) or 0
             if y_ld == 0:
                 y = y.contiguous()
-        with torch.cuda.device(x.device):
+        with _dev(x.device):
             dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
             dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_residual else None
             dgamma = dgamma_out if dgamma_out is not None else torch.empty(c, dtype=torch.float32, device=x.device)
@@ -460,7 +492,7 @@ class HipBackend:
         x = x.contiguous()
         n, c = x.shape
         part, piv = conv_stats if conv_stats is not None else (None, None)
-        with torch.cuda.device(x.device):
+        with _dev(x.device):
             out = torch.empty(2 * c + 1, dtype=torch.float32, device=x.device)
             ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
             engine.check(L.lgs_bn_stats(_ptr(x), n, c, _ptr(out), _dtype_code(x), _ptr(ws), _ptr(part),
@@ -471,7 +503,7 @@ class HipBackend:
         """all_stats [world, 2C+1] -> (stats [2C] = global mean | invstd, inv_n [1] = 1 / global rows); one kernel"""
         L = engine.lib()
         world = all_stats.shape[0]
-        with torch.cuda.device(all_stats.device):
+        with _dev(all_stats.device):
             stats = torch.empty(2 * c, dtype=torch.float32, device=all_stats.device)
             inv_n = torch.empty(1, dtype=torch.float32, device=all_stats.device)
             engine.check(L.lgs_bn_sync_combine(_ptr(all_stats), int(world), int(c), float(eps), float(momentum), _ptr(running_mean),
@@ -482,7 +514,7 @@ class HipBackend:
         L = engine.lib()
         x = x.contiguous()
         n, c = x.shape
-        with torch.cuda.device(x.device):
+        with _dev(x.device):
             y = torch.empty_like(x)
             res = residual.contiguous() if residual is not None else None
             engine.check(L.lgs_bn_apply(_ptr(x), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(res), int(relu), _ptr(y),
@@ -493,7 +525,7 @@ class HipBackend:
         """-> sums [2C] (local sum dy', sum dy' xhat); the same vectors are also written to dgamma_out / dbeta_out"""
         L = engine.lib()
         n, c = x.shape
-        with torch.cuda.device(x.device):
+        with _dev(x.device):
             sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
             ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
             engine.check(L.lgs_bn_backward_reduce(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), int(relu), _ptr(sums),
@@ -505,7 +537,7 @@ class HipBackend:
         L = engine.lib()
         n, c = x.shape
         dev_inv = inv_n_total if torch.is_tensor(inv_n_total) else None
-        with torch.cuda.device(x.device):
+        with _dev(x.device):
             dx = torch.empty_like(x)
             dres = torch.empty_like(x) if want_residual else None
             engine.check(L.lgs_bn_backward_apply(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(sums),
@@ -522,7 +554,7 @@ class HipBackend:
         n, c = feats.shape
         na = anchors.shape[0]
         dt = _dtype_code(feats)
-        with torch.cuda.device(feats.device):
+        with _dev(feats.device):
             sim = torch.empty((n, na), dtype=torch.float32, device=feats.device)
             inv = torch.empty(max(n, 1), dtype=torch.float32, device=feats.device)
             ws = _ws(L.lgs_clip_workspace_bytes(c, na, dt), feats.device)
@@ -545,7 +577,7 @@ class HipBackend:
         na, k = anchors.shape[0], neg.shape[1]
         dt = _dtype_code(feats)
         dev = feats.device
-        with torch.cuda.device(dev):
+        with _dev(dev):
             d_pos = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
             d_neg = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
             inv = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
@@ -562,7 +594,7 @@ class HipBackend:
         L = engine.lib()
         feats, tn, labels, neg, inv = saved
         n, c = feats.shape
-        with torch.cuda.device(feats.device):
+        with _dev(feats.device):
             gf = torch.empty_like(feats)
             gp = g_dpos.contiguous().float() if g_dpos is not None else None
             gn = g_dneg.contiguous().float() if g_dneg is not None else None
@@ -581,7 +613,7 @@ class HipBackend:
         labels = labels.contiguous().to(torch.int64)
         n, c = logits.shape
         dt = _dtype_code(logits)
-        with torch.cuda.device(logits.device):
+        with _dev(logits.device):
             # the same predicate the kernel uses: a label outside [0, C) is an ignored row, not a counted one
             valid = ((labels != ignore_index) & (labels >= 0) & (labels < c)).sum().to(torch.float32).clamp_min(1.0)
             scale = valid.reciprocal()
