@@ -76,6 +76,10 @@ int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype);
 // lgs_conv_wide.hip: 2-D blocked forward / dgrad for >= 256 output channels (bf16); same packed weight image as k_conv_gather's wide tile
 int launch_conv_wide(const View &v, const void *in, int cin_real, int in_ld, const void *wp, int nb_total, int ncp, int nbp, int K,
                      void *out, int cout_real, const float *bias, int gc64, hipStream_t s);
+// lgs_wgrad_wide.hip: per-offset dense GEMM over compacted pair lists for >= 256 x 256 channel 3^3 weight gradients (bf16)
+int64_t wgrad_wide_workspace_bytes(const View &v, int cin, int cout);
+int conv_wgrad_wide(const View &v, const void *in, int cin, int in_ld, const void *gout, int cout, float *gw, void *workspace,
+                    hipStream_t s, bool *done);
 // order `stream` after the construction of km's manager's maps (they are built on the manager's own stream)
 int kmap_wait(lgs_kmap *km, hipStream_t stream);
 

@@ -950,6 +950,8 @@ int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype) 
     PsPlan f = ps_plan(km->fwd, cin, cout), t = ps_plan(km->fwd, cout, cin);
     const int64_t pb = (f.ok ? f.partial_bytes : 0) > (t.ok ? t.partial_bytes : 0) ? (f.ok ? f.partial_bytes : 0) : (t.ok ? t.partial_bytes : 0);
     if (align256(pb) + 256 > bytes) bytes = align256(pb) + 256;
+    const int64_t wb = wgrad_wide_workspace_bytes(km->fwd, cin, cout);
+    if (wb > bytes) bytes = wb;
   }
   if (dtype == LGS_BF16 && cin % 8 != 0) {
     int64_t nmax = km->fwd.n_in > km->bwd.n_in ? km->fwd.n_in : km->bwd.n_in;
@@ -1136,6 +1138,11 @@ int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const 
   LGS_REQUIRE(dtype == LGS_BF16 || in_row_stride == 0 || in_row_stride == cin, "lgs_conv_wgrad: strided input needs bf16");
   if (dtype == LGS_F32) return conv_wgrad_f32path<float>(vv, in, cin, grad_out, cout, grad_weight, workspace, s);
   if (dtype == LGS_BF16) {
+    if (km->fwd.n_pad > 0 && km->ks == 3 && !transposed) {
+      bool done = false;
+      int rc = conv_wgrad_wide(km->fwd, in, cin, in_row_stride, grad_out, cout, grad_weight, workspace, s, &done);
+      if (rc || done) return rc;
+    }
     if (km->fwd.n_pad > 0 && (km->ks == 3 || km->ks == 2)) {
       bool done = false;
       int rc = conv_wgrad_ps(km->fwd, transposed, reinterpret_cast<const bf16_t *>(in), cin, reinterpret_cast<const bf16_t *>(grad_out),
