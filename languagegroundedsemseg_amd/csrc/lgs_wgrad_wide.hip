@@ -15,7 +15,7 @@
 //   1. compaction (three small kernels per call, ~0.15 ms at 1.2 M voxels): per (offset, 256-position tile) counts ->
 //      exclusive scan per offset -> (in row, out row) lists in position order (deterministic: the fp32 summation order of the
 //      result never depends on timing);
-//   2. k_wgrad_wide: workgroup = (offset k, range of 32768 pairs, 256 x 256 tile of gw[k]), 8 waves as 2 (ci) x 4 (co), a wave
+//   2. k_wgrad_wide: workgroup = (offset k, range of 16384 POSITIONS, 256 x 256 tile of gw[k]), 8 waves as 2 (ci) x 4 (co), a wave
 //      owns 128 x 64 = 4 x 2 MFMA tiles (32x32x16 bf16) in FIXED accumulation registers a[0:127].  A stage = 64 pairs: the two
 //      gathered operand tiles ([64 rows][512 B], 32 KB each) come in by LDS-DMA (waves 0..3: `in` rows, waves 4..7: `gout`
 //      rows, complementary schedules on each SIMD as in k_conv_wide), double-buffered, one barrier per stage; both MFMA
@@ -24,8 +24,11 @@
 //      inline-asm operands); 64-byte channel segments of a row are XOR-swizzled with (row & 3) on the DMA source so that
 //      the four rows a transpose-read touches sit in different bank groups;
 //   3. k_wgrad_wide_reduce: the per-range partial tiles (fp32) are added in range order.
-// Pair counts stay on the device (no host sync): the grid covers the upper bound N pairs per offset, workgroups beyond an
-// offset's count exit at once, the reduction reads the same counts.
+// Ranges are ranges of output POSITIONS, the same for all 27 offsets (a range's pairs of offset k are the list entries between
+// the scanned tile offsets of its first and last 256-position tile): the 27 workgroups of a range then read the same gout rows
+// and neighbouring in rows, so co-resident workgroups share them in L2 / Infinity Cache (pair-index ranges, round 3's first
+// version, drift apart across offsets: 8.30 -> 7.51 ms at 1.2 M voxels 512 x 512).  Pair counts stay on the device (no host
+// sync): the grid is (ranges x 27 x tiles), a range without pairs writes a zero tile, the reduction adds all of them.
 #include "lgs_common.h"
 
 #include <stdlib.h>
@@ -200,9 +203,10 @@ struct WwArgs {
   const bf16_t *in, *gout;          // [rows][in_ld], [rows][cout]
   const int32_t *pin, *pout;        // [27][stride] compacted pairs
   const int32_t *total;             // [27]
+  const int32_t *off;               // [27][ntile] first pair of every compaction tile
   float *partial;                   // [27 * nchunk][ci_pad][co_pad]
   int64_t stride;
-  int cin, cout, in_ld, nchunk, chunk, ci_pad, co_pad, ti, tj;
+  int cin, cout, in_ld, nchunk, chunk, ntile, ci_pad, co_pad, ti, tj;
   unsigned in_bytes, go_bytes;
 };
 
@@ -230,10 +234,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_wide(WwArgs a) {
   const int tile = (int)(lid % (unsigned)T), k = (int)((lid / (unsigned)T) % 27u), chunk = (int)(lid / (unsigned)(27 * T));
   const int ti = tile / a.tj, tj = tile % a.tj;
   const int slot = k * a.nchunk + chunk;
-  const int Mk = a.total[k];
-  const int start = chunk * a.chunk;
-  if (start >= Mk) return;
-  const int end = min(start + a.chunk, Mk);
+  // the workgroup's pairs: those of offset k whose OUTPUT position lies in position range `chunk` (a.chunk positions, a whole
+  // number of compaction tiles) -- the 27 offsets of one range gather the same neighbourhood of rows, so the ranges of the
+  // workgroups in flight (a few position ranges x 27 offsets x T tiles) fit the Infinity Cache
+  const int tpr = a.chunk / kWwTile, t0 = chunk * tpr, t1 = t0 + tpr;
+  const int start = a.off[k * a.ntile + t0];
+  const int end = t1 < a.ntile ? a.off[k * a.ntile + t1] : a.total[k];
   const int nstage = (end - start + kWwStage - 1) / kWwStage;
 
   asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0\n\tv_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0\n\tv_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0\n\tv_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0\n\tv_accvgpr_write_b32 a64, 0\n\tv_accvgpr_write_b32 a65, 0\n\tv_accvgpr_write_b32 a66, 0\n\tv_accvgpr_write_b32 a67, 0\n\tv_accvgpr_write_b32 a68, 0\n\tv_accvgpr_write_b32 a69, 0\n\tv_accvgpr_write_b32 a70, 0\n\tv_accvgpr_write_b32 a71, 0\n\tv_accvgpr_write_b32 a72, 0\n\tv_accvgpr_write_b32 a73, 0\n\tv_accvgpr_write_b32 a74, 0\n\tv_accvgpr_write_b32 a75, 0\n\tv_accvgpr_write_b32 a76, 0\n\tv_accvgpr_write_b32 a77, 0\n\tv_accvgpr_write_b32 a78, 0\n\tv_accvgpr_write_b32 a79, 0\n\tv_accvgpr_write_b32 a80, 0\n\tv_accvgpr_write_b32 a81, 0\n\tv_accvgpr_write_b32 a82, 0\n\tv_accvgpr_write_b32 a83, 0\n\tv_accvgpr_write_b32 a84, 0\n\tv_accvgpr_write_b32 a85, 0\n\tv_accvgpr_write_b32 a86, 0\n\tv_accvgpr_write_b32 a87, 0\n\tv_accvgpr_write_b32 a88, 0\n\tv_accvgpr_write_b32 a89, 0\n\tv_accvgpr_write_b32 a90, 0\n\tv_accvgpr_write_b32 a91, 0\n\tv_accvgpr_write_b32 a92, 0\n\tv_accvgpr_write_b32 a93, 0\n\tv_accvgpr_write_b32 a94, 0\n\tv_accvgpr_write_b32 a95, 0\n\tv_accvgpr_write_b32 a96, 0\n\tv_accvgpr_write_b32 a97, 0\n\tv_accvgpr_write_b32 a98, 0\n\tv_accvgpr_write_b32 a99, 0\n\tv_accvgpr_write_b32 a100, 0\n\tv_accvgpr_write_b32 a101, 0\n\tv_accvgpr_write_b32 a102, 0\n\tv_accvgpr_write_b32 a103, 0\n\tv_accvgpr_write_b32 a104, 0\n\tv_accvgpr_write_b32 a105, 0\n\tv_accvgpr_write_b32 a106, 0\n\tv_accvgpr_write_b32 a107, 0\n\tv_accvgpr_write_b32 a108, 0\n\tv_accvgpr_write_b32 a109, 0\n\tv_accvgpr_write_b32 a110, 0\n\tv_accvgpr_write_b32 a111, 0\n\tv_accvgpr_write_b32 a112, 0\n\tv_accvgpr_write_b32 a113, 0\n\tv_accvgpr_write_b32 a114, 0\n\tv_accvgpr_write_b32 a115, 0\n\tv_accvgpr_write_b32 a116, 0\n\tv_accvgpr_write_b32 a117, 0\n\tv_accvgpr_write_b32 a118, 0\n\tv_accvgpr_write_b32 a119, 0\n\tv_accvgpr_write_b32 a120, 0\n\tv_accvgpr_write_b32 a121, 0\n\tv_accvgpr_write_b32 a122, 0\n\tv_accvgpr_write_b32 a123, 0\n\tv_accvgpr_write_b32 a124, 0\n\tv_accvgpr_write_b32 a125, 0\n\tv_accvgpr_write_b32 a126, 0\n\tv_accvgpr_write_b32 a127, 0" ::: LGS_WW_ACC_CLOBBER);
@@ -361,8 +367,8 @@ __global__ __launch_bounds__(256) void k_wgrad_wide_reduce(const float *__restri
   const int64_t tot = (int64_t)27 * cin * cq;
   if (idx >= tot) return;
   const int q = (int)(idx % cq), ci = (int)((idx / cq) % cin), k = (int)(idx / ((int64_t)cq * cin));
-  const int Mk = total[k];
-  const int nr = (Mk + chunk - 1) / chunk;
+  (void)total; (void)chunk;
+  const int nr = nchunk;                       // every position range wrote its tile (zeros when it has no pair of offset k)
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int c = 0; c < nr; ++c) {
     const float4 x = *reinterpret_cast<const float4 *>(partial + (((int64_t)(k * nchunk + c) * ci_pad + ci) * co_pad + q * 4));
@@ -382,16 +388,10 @@ inline WwPlan ww_plan(const View &v, int cin, int cout) {
   static const bool on = getenv("LGS_WGRAD_WIDE") == nullptr || atoi(getenv("LGS_WGRAD_WIDE")) != 0;   // A/B knob
   // maps below ~200 k positions keep the position-stationary kernel (level 2, 81 k rows, 256 -> 256: 0.82 vs 0.31 ms)
   if (!on || v.K != 27 || v.KS != 27 || v.nbr == nullptr || v.n_pad < 200000 || v.n_pad % kWwTile != 0) return p;
-  // pairs per workgroup range: as small as the partial-tile buffer (sized for the upper bound of N pairs per offset) allows --
-  // more, shorter workgroups balance better (level 1, 512 -> 256: 1.39 ms at 8192 vs 1.99 ms at 32768; level 0 is the same
-  // from 16384 up: 8.4 ms)
-  static const int chunk_env = getenv("LGS_WW_CHUNK") ? atoi(getenv("LGS_WW_CHUNK")) : 0;   // tuning knob
-  p.chunk = 8192;
-  while (p.chunk < (1 << 20) &&
-         (int64_t)27 * ((v.n_pad + p.chunk - 1) / p.chunk) * (((cin + 255) / 256) * 256) * (int64_t)(((cout + 255) / 256) * 256) * 4 > (1100ll << 20))
-    p.chunk *= 2;
-  if (chunk_env >= 1024) p.chunk = chunk_env / 64 * 64;
-  if (cin < 256 || cout < 256 || cin % 8 != 0 || cout % 8 != 0) return p;
+  // positions per workgroup range (a whole number of 256-position tiles): small enough that the rows of the ranges in flight
+  // fit the Infinity Cache, large enough that the fp32 partial tiles (256 KB per workgroup) stay a small part of the traffic
+  static const int range_env = getenv("LGS_WW_RANGE") ? atoi(getenv("LGS_WW_RANGE")) : 0;   // tuning knob
+  p.chunk = range_env >= 256 ? range_env / 256 * 256 : 16384;
   p.ntile = (int)(v.n_pad / kWwTile);
   p.nchunk = (int)((v.n_pad + p.chunk - 1) / p.chunk);
   p.ti = (cin + 255) / 256; p.tj = (cout + 255) / 256;
@@ -434,7 +434,7 @@ int conv_wgrad_wide(const View &v, const void *in, int cin, int in_ld, const voi
   }
   WwArgs a;
   a.in = reinterpret_cast<const bf16_t *>(in); a.gout = reinterpret_cast<const bf16_t *>(gout);
-  a.pin = pin; a.pout = pout; a.total = total; a.partial = partial; a.stride = v.n_pad;
+  a.pin = pin; a.pout = pout; a.total = total; a.off = off; a.ntile = p.ntile; a.partial = partial; a.stride = v.n_pad;
   a.cin = cin; a.cout = cout; a.in_ld = ld; a.nchunk = p.nchunk; a.chunk = p.chunk; a.ci_pad = p.ti * 256; a.co_pad = p.tj * 256; a.ti = p.ti; a.tj = p.tj;
   a.in_bytes = (unsigned)in_b; a.go_bytes = (unsigned)go_b;
   hipLaunchKernelGGL(k_wgrad_wide, dim3((unsigned)(27 * p.nchunk * p.ti * p.tj)), dim3(512), kWwLds, s, a);
