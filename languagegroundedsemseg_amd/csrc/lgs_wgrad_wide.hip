@@ -392,6 +392,9 @@ inline WwPlan ww_plan(const View &v, int cin, int cout) {
   // fit the Infinity Cache, large enough that the fp32 partial tiles (256 KB per workgroup) stay a small part of the traffic
   static const int range_env = getenv("LGS_WW_RANGE") ? atoi(getenv("LGS_WW_RANGE")) : 0;   // tuning knob
   p.chunk = range_env >= 256 ? range_env / 256 * 256 : 16384;
+  if (cin < 256 || cout < 256 || cin % 8 != 0 || cout % 8 != 0) return p;
+  while ((int64_t)27 * ((v.n_pad + p.chunk - 1) / p.chunk) * (((cin + 255) / 256) * 256) * (int64_t)(((cout + 255) / 256) * 256) * 4 > (3ll << 30))
+    p.chunk *= 2;
   p.ntile = (int)(v.n_pad / kWwTile);
   p.nchunk = (int)((v.n_pad + p.chunk - 1) / p.chunk);
   p.ti = (cin + 255) / 256; p.tj = (cout + 255) / 256;
