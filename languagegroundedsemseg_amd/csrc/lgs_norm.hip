@@ -11,6 +11,8 @@
 // are reduced per block in LDS, then across blocks through a [blocks, 2C] fp32 scratch that a small fold
 // kernel sums in a fixed order (double accumulation) -> deterministic, no float atomics.
 #include "lgs_common.h"
+#include <atomic>
+#include <mutex>
 
 namespace lgs {
 
@@ -379,6 +381,338 @@ inline int reduce_blocks(int64_t n, int64_t *rows_per_block) {
   return (int)((n + *rows_per_block - 1) / *rows_per_block > 0 ? (n + *rows_per_block - 1) / *rows_per_block : 1);
 }
 
+// ------------------------------------------------------------------------------------------------ one launch per direction
+// A BatchNorm direction is three dependent steps (column sums over all rows -> fold + finish the statistics -> elementwise
+// apply): three launches per direction made 372 of the compute stream's 596 launches per training step, most of them on
+// coarse levels where a launch is a few microseconds of work.  The fused kernels run the three steps in ONE launch of <= 512
+// co-resident workgroups separated by two grid-wide barriers (arrive = agent-scope add on a counter, wait = spin on
+// it); a workgroup applies to the SAME slab of rows it reduced, walking it backwards, so the rows it read last in step 1 are
+// the first it needs in step 3 (L2 / Infinity Cache hits instead of a second HBM pass on the large levels).
+// Co-residency: 512 workgroups x 256 threads at <= 128 VGPRs is half of what the chip holds (256 CUs x 4), so two such kernels
+// from different streams / processes can spin at the same time without starving each other's unscheduled workgroups.
+constexpr int kFusedMaxBlocks = 512;
+
+// Values that cross workgroups inside a fused kernel (scratch rows, statistics) are written and read with agent-scope
+// accesses (sc1: coherent across the eight XCDs' L2s) instead of fencing: a release / acquire fence at agent scope writes back
+// and invalidates the whole L2 of the XCD, and 512 workgroups doing that twice cost 0.24 ms per launch.
+__device__ inline void st_coh(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline float ld_coh(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void grid_arrive_wait(unsigned *ctr, unsigned target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's coherent stores are acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+}
+// the last workgroup to leave puts the counter back to zero for the slot's next user
+__device__ inline void grid_leave(unsigned *ctr, unsigned total) {
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == total - 1) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// fold_sums over rows other workgroups of this launch wrote
+__device__ inline void fold_sums_coh(const float *scratch, int nblocks, int c, int ch, int part, double &s, double &ss,
+                                     double (*red)[2][kFoldCh]) {
+  s = 0.0; ss = 0.0;
+  if (ch < c) {
+#pragma unroll 8
+    for (int b = part; b < nblocks; b += kFoldSl) { s += ld_coh(scratch + (int64_t)b * 2 * c + ch); ss += ld_coh(scratch + (int64_t)b * 2 * c + c + ch); }
+  }
+  red[part][0][threadIdx.x % kFoldCh] = s;
+  red[part][1][threadIdx.x % kFoldCh] = ss;
+  __syncthreads();
+  if (part == 0) {
+    for (int q = 1; q < kFoldSl; ++q) { s += red[q][0][threadIdx.x % kFoldCh]; ss += red[q][1][threadIdx.x % kFoldCh]; }
+  }
+}
+
+// column sums of one slab of rows [r0, r1) -> dst[2][C]; the body of k_colreduce (same summation order)
+template <typename T, int MODE>
+__device__ inline void colreduce_slab(const T *x, const T *y, const T *dy, const float *stats, const float *gamma, const float *beta,
+                                      int64_t n, int c, int relu, int64_t r0, int64_t r1, float *dst, int64_t dy_ld, int64_t y_ld) {
+  constexpr int W = Vec<T>::W;
+  const int G = c / W, RL = kNT / G;
+  const int cg = threadIdx.x % G, rl = threadIdx.x / G;
+  const bool active = rl < RL;
+  float s0[W], s1[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) s0[i] = s1[i] = 0.f;
+  float mean[W], istd[W], gm[W], bt[W];
+  if (MODE == 1) {
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      mean[i] = stats[cg * W + i]; istd[i] = stats[c + cg * W + i];
+      gm[i] = relu == 2 ? gamma[cg * W + i] : 0.f; bt[i] = relu == 2 ? beta[cg * W + i] : 0.f;
+    }
+  } else {
+    if (n > 0) Vec<T>::load(x + cg * W, mean);   // pivot = row 0, as in k_colreduce<T, 0>
+  }
+  if (active) {
+    int64_t r = r0 + rl;
+    constexpr int U = MODE == 0 ? 4 : 2;
+    auto accumulate = [&](const float (&xv)[W], float (&gv)[W], const float (&yv)[W]) __attribute__((always_inline)) {
+      if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < W; ++i) { const float d = xv[i] - mean[i]; s0[i] += d; s1[i] += d * d; }
+      } else {
+        if (relu == 1) {
+#pragma unroll
+          for (int i = 0; i < W; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
+        } else if (relu == 2) {
+#pragma unroll
+          for (int i = 0; i < W; ++i) gv[i] = ((xv[i] - mean[i]) * (istd[i] * gm[i]) + bt[i]) > 0.f ? gv[i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < W; ++i) { s0[i] += gv[i]; s1[i] += gv[i] * (xv[i] - mean[i]) * istd[i]; }
+      }
+    };
+    for (; r + (U - 1) * RL < r1; r += U * RL) {
+      float xv[U][W], gv[U][W], yv[U][W];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        Vec<T>::load(x + (r + u * RL) * c + cg * W, xv[u]);
+        if (MODE == 1) {
+          Vec<T>::load(dy + (r + u * RL) * dy_ld + cg * W, gv[u]);
+          if (relu == 1) Vec<T>::load(y + (r + u * RL) * y_ld + cg * W, yv[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) accumulate(xv[u], gv[u], yv[u]);
+    }
+    for (; r < r1; r += RL) {
+      float xv[W], gv[W], yv[W];
+      Vec<T>::load(x + r * c + cg * W, xv);
+      if (MODE == 1) {
+        Vec<T>::load(dy + r * dy_ld + cg * W, gv);
+        if (relu == 1) Vec<T>::load(y + r * y_ld + cg * W, yv);
+      }
+      accumulate(xv, gv, yv);
+    }
+  }
+  __shared__ float red[2][kNT][8];
+#pragma unroll
+  for (int i = 0; i < W; ++i) { red[0][threadIdx.x][i] = s0[i]; red[1][threadIdx.x][i] = s1[i]; }
+  __syncthreads();
+  if (rl == 0) {
+    for (int j = 1; j < RL; ++j) {
+#pragma unroll
+      for (int i = 0; i < W; ++i) { s0[i] += red[0][j * G + cg][i]; s1[i] += red[1][j * G + cg][i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < W; ++i) { st_coh(dst + cg * W + i, s0[i]); st_coh(dst + c + cg * W + i, s1[i]); }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(4))) void k_bn_fwd_fused(const T *x, const T *res, int64_t n, int c, const float *gamma, const float *beta,
+                                                      float eps, float momentum, float *running_mean, float *running_var,
+                                                      long long *nbt, float *stats, int relu, T *y, int64_t y_ld, float *scratch,
+                                                      const float *partials, int partial_rows, int partial_rpb, int nfoldrows,
+                                                      const float *pivot_ptr, int64_t rows_per_block, unsigned *ctr) {
+  constexpr int W = Vec<T>::W;
+  const unsigned nwg = gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(r0 + rows_per_block, n);
+  // ---- step 1: per-workgroup column sums (or: fold the conv epilogue's partial rows into <= 128 rows)
+  if (partials) {
+    const int c2 = 2 * c;
+    for (int pb = blockIdx.x; pb < nfoldrows; pb += nwg) {
+      const int p0 = pb * partial_rpb, p1 = min(p0 + partial_rpb, partial_rows);
+      for (int col = threadIdx.x; col < c2; col += kNT) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int r = p0;
+        for (; r + 4 <= p1; r += 4) {
+          a0 += partials[(int64_t)(r + 0) * c2 + col]; a1 += partials[(int64_t)(r + 1) * c2 + col];
+          a2 += partials[(int64_t)(r + 2) * c2 + col]; a3 += partials[(int64_t)(r + 3) * c2 + col];
+        }
+        for (; r < p1; ++r) a0 += partials[(int64_t)r * c2 + col];
+        st_coh(scratch + (int64_t)pb * c2 + col, (a0 + a1) + (a2 + a3));
+      }
+    }
+  } else {
+    colreduce_slab<T, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, n, c, 0, r0, r1, scratch + (int64_t)blockIdx.x * 2 * c, c, c);
+  }
+  grid_arrive_wait(ctr, nwg);
+  // ---- step 2: fold + finish the statistics, 16 channels per workgroup
+  {
+    __shared__ double red[kFoldSl][2][kFoldCh];
+    const int nfb = (c + kFoldCh - 1) / kFoldCh;
+    for (int fb = blockIdx.x; fb < nfb; fb += nwg) {
+      const int ch = fb * kFoldCh + (threadIdx.x % kFoldCh), part = threadIdx.x / kFoldCh;
+      double s, ss;
+      fold_sums_coh(scratch, nfoldrows, c, ch, part, s, ss, red);
+      if (part == 0 && ch < c) {
+        const double pivot = partials ? (pivot_ptr ? (double)pivot_ptr[ch] : 0.0) : (n > 0 ? (double)ld_elem(x + ch) : 0.0);
+        const double dm = n > 0 ? s / (double)n : 0.0;
+        double var = n > 0 ? ss / (double)n - dm * dm : 0.0;
+        if (var < 0.0) var = 0.0;
+        const double mean = pivot + dm;
+        st_coh(stats + ch, (float)mean);
+        st_coh(stats + c + ch, (float)(1.0 / sqrt(var + (double)eps)));
+        if (running_mean) {
+          const double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
+          running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+          running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+        }
+      }
+      __syncthreads();
+    }
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+  }
+  grid_arrive_wait(ctr, 2 * nwg);
+  grid_leave(ctr, 3 * nwg);
+  // ---- step 3: y = relu?((x - mean) * invstd * gamma + beta (+ residual)) over this workgroup's slab, last rows first
+  const int G = c / W, RL = kNT / G;
+  const int cg = threadIdx.x % G, rl = threadIdx.x / G;
+  if (rl >= RL) return;
+  float sc[W], mean[W], bt[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    const int ch = cg * W + k;
+    sc[k] = ld_coh(stats + c + ch) * gamma[ch];
+    mean[k] = ld_coh(stats + ch);
+    bt[k] = beta[ch];
+  }
+  constexpr int U = W == 8 ? 2 : 4;   // rows in flight per thread (registers: <= 128 VGPRs, see above)
+  for (int64_t r = r1 - 1 - rl; r >= r0; r -= (int64_t)U * RL) {
+    float xv[U][W], rv[U][W];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t ru = r - (int64_t)u * RL;
+      if (ru >= r0) {
+        Vec<T>::load(x + ru * c + cg * W, xv[u]);
+        if (res) Vec<T>::load(res + ru * c + cg * W, rv[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t ru = r - (int64_t)u * RL;
+      if (ru >= r0) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          float o = (xv[u][k] - mean[k]) * sc[k] + bt[k];   // the exact expression of k_bn_apply (the backward recomputes the mask from it)
+          if (res) o += rv[u][k];
+          xv[u][k] = (relu && o < 0.f) ? 0.f : o;
+        }
+        Vec<T>::store(y + ru * y_ld + cg * W, xv[u]);
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(4))) void k_bn_bwd_fused(const T *x, const T *y, const T *dy, int64_t n, int c, const float *gamma,
+                                                      const float *beta, const float *stats, int relu, T *dx, T *dres, float *dgamma,
+                                                      float *dbeta, float *scratch, float *sums, int64_t dy_ld, int64_t y_ld,
+                                                      int64_t rows_per_block, float inv_n, unsigned *ctr) {
+  constexpr int W = Vec<T>::W;
+  const unsigned nwg = gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(r0 + rows_per_block, n);
+  colreduce_slab<T, 1>(x, y, dy, stats, gamma, beta, n, c, relu, r0, r1, scratch + (int64_t)blockIdx.x * 2 * c, dy_ld, y_ld);
+  grid_arrive_wait(ctr, nwg);
+  {
+    __shared__ double red[kFoldSl][2][kFoldCh];
+    const int nfb = (c + kFoldCh - 1) / kFoldCh;
+    for (int fb = blockIdx.x; fb < nfb; fb += nwg) {
+      const int ch = fb * kFoldCh + (threadIdx.x % kFoldCh), part = threadIdx.x / kFoldCh;
+      double s, ss;
+      fold_sums_coh(scratch, (int)nwg, c, ch, part, s, ss, red);
+      if (part == 0 && ch < c) {
+        dbeta[ch] = (float)s; dgamma[ch] = (float)ss;
+        st_coh(sums + ch, (float)s); st_coh(sums + c + ch, (float)ss);
+      }
+      __syncthreads();
+    }
+  }
+  grid_arrive_wait(ctr, 2 * nwg);
+  grid_leave(ctr, 3 * nwg);
+  const int G = c / W, RL = kNT / G;
+  const int cg = threadIdx.x % G, rl = threadIdx.x / G;
+  if (rl >= RL) return;
+  float mean[W], istd[W], sc[W], bt[W], gi[W], m1[W], m2[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    const int ch = cg * W + k;
+    mean[k] = stats[ch]; istd[k] = stats[c + ch];
+    sc[k] = istd[k] * (relu == 2 ? gamma[ch] : 0.f);
+    bt[k] = relu == 2 ? beta[ch] : 0.f;
+    gi[k] = gamma[ch] * istd[k];
+    m1[k] = ld_coh(sums + ch) * inv_n; m2[k] = ld_coh(sums + c + ch) * inv_n;
+  }
+  constexpr int U = W == 8 ? 1 : 2;
+  for (int64_t r = r1 - 1 - rl; r >= r0; r -= (int64_t)U * RL) {
+    float xv[U][W], gv[U][W], yv[U][W];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t ru = r - (int64_t)u * RL;
+      if (ru >= r0) {
+        Vec<T>::load(x + ru * c + cg * W, xv[u]);
+        Vec<T>::load(dy + ru * dy_ld + cg * W, gv[u]);
+        if (relu == 1) Vec<T>::load(y + ru * y_ld + cg * W, yv[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t ru = r - (int64_t)u * RL;
+      if (ru >= r0) {
+        if (relu == 1) {
+#pragma unroll
+          for (int k = 0; k < W; ++k) gv[u][k] = yv[u][k] > 0.f ? gv[u][k] : 0.f;
+        } else if (relu == 2) {
+#pragma unroll
+          for (int k = 0; k < W; ++k) gv[u][k] = ((xv[u][k] - mean[k]) * sc[k] + bt[k]) > 0.f ? gv[u][k] : 0.f;
+        }
+        if (dres) Vec<T>::store(dres + ru * c + cg * W, gv[u]);
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          const float xh = (xv[u][k] - mean[k]) * istd[k];
+          xv[u][k] = gi[k] * (gv[u][k] - m1[k] - xh * m2[k]);
+        }
+        Vec<T>::store(dx + ru * c + cg * W, xv[u]);
+      }
+    }
+  }
+}
+
+// barrier counters of the fused kernels: a ring of slots per device, zeroed once; a kernel leaves its slot at zero
+constexpr int kCtrSlots = 256;
+inline unsigned *fused_counter() {
+  static unsigned *ring[64] = {nullptr};
+  static std::atomic<unsigned> next[64];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ring[dev]) {
+    unsigned *p = nullptr;
+    if (hipMalloc(&p, kCtrSlots * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, kCtrSlots * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+    ring[dev] = p;
+  }
+  return ring[dev] + (next[dev].fetch_add(1) % kCtrSlots);
+}
+inline bool bn_fused_on(int64_t tensor_bytes) {
+  static const bool on = getenv("LGS_BN_FUSED") == nullptr || atoi(getenv("LGS_BN_FUSED")) != 0;   // A/B knob: 0 = three launches
+  // above ~24 MB a direction is bandwidth-bound and the three-launch path's 4096-workgroup apply streams faster than 512
+  // resident workgroups can (1.2 M rows x 96 ch bf16 forward: 0.135 ms vs 0.181 ms fused); below, launches dominate
+  static const int64_t max_mb = getenv("LGS_BN_FUSED_MAX_MB") ? atoll(getenv("LGS_BN_FUSED_MAX_MB")) : 24;
+  return on && tensor_bytes <= (max_mb << 20);
+}
+inline int fused_blocks(int64_t n, int64_t *rows_per_block) {
+  int64_t nb = (n + 127) / 128;
+  if (nb > kFusedMaxBlocks) nb = kFusedMaxBlocks;
+  if (nb < 1) nb = 1;
+  int64_t rpb = (n + nb - 1) / nb;
+  if (rpb < 1) rpb = 1;
+  *rows_per_block = rpb;
+  nb = (n + rpb - 1) / rpb;
+  return (int)(nb > 0 ? nb : 1);
+}
+
 // statistics source: either the column reduction over x, or the conv epilogue's per-tile partial rows
 template <typename T>
 int stats_partials(const T *x, int64_t n, int c, const float *partials, int partial_rows, float *scratch, hipStream_t s, int *nb_out) {
@@ -408,6 +742,23 @@ int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const flo
   float *scratch = reinterpret_cast<float *>(workspace);  // caller-owned: no allocator call (and no implicit sync) here
   const T *x = reinterpret_cast<const T *>(xv);
   const int pm = (partials && partial_rows > 0) ? 1 : 0;
+  if (bn_fused_on(n * (int64_t)c * (int64_t)sizeof(T))) {
+    unsigned *ctr = fused_counter();
+    LGS_REQUIRE(ctr != nullptr, "lgs_bn_forward: could not allocate the grid-barrier counters");
+    int64_t rpb;
+    const int grid = fused_blocks(n, &rpb);
+    int prpb = 0, nfold = grid;
+    if (pm) {
+      int pnb = partial_rows < 128 ? partial_rows : 128;
+      prpb = (partial_rows + pnb - 1) / pnb;
+      nfold = (partial_rows + prpb - 1) / prpb;
+    }
+    hipLaunchKernelGGL((k_bn_fwd_fused<T>), grid, kNT, 0, s, x, reinterpret_cast<const T *>(res), n, c, gamma, beta, eps, momentum, rm, rv, nbt,
+                       stats, relu, reinterpret_cast<T *>(yv), y_ld, scratch, pm ? partials : (const float *)nullptr, partial_rows, prpb, nfold,
+                       pivot, rpb, ctr);
+    LGS_HIP(hipGetLastError());
+    return 0;
+  }
   stats_partials<T>(x, n, c, partials, partial_rows, scratch, s, &nb);
   hipLaunchKernelGGL((k_fold_fwd<T>), (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, x, nb, c, n, eps, momentum, rm, rv, nbt, stats, pm, pivot);
   int64_t total = n * (int64_t)(c / W);
@@ -431,6 +782,17 @@ int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, in
   float *scratch = reinterpret_cast<float *>(workspace);
   float *sums = scratch + (size_t)2 * c * nb;
   const T *x = reinterpret_cast<const T *>(xv), *y = reinterpret_cast<const T *>(yv), *dy = reinterpret_cast<const T *>(dyv);
+  if (bn_fused_on(n * (int64_t)c * (int64_t)sizeof(T))) {
+    unsigned *ctr = fused_counter();
+    LGS_REQUIRE(ctr != nullptr, "lgs_bn_backward: could not allocate the grid-barrier counters");
+    int64_t frpb;
+    const int grid = fused_blocks(n, &frpb);
+    hipLaunchKernelGGL((k_bn_bwd_fused<T>), grid, kNT, 0, s, x, y, dy, n, c, gamma, beta, stats, relu, reinterpret_cast<T *>(dxv),
+                       reinterpret_cast<T *>(dresv), dgamma, dbeta, scratch, scratch + (size_t)2 * c * grid, dy_ld, y_ld, frpb,
+                       n > 0 ? 1.f / (float)n : 0.f, ctr);
+    LGS_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, x, y, dy, stats, gamma, beta, n, c, relu, rpb, scratch, dy_ld, y_ld);
   hipLaunchKernelGGL(k_fold_bwd, (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, nb, c, dgamma, dbeta, sums);
   int64_t total = n * (int64_t)(c / W);

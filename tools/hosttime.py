@@ -8,7 +8,8 @@ from languagegroundedsemseg_amd.ddp import BucketedDDP
 from languagegroundedsemseg_amd.synthetic import make_batch
 
 dev = torch.device("cuda:0")
-B = 8
+import os
+B = int(os.environ.get("HOSTTIME_SCENES", "8"))
 coords_np, feats_np, labels_np = make_batch(list(range(B)), voxel=0.02, n_target=150000)
 coords, feats, labels = [torch.from_numpy(a).to(dev) for a in (coords_np, feats_np, labels_np)]
 model = bench.build(dev, torch.bfloat16)
@@ -27,8 +28,15 @@ for i in range(3):
     print("host enqueue %.1f ms, then GPU drain %.1f ms, total %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t2 - t0) * 1e3))
 import cProfile, pstats
 pr = cProfile.Profile()
-pr.enable()
-bench.train_step(model, ddp, opt, coords, feats, labels, torch.bfloat16, 20)
-pr.disable()
+with torch.autograd.set_multithreading_enabled(False):   # backward on this thread, so that the profiler sees it
+    bench.train_step(model, ddp, opt, coords, feats, labels, torch.bfloat16, 19)
+    torch.cuda.synchronize()
+    pr.enable()
+    for i in range(5):
+        bench.train_step(model, ddp, opt, coords, feats, labels, torch.bfloat16, 20 + i)
+    pr.disable()
 torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+print("== 5 steps, by cumulative time")
+pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+print("== 5 steps, by own time")
+pstats.Stats(pr).sort_stats("tottime").print_stats(45)
