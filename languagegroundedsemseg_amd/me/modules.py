@@ -59,11 +59,41 @@ def grad_slot_view(param):
     return flat[off:off + n].view(shape)
 
 
+def conv_weight_grad(kmap, feats, gout, transposed, kparam, kshape, kdtype):
+    """Weight gradient of one convolution.  When the kernel parameter owns a bucket slot the gradient is written straight
+    into it ON A SIDE STREAM (off the backward critical path dgrad -> BN -> dgrad ...; both kernels are latency-bound, so
+    running them concurrently fills the machine) and the slot view is returned for autograd to adopt as `.grad`."""
+    view = grad_slot_view(kparam) if kparam is not None else None
+    backend = get_backend()
+    if view is None or not gout.is_cuda or not hasattr(backend, "side_stream"):
+        return kmap.conv_wgrad(feats, gout, transposed).reshape(kshape).to(kdtype)
+    if _DBG_WGRAD == "skip":
+        return view                                      # profiling knob: no weight gradient at all
+    if _DBG_WGRAD == "inline":
+        kmap.conv_wgrad(feats, gout, transposed, out=view.view(kmap.K, -1, kshape[-1]))
+        return view                                      # profiling knob: weight gradient on the compute stream
+    main = torch.cuda.current_stream(gout.device)
+    side = backend.side_stream(gout.device)
+    side.wait_stream(main)                               # feats / gout are ready
+    with torch.cuda.stream(side):
+        kmap.conv_wgrad(feats, gout, transposed, out=view.view(kmap.K, -1, kshape[-1]))
+        # one reusable event per parameter: BucketedDDP waits for exactly the weight gradients of the bucket it is about
+        # to reduce (ddp._wait_bucket_wgrads), not for the whole side stream
+        ev = getattr(kparam, "_lgs_wgrad_event", None)
+        if ev is None:
+            ev = kparam._lgs_wgrad_event = torch.cuda.Event()
+        ev.record(side)
+        _WGRAD_SEQ[0] += 1
+        kparam._lgs_wgrad_seq = _WGRAD_SEQ[0]
+        owner = getattr(kparam, "_lgs_ddp", None)
+        kparam._lgs_wgrad_step = owner._step if owner is not None else -1
+    feats.record_stream(side)
+    gout.record_stream(side)
+    return view                                          # consumers wait for the side stream in BucketedDDP
+
+
 class MinkowskiConvolutionFunction(torch.autograd.Function):
-    """out = conv(in) over a cached kernel map; backward = dgrad + wgrad (+ bias grad) on the same map.
-    When the kernel parameter owns a bucket slot the weight gradient is written straight into it ON A SIDE STREAM:
-    wgrad is off the backward critical path (dgrad -> BN -> dgrad ...), and both kernels are latency-bound, so running
-    them concurrently fills the machine."""
+    """out = conv(in) over a cached kernel map; backward = dgrad + wgrad (conv_weight_grad) (+ bias grad) on the same map."""
 
     @staticmethod
     def forward(ctx, feats, kernel, bias, kmap, transposed, bn_pivot=None, want_bn_stats=False, pack_cache=None):
@@ -86,35 +116,7 @@ class MinkowskiConvolutionFunction(torch.autograd.Function):
         gout = gout.contiguous()
         gin = gw = gb = None
         if ctx.needs_input_grad[1]:
-            view = grad_slot_view(ctx.kparam) if ctx.kparam is not None else None
-            backend = get_backend()
-            if view is not None and gout.is_cuda and hasattr(backend, "side_stream") and _DBG_WGRAD == "skip":
-                gw = view                                    # profiling knob: no weight gradient at all
-            elif view is not None and gout.is_cuda and hasattr(backend, "side_stream") and _DBG_WGRAD == "inline":
-                ctx.kmap.conv_wgrad(feats, gout, ctx.transposed, out=view.view(ctx.kmap.K, -1, ctx.kshape[-1]))
-                gw = view                                    # profiling knob: weight gradient on the compute stream
-            elif view is not None and gout.is_cuda and hasattr(backend, "side_stream"):
-                main = torch.cuda.current_stream(gout.device)
-                side = backend.side_stream(gout.device)
-                side.wait_stream(main)                       # feats / gout are ready
-                with torch.cuda.stream(side):
-                    gw = ctx.kmap.conv_wgrad(feats, gout, ctx.transposed, out=view.view(ctx.kmap.K, -1, ctx.kshape[-1]))
-                    # one reusable event per parameter: BucketedDDP waits for exactly the weight gradients of the bucket it
-                    # is about to reduce (ddp._wait_bucket_wgrads), not for the whole side stream
-                    kp = ctx.kparam
-                    ev = getattr(kp, "_lgs_wgrad_event", None)
-                    if ev is None:
-                        ev = kp._lgs_wgrad_event = torch.cuda.Event()
-                    ev.record(side)
-                    _WGRAD_SEQ[0] += 1
-                    kp._lgs_wgrad_seq = _WGRAD_SEQ[0]
-                    owner = getattr(kp, "_lgs_ddp", None)
-                    kp._lgs_wgrad_step = owner._step if owner is not None else -1
-                feats.record_stream(side)
-                gout.record_stream(side)
-                gw = view                                    # consumers wait for the side stream in BucketedDDP
-            else:
-                gw = ctx.kmap.conv_wgrad(feats, gout, ctx.transposed).reshape(ctx.kshape).to(kernel.dtype)
+            gw = conv_weight_grad(ctx.kmap, feats, gout, ctx.transposed, ctx.kparam, ctx.kshape, kernel.dtype)
         if ctx.needs_input_grad[0]:
             if getattr(ctx, "pack_cache", None) is not None:
                 gin = ctx.kmap.conv_dgrad(gout, kernel, ctx.transposed, pack_cache=ctx.pack_cache)

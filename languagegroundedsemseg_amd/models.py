@@ -43,10 +43,155 @@ class BasicBlock(nn.Module):
         self.cat_up = 0          # > 0: this block's output is a skip tensor; channels of the `up` half it will be concatenated with
 
     def forward(self, x):
+        if _block_fast_path_ok(self, x):
+            return _block_fast_forward(self, x)
         out = self.norm1(self.conv1(x, bn=self.norm1), relu=True)
         out = self.conv2(out, bn=self.norm2)
         residual = x if self.downsample is None else self.downsample[1](self.downsample[0](x, bn=self.downsample[1]))
         return self.norm2(out, relu=self.final_relu, residual=residual, cat_up=self.cat_up)
+
+
+# ---------------------------------------------------------------------------------------------- whole-block autograd node
+# Op by op a BasicBlock is 4 (6 with a downsample branch) autograd nodes, as many module calls and SparseTensor wrappers each
+# way; at one scene per step (~150 k voxels) the training step is bound by exactly that host work.
+# The fast path issues the same engine calls, in the same order, with the same arguments, from ONE autograd node:
+#   forward   conv1 -> norm1+ReLU -> conv2 -> [downsample conv 1x1
+#             -> its norm] -> norm2 + residual (+ ReLU)
+#   backward  norm2 -> {wgrad2 on the side stream, dgrad2} -> norm1 -> {wgrad1, dgrad1} [-> downsample norm -> {wgrad, dgrad}]
+#             -> ONE in-place add of the residual branch's gradient (autograd's accumulation of the two branches, same rounding)
+# It is taken only when every module of the block is a plain training-mode MinkowskiConvolution / MinkowskiBatchNorm on the
+# HIP backend with no hooks attached (the layer-wise parity tests hook the modules and so run the op-by-op path);
+# LGS_BLOCK_FUSED=0 turns it off.
+import os as _os
+_BLOCK_FUSED = _os.environ.get("LGS_BLOCK_FUSED", "1") != "0"
+
+
+def _plain(m):
+    return not (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks)
+
+
+def _block_fast_path_ok(blk, x):
+    if not _BLOCK_FUSED or blk.cat_up or not x.F.is_cuda or not torch.is_grad_enabled():
+        return False
+    from torch.nn.modules import module as _m
+    if _m._global_forward_hooks or _m._global_forward_pre_hooks or _m._global_backward_hooks or not _plain(blk):
+        return False
+    be = ME.get_backend()
+    if not (hasattr(be, "bn_forward") and hasattr(be, "side_stream") and getattr(be, "bn_counts_batches", False)):
+        return False
+    convs, norms = [blk.conv1, blk.conv2], [blk.norm1, blk.norm2]
+    if blk.downsample is not None:
+        if len(blk.downsample) != 2:
+            return False
+        convs.append(blk.downsample[0]); norms.append(blk.downsample[1])
+    for c in convs:
+        if type(c) is not ME.MinkowskiConvolution or c.bias is not None or c.kernel.dtype != torch.float32 or not _plain(c):
+            return False
+    for n in norms:
+        b = n.bn
+        if type(n) is not ME.MinkowskiBatchNorm or not (b.training and b.affine and b.track_running_stats) or not _plain(n) or not _plain(b):
+            return False
+    return x.F.dtype in (torch.bfloat16, torch.float32) and x.F.shape[1] == blk.conv1.in_channels
+
+
+def _block_fast_forward(blk, x):
+    mgr, key = x.coordinate_manager, x.coordinate_map_key
+    kmap3 = mgr.kernel_map_handle(key, key, 3)
+    ds = blk.downsample
+    if ds is not None:
+        kmap1 = mgr.kernel_map_handle(key, key, 1)
+        y = _BasicBlockFunction.apply(x.F, blk, kmap3, kmap1, blk.conv1.kernel, blk.norm1.bn.weight, blk.norm1.bn.bias,
+                                      blk.conv2.kernel, blk.norm2.bn.weight, blk.norm2.bn.bias,
+                                      ds[0].kernel, ds[1].bn.weight, ds[1].bn.bias)
+    else:
+        y = _BasicBlockFunction.apply(x.F, blk, kmap3, None, blk.conv1.kernel, blk.norm1.bn.weight, blk.norm1.bn.bias,
+                                      blk.conv2.kernel, blk.norm2.bn.weight, blk.norm2.bn.bias)
+    return ME.SparseTensor(y, coordinate_map_key=key, coordinate_manager=mgr)
+
+
+def _bn_fwd(be, x, bn, g, b, residual, relu, conv_stats):
+    if conv_stats is not None and (conv_stats[1] is None):
+        conv_stats = None                                  # pivot convention of MinkowskiBatchNorm.forward
+    if conv_stats is not None:
+        return be.bn_forward(x, g, b, bn.eps, bn.momentum, bn.running_mean, bn.running_var, residual, relu, bn.num_batches_tracked,
+                             conv_stats=conv_stats)
+    return be.bn_forward(x, g, b, bn.eps, bn.momentum, bn.running_mean, bn.running_var, residual, relu, bn.num_batches_tracked)
+
+
+def _bn_bwd(be, x, y, dy, g, b, gp, bp, stats, relu_mode, want_res, need):
+    """-> dx, dres, d gamma, d beta (the last two as bucket-slot views when the parameters gp / bp own slots)"""
+    from .me.modules import grad_slot_view
+    gv = grad_slot_view(gp) if gp is not None else None
+    bv = grad_slot_view(bp) if bp is not None else None
+    if gv is None or bv is None:
+        gv = bv = None
+    dx, dres, dg, db = be.bn_backward(x, y, dy, g, b, stats, relu_mode, want_res, gv, bv)
+    if gv is not None:
+        return dx, dres, gv, bv
+    return dx, dres, (dg.to(g.dtype) if need else None), (db.to(g.dtype) if need else None)
+
+
+class _BasicBlockFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, blk, kmap3, kmap1, w1, g1, b1, w2, g2, b2, wd=None, gd=None, bd=None):
+        be = ME.get_backend()
+        n1, n2 = blk.norm1.bn, blk.norm2.bn
+        pc1, pc2 = blk.conv1._cache_for(x), blk.conv2._cache_for(x)
+        want = bool(getattr(be, "conv_bn_stats", False))   # the conv epilogue also emits the next norm's statistics (off by default)
+        o1, s1 = kmap3.conv_forward(x, w1, None, False, bn_pivot=n1.running_mean, want_bn_stats=True, pack_cache=pc1) if want else \
+            (kmap3.conv_forward(x, w1, None, False, pack_cache=pc1), None)
+        y1, st1 = _bn_fwd(be, o1, n1, g1, b1, None, True, s1)
+        o2, s2 = kmap3.conv_forward(y1, w2, None, False, bn_pivot=n2.running_mean, want_bn_stats=True, pack_cache=pc2) if want else \
+            (kmap3.conv_forward(y1, w2, None, False, pack_cache=pc2), None)
+        ctx.has_ds = wd is not None
+        if ctx.has_ds:
+            nd = blk.downsample[1].bn
+            pcd = blk.downsample[0]._cache_for(x)
+            od, sd = kmap1.conv_forward(x, wd, None, False, bn_pivot=nd.running_mean, want_bn_stats=True, pack_cache=pcd) if want else \
+                (kmap1.conv_forward(x, wd, None, False, pack_cache=pcd), None)
+            res, std = _bn_fwd(be, od, nd, gd, bd, None, False, sd)
+        else:
+            res = x
+        relu = bool(blk.final_relu)
+        y2, st2 = _bn_fwd(be, o2, n2, g2, b2, res, relu, s2)
+        ctx.kmap3, ctx.kmap1, ctx.relu, ctx.pc = kmap3, kmap1, relu, (pc1, pc2, pcd if ctx.has_ds else None)
+        ctx.params = tuple(t if isinstance(t, nn.Parameter) else None for t in (w1, g1, b1, w2, g2, b2, wd, gd, bd))
+        if ctx.has_ds:
+            ctx.save_for_backward(x, w1, g1, b1, w2, g2, b2, o1, st1, y1, o2, st2, y2, wd, gd, bd, od, std)
+        else:
+            ctx.save_for_backward(x, w1, g1, b1, w2, g2, b2, o1, st1, y1, o2, st2, y2)
+        return y2
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .me.modules import conv_weight_grad
+        be = ME.get_backend()
+        sv = ctx.saved_tensors
+        x, w1, g1, b1, w2, g2, b2, o1, st1, y1, o2, st2, y2 = sv[:13]
+        need = ctx.needs_input_grad
+        kmap3, (pc1, pc2, pcd) = ctx.kmap3, ctx.pc
+        pw1, pg1, pb1, pw2, pg2, pb2, pwd, pgd, pbd = ctx.params
+        # inputs: 0 x | 1 blk 2 kmap3 3 kmap1 | 4 w1 5 g1 6 b1 | 7 w2 8 g2 9 b2 | 10 wd 11 gd 12 bd
+        # norm2 (+ residual) (+ ReLU): mask from the saved output when there is a ReLU (a residual was added)
+        dx2, dres, dg2, db2 = _bn_bwd(be, o2, y2 if ctx.relu else None, dy, g2, b2, pg2, pb2, st2, 1 if ctx.relu else 0, True,
+                                      need[8] or need[9])
+        gw2 = conv_weight_grad(kmap3, y1, dx2, False, pw2, w2.shape, w2.dtype) if need[7] else None
+        dy1 = kmap3.conv_dgrad(dx2, w2, False, pack_cache=pc2)
+        dx1, _, dg1, db1 = _bn_bwd(be, o1, None, dy1, g1, b1, pg1, pb1, st1, 2, False, need[5] or need[6])
+        gw1 = conv_weight_grad(kmap3, x, dx1, False, pw1, w1.shape, w1.dtype) if need[4] else None
+        gin = None
+        if ctx.has_ds:
+            wd, gd, bd, od, std = sv[13:]
+            dxd, _, dgd, dbd = _bn_bwd(be, od, None, dres, gd, bd, pgd, pbd, std, 0, False, need[11] or need[12])
+            gwd = conv_weight_grad(ctx.kmap1, x, dxd, False, pwd, wd.shape, wd.dtype) if need[10] else None
+            if need[0]:
+                gin = kmap3.conv_dgrad(dx1, w1, False, pack_cache=pc1)
+                gin += ctx.kmap1.conv_dgrad(dxd, wd, False, pack_cache=pcd)
+            return gin, None, None, None, gw1, dg1, db1, gw2, dg2, db2, gwd, dgd, dbd
+        if need[0]:
+            gin = kmap3.conv_dgrad(dx1, w1, False, pack_cache=pc1)
+            gin += dres
+        return gin, None, None, None, gw1, dg1, db1, gw2, dg2, db2
 
 
 class Res16UNet(ME.MinkowskiNetwork):

@@ -284,3 +284,59 @@ def test_insseg_step_at_size_vs_oracle(frozen):
     b = _insseg_step(DEV, torch.bfloat16, coords, feats, labels, inst, centers, frozen)
     print("insseg bf16: offsets rel-L2 %.2e, logits rel-L2 %.2e, loss %.5f" % (rel_l2(b[0], o[0]), rel_l2(b[1], o[1]), b[2]))
     assert rel_l2(b[1], o[1]) < 5e-2 and abs(b[2] - o[2]) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------- whole-block autograd node
+@pytest.mark.parametrize("name,dtype,bucketed", [("Res16UNet34C", torch.bfloat16, True), ("Res16UNet14A", torch.float32, False),
+                                                 ("Res16UNet34D", torch.bfloat16, True)])
+def test_block_fast_path_is_the_op_by_op_path(name, dtype, bucketed):
+    """models._BasicBlockFunction issues the same engine calls as the module-by-module BasicBlock.forward: logits, running
+    statistics and every parameter gradient must be IDENTICAL (deterministic kernels, same arguments, same order; the one
+    in-place add of the residual-branch gradient is autograd's own accumulation), with and without gradient buckets"""
+    from languagegroundedsemseg_amd import models
+    from languagegroundedsemseg_amd.ddp import BucketedDDP
+    from languagegroundedsemseg_amd.losses import fused_cross_entropy
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    coords, feats, labels = make_batch([5, 6], voxel=0.05, n_target=9000)
+    c, f = torch.from_numpy(coords).to(DEV), torch.from_numpy(feats).to(DEV).to(dtype)
+    l = torch.from_numpy(labels % 20).to(DEV)
+
+    def run(fused):
+        prev = models._BLOCK_FUSED
+        models._BLOCK_FUSED = fused
+        try:
+            m = deterministic_init(load_model(name)(3, 20, Cfg()), 7).to(DEV).train()
+            ddp = BucketedDDP(m, bucket_mb=4.0) if bucketed else None
+            out = []
+            for _ in range(2):          # second step: running statistics / packed weights of step 1 are in play
+                if ddp is not None:
+                    ddp.zero_grad()
+                else:
+                    m.zero_grad(set_to_none=True)
+                logits, feats_out = m(ME.SparseTensor(f, c))
+                loss = fused_cross_entropy(logits.F, l, ignore_index=-1)
+                loss.backward()
+                if ddp is not None:
+                    ddp.finalize()
+                torch.cuda.synchronize()
+                out.append((logits.F.detach().float().cpu(), {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters()},
+                            {k: b.detach().float().cpu().clone() for k, b in m.named_buffers()}))
+            return out
+        finally:
+            models._BLOCK_FUSED = prev
+
+    calls = []
+    orig = models._BasicBlockFunction.forward
+    a = run(False)
+    models._BasicBlockFunction.forward = staticmethod(lambda *args, **kw: (calls.append(1), orig(*args, **kw))[1])
+    try:
+        b = run(True)
+    finally:
+        models._BasicBlockFunction.forward = orig
+    assert len(calls) > 0, "the fast path was not taken"
+    for (la, ga, ba), (lb, gb, bb) in zip(a, b):
+        assert torch.equal(la, lb)
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
+        for k in ba:
+            assert torch.equal(ba[k], bb[k]), k
