@@ -80,15 +80,26 @@ def _row_strided(t, c):
 _WS = {}
 
 
-def _ws(nbytes, device):
+def _ws(nbytes, device, stream=None):
     """Scratch of one engine call: ONE grow-only buffer per (device, current stream).  Every use is confined to the launches
     of a single call, and calls on one stream run in order, so the next call may overwrite it; weight gradients on the side
     stream get their own.  (A fresh torch.empty per call cost ~7 us of allocator time, ~250 times per step.)"""
-    key = (device.index, torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch._C._cuda_getDevice()))
+    if stream is None:
+        raw_stream = torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch._C._cuda_getDevice())
+    else:
+        raw_stream = stream.cuda_stream
+    key = (device.index, raw_stream)
     t = _WS.get(key)
     nbytes = int(nbytes)
     if t is None or t.numel() < nbytes:
-        t = torch.empty(max(nbytes + nbytes // 4, 1 << 20), dtype=torch.uint8, device=device)
+        size = max(nbytes + nbytes // 4, 1 << 20)
+        if stream is None:
+            t = torch.empty(size, dtype=torch.uint8, device=device)
+        else:
+            # the buffer must belong to the allocator pool of the stream that uses it: when it is replaced by a larger one, the
+            # old block may only be handed out again in that stream's order
+            with torch.cuda.stream(stream):
+                t = torch.empty(size, dtype=torch.uint8, device=device)
         _WS[key] = t
     return t
 
@@ -265,9 +276,14 @@ class HipKernelMap:
                                           _ptr(pk), int(mode), _stream()))
         return gin
 
-    def conv_wgrad(self, x, gout, transposed, out=None):
-        """-> grad_weight [K,cin,cout] fp32; written straight into `out` (e.g. a view of a gradient bucket) if given"""
+    def conv_wgrad(self, x, gout, transposed, out=None, stream=None):
+        """-> grad_weight [K,cin,cout] fp32; written straight into `out` (e.g. a view of a gradient bucket) if given.
+        stream: enqueue on this torch stream instead of the current one (the caller has ordered it after the producers of
+        x / gout; no stream context switch on the host)"""
         L = engine.lib()
+        if stream is not None and (not gout.is_contiguous() or (not x.is_contiguous() and _row_strided(x, x.shape[1]) is None)):
+            with torch.cuda.stream(stream):         # rare: a copy is needed, make it on the target stream
+                return self.conv_wgrad(x, gout, transposed, out=out)
         gout = gout.contiguous()
         cin, cout = x.shape[1], gout.shape[1]
         # strided input (see conv_forward): only the position-stationary bf16 kernel reads it in place
@@ -275,18 +291,24 @@ class HipKernelMap:
         dt = _dtype_code(x)
         if ld is not None and not L.lgs_conv_wgrad_supports_stride(self.h, int(transposed), cin, cout, dt, int(ld)):
             ld = None      # the position-stationary kernel declines this shape: hand the pair-list kernel a contiguous copy
-        if ld is None:
+        if ld is None and not x.is_contiguous():
+            if stream is not None:
+                with torch.cuda.stream(stream):
+                    return self.conv_wgrad(x, gout, transposed, out=out)
             x = x.contiguous()
         assert gout.dtype == x.dtype
+        raw = stream.cuda_stream if stream is not None else _stream()
         with _dev(x.device):
             if out is not None:
                 assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == self.K * cin * cout
                 gw = out
             else:
                 gw = torch.empty((self.K, cin, cout), dtype=torch.float32, device=x.device)
-            ws = _ws(L.lgs_conv_workspace_bytes(self.h, cin, cout, dt, 2), x.device)
+            if out is None and stream is not None:
+                gw.record_stream(stream)
+            ws = _ws(L.lgs_conv_workspace_bytes(self.h, cin, cout, dt, 2), x.device, stream)
             engine.check(L.lgs_conv_wgrad(self.h, int(transposed), _ptr(x), cin, _ptr(gout), cout, _ptr(gw), dt, _ptr(ws),
-                                          int(ld or 0), _stream()))
+                                          int(ld or 0), raw))
         return gw
 
 
@@ -401,6 +423,8 @@ class HipBackend:
 
     def __init__(self):
         self._side = {}
+        self._cur = {}
+        self._fork = {}
 
     def new_manager(self, device):
         return HipManager(device)
@@ -413,12 +437,29 @@ class HipBackend:
         """the optimiser changed the parameters outside autograd: re-pack every cached weight image in one launch"""
         get_packed().repack_all()
 
+    def current_stream(self, device):
+        """torch.cuda.current_stream(device) without its per-call Python cost: Stream objects are cached per raw handle"""
+        idx = device.index if device.index is not None else torch._C._cuda_getDevice()
+        raw = torch._C._cuda_getCurrentRawStream(idx)
+        s = self._cur.get((idx, raw))
+        if s is None:
+            s = self._cur[(idx, raw)] = torch.cuda.current_stream(device)
+        return s
+
+    def fork_event(self, device):
+        """one reusable event per device for ordering the side stream after the compute stream (record, then wait_event)"""
+        idx = device.index if device.index is not None else torch._C._cuda_getDevice()
+        ev = self._fork.get(idx)
+        if ev is None:
+            ev = self._fork[idx] = torch.cuda.Event()
+        return ev
+
     def side_stream(self, device):
         """second HIP stream per device: weight gradients run here, concurrently with the dgrad / BN chain.
         LGS_WGRAD_CUMASK=<hex words, comma separated, least significant first> (experiment knob): create it with a CU mask
         (hipExtStreamCreateWithCUMask), so that the position-stationary weight-gradient kernel -- which owns whole CUs --
         is confined to a partition instead of evicting the compute stream's waves everywhere."""
-        key = torch.device(device).index
+        key = device.index if isinstance(device, torch.device) else torch.device(device).index
         if key not in self._side:
             mask = os.environ.get("LGS_WGRAD_CUMASK")
             if mask:

@@ -72,21 +72,22 @@ def conv_weight_grad(kmap, feats, gout, transposed, kparam, kshape, kdtype):
     if _DBG_WGRAD == "inline":
         kmap.conv_wgrad(feats, gout, transposed, out=view.view(kmap.K, -1, kshape[-1]))
         return view                                      # profiling knob: weight gradient on the compute stream
-    main = torch.cuda.current_stream(gout.device)
-    side = backend.side_stream(gout.device)
-    side.wait_stream(main)                               # feats / gout are ready
-    with torch.cuda.stream(side):
-        kmap.conv_wgrad(feats, gout, transposed, out=view.view(kmap.K, -1, kshape[-1]))
-        # one reusable event per parameter: BucketedDDP waits for exactly the weight gradients of the bucket it is about
-        # to reduce (ddp._wait_bucket_wgrads), not for the whole side stream
-        ev = getattr(kparam, "_lgs_wgrad_event", None)
-        if ev is None:
-            ev = kparam._lgs_wgrad_event = torch.cuda.Event()
-        ev.record(side)
-        _WGRAD_SEQ[0] += 1
-        kparam._lgs_wgrad_seq = _WGRAD_SEQ[0]
-        owner = getattr(kparam, "_lgs_ddp", None)
-        kparam._lgs_wgrad_step = owner._step if owner is not None else -1
+    dev = gout.device
+    side = backend.side_stream(dev)
+    fork = backend.fork_event(dev)
+    fork.record(backend.current_stream(dev))             # feats / gout are ready
+    side.wait_event(fork)
+    kmap.conv_wgrad(feats, gout, transposed, out=view.view(kmap.K, -1, kshape[-1]), stream=side)
+    # one reusable event per parameter: BucketedDDP waits for exactly the weight gradients of the bucket it is about to
+    # reduce (ddp._wait_bucket_wgrads), not for the whole side stream
+    ev = getattr(kparam, "_lgs_wgrad_event", None)
+    if ev is None:
+        ev = kparam._lgs_wgrad_event = torch.cuda.Event()
+    ev.record(side)
+    _WGRAD_SEQ[0] += 1
+    kparam._lgs_wgrad_seq = _WGRAD_SEQ[0]
+    owner = getattr(kparam, "_lgs_ddp", None)
+    kparam._lgs_wgrad_step = owner._step if owner is not None else -1
     feats.record_stream(side)
     gout.record_stream(side)
     return view                                          # consumers wait for the side stream in BucketedDDP
