@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LGS_ABI_VERSION 5
+#define LGS_ABI_VERSION 6
 
 enum lgs_dtype { LGS_F32 = 0, LGS_BF16 = 1 };
 
@@ -142,6 +142,15 @@ int lgs_conv_forward(lgs_kmap *km, int transposed, const void *in, int cin, cons
 /* grad_in[n_in,cin] from grad_out[n_out,cout] */
 int lgs_conv_dgrad(lgs_kmap *km, int transposed, const void *grad_out, int cout, const float *weight, int cin,
                    void *grad_in, int dtype, void *workspace, void *packed, int pack_mode, void *stream);
+
+/* grad_in += dgrad(grad_out): the sum autograd forms when the convolution's input also feeds a residual branch
+ * (models/modules/resnet_block.py:41-57: `out += residual`), taken in the kernel epilogue and rounded exactly like "store the
+ * dgrad, then add the two tensors".  lgs_conv_dgrad_can_accumulate() tells whether the launch shape of (km, transposed, cin,
+ * cout, dtype) has that epilogue (1) or the caller has to add the tensors itself (0); lgs_conv_dgrad_accumulate() fails
+ * for a shape that has not. */
+int lgs_conv_dgrad_can_accumulate(const lgs_kmap *km, int transposed, int cin, int cout, int dtype);
+int lgs_conv_dgrad_accumulate(lgs_kmap *km, int transposed, const void *grad_out, int cout, const float *weight, int cin,
+                              void *grad_in, int dtype, void *workspace, void *packed, int pack_mode, void *stream);
 /* grad_weight[K,cin,cout] (float32, overwritten) */
 int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const void *grad_out, int cout,
                    float *grad_weight, int dtype, void *workspace, int in_row_stride /* elements; 0 = cin */, void *stream);

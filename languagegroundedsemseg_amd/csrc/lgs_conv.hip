@@ -160,7 +160,14 @@ struct ClipEpi {
 struct BnEpi {
   float *partial = nullptr;     // [gridDim.x][2][cout_real]
   const float *pivot = nullptr; // [cout_real] or NULL
+  int accum = 0;                // 1: out += result (lgs_conv_dgrad_accumulate: the residual branch's gradient is already in `out`)
 };
+// four adjacent stored elements -> fp32 (one 8- or 16-byte access)
+__device__ inline void load4(const float *p, float (&v)[4]) { const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+__device__ inline void load4(const bf16_t *p, float (&v)[4]) {
+  const uint2 t = *reinterpret_cast<const uint2 *>(p);
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
 template <typename T> __device__ inline float stored_value(float x);
 template <> __device__ inline float stored_value<float>(float x) { return x; }
 template <> __device__ inline float stored_value<bf16_t>(float x) { return bf16_to_f32(f32_to_bf16(x)); }
@@ -635,6 +642,14 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
         float o0 = acc[rb][nb][4 * q + 0], o1 = acc[rb][nb][4 * q + 1], o2 = acc[rb][nb][4 * q + 2],
               o3 = acc[rb][nb][4 * q + 3];
         if (bias) { o0 += bias[c0]; o1 += bias[c0 + 1]; o2 += bias[c0 + 2]; o3 += bias[c0 + 3]; }
+        if constexpr (EPI == 0) {
+          if (be.accum) {   // kernel-uniform.  The sum is rounded exactly like "store the result, then add the two tensors"
+            float prev[4];
+            load4(dst + c0, prev);
+            o0 = stored_value<T>(o0) + prev[0]; o1 = stored_value<T>(o1) + prev[1];
+            o2 = stored_value<T>(o2) + prev[2]; o3 = stored_value<T>(o3) + prev[3];
+          }
+        }
         if (out_f32) {  // CLIP similarity: fp32 output, per-row scale (1/|f|)
           *reinterpret_cast<float4 *>(out_f32 + (int64_t)orow * cout_real + c0) = make_float4(o0 * rs, o1 * rs, o2 * rs, o3 * rs);
         } else if constexpr (EPL == 4) {
@@ -771,7 +786,7 @@ GatherCfg gather_cfg(const View &v, int nb_total) {
 // out = p0 + p1 + p2 (+ bias), fixed order; 4 elements per thread
 template <typename T>
 __global__ void k_sum_partials(const float *__restrict__ part, int64_t n4, int64_t zstride, const float *__restrict__ bias,
-                               int cout, T *__restrict__ out) {
+                               int cout, T *__restrict__ out, int accum) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const float4 a = reinterpret_cast<const float4 *>(part)[i];
@@ -779,6 +794,12 @@ __global__ void k_sum_partials(const float *__restrict__ part, int64_t n4, int64
   const float4 c = reinterpret_cast<const float4 *>(part + 2 * zstride)[i];
   float o0 = a.x + b.x + c.x, o1 = a.y + b.y + c.y, o2 = a.z + b.z + c.z, o3 = a.w + b.w + c.w;
   if (bias) { const int c0 = (int)((i * 4) % cout); o0 += bias[c0]; o1 += bias[c0 + 1]; o2 += bias[c0 + 2]; o3 += bias[c0 + 3]; }
+  if (accum) {
+    float prev[4];
+    load4(out + 4 * i, prev);
+    o0 = stored_value<T>(o0) + prev[0]; o1 = stored_value<T>(o1) + prev[1];
+    o2 = stored_value<T>(o2) + prev[2]; o3 = stored_value<T>(o3) + prev[3];
+  }
   if constexpr (sizeof(T) == 4) {
     reinterpret_cast<float4 *>(out)[i] = make_float4(o0, o1, o2, o3);
   } else {
@@ -795,6 +816,10 @@ inline int64_t split_partial_bytes(int K, int64_t n_out, int o_real) {
   const int64_t b = 3 * n_out * (int64_t)o_real * 4;
   return b <= kSplitMaxBytes ? align256(b) : 0;
 }
+
+// epilogue options of one launch: a slot-split launch writes fp32 partial images (statistics / accumulation happen in
+// k_sum_partials or not at all)
+inline BnEpi bn_epi(const BnEpi *bn, bool did_split) { return (bn && !did_split) ? *bn : BnEpi(); }
 
 template <typename T>
 int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real, int nc, const uint4 *wp,
@@ -827,11 +852,12 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
     hipLaunchKernelGGL((k_conv_gather<T, RB, NCB, WM, WN, SC, D>), grid, dim3(WM *WN * 64), 0, s, v, in, cin_real, nc,    \
                        reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, out, cout_real, did_split ? nullptr : bias, \
                        did_split ? zpartial : out_f32, row_scale, in_bytes, w_bytes, zstride, ClipEpi(),           \
-                       (bn && !did_split) ? *bn : BnEpi(), gc, in_ld > 0 ? in_ld : cin_real);                     \
+                       bn_epi(bn, did_split), gc, in_ld > 0 ? in_ld : cin_real);                                  \
     if (bn_rows) *bn_rows = did_split ? 0 : (int)grid.x;                                                          \
   } while (0)
   if (cfg.id == 17) {
     LGS_REQUIRE(sizeof(T) == 2 && !out_f32 && !row_scale && !(bn && bn->partial), "wide conv: bf16 feature output only (internal error)");
+    LGS_REQUIRE(!(bn && bn->accum), "wide conv: no accumulating epilogue (lgs_conv_dgrad_can_accumulate says so)");
     if (bn_rows) *bn_rows = 0;
     return launch_conv_wide(v, in, cin_real, in_ld > 0 ? in_ld : cin_real, wp, nb_total, ncp, nbp, K, out, cout_real, bias,
                             gc >= nc ? 0 : (gc + 1) / 2, s);
@@ -864,7 +890,8 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
 #undef LGS_LAUNCH
   if (did_split) {
     const int64_t n4 = zstride / 4;
-    if (n4 > 0) hipLaunchKernelGGL((k_sum_partials<T>), (unsigned)((n4 + 255) / 256), 256, 0, s, zpartial, n4, zstride, bias, cout_real, out);
+    if (n4 > 0) hipLaunchKernelGGL((k_sum_partials<T>), (unsigned)((n4 + 255) / 256), 256, 0, s, zpartial, n4, zstride, bias, cout_real, out,
+                                   (bn && bn->accum) ? 1 : 0);
   }
   LGS_HIP(hipGetLastError());
   return 0;
@@ -1147,6 +1174,33 @@ int lgs_conv_dgrad(lgs_kmap *km, int transposed, const void *grad_out, int cout,
   if (dtype == LGS_F32) return conv_gather_op<float>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, nullptr, packed, pack_mode);
   if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, nullptr, packed, pack_mode);
   LGS_REQUIRE(false, "lgs_conv_dgrad: unknown dtype");
+}
+
+// 1 if lgs_conv_dgrad_accumulate adds inside the kernel epilogue for this launch shape (everything but the 2-D blocked wide
+// kernel and input widths off the 4-channel grid)
+int lgs_conv_dgrad_can_accumulate(const lgs_kmap *km, int transposed, int cin, int cout, int dtype) {
+  if (!km || (transposed && km->ks == 3) || cin % 4 != 0 || (dtype != LGS_F32 && dtype != LGS_BF16)) return 0;
+  const View &v = transposed ? km->fwd : km->bwd;
+  if (v.n_pad == 0) return 0;
+  (void)cout;
+  const int nb_total = pad32(cin) / 32;
+  const int id = dtype == LGS_F32 ? gather_cfg<float>(v, nb_total).id : gather_cfg<bf16_t>(v, nb_total).id;
+  return id == 17 ? 0 : 1;
+}
+
+// grad_in += dgrad(grad_out): the sum autograd would form when the convolution's input also feeds a residual branch, taken
+// in the epilogue (rounded exactly like "store dgrad, then add"), instead of a separate elementwise pass over [N, cin]
+int lgs_conv_dgrad_accumulate(lgs_kmap *km, int transposed, const void *grad_out, int cout, const float *weight, int cin,
+                              void *grad_in, int dtype, void *workspace, void *packed, int pack_mode, void *stream) {
+  LGS_REQUIRE(km && weight && workspace && grad_in, "lgs_conv_dgrad_accumulate: null argument");
+  LGS_REQUIRE(lgs_conv_dgrad_can_accumulate(km, transposed, cin, cout, dtype), "lgs_conv_dgrad_accumulate: this launch shape has no accumulating epilogue (ask lgs_conv_dgrad_can_accumulate first)");
+  const View &v = transposed ? km->fwd : km->bwd;
+  View vv = v; vv.mirror = (km->ks == 3) ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (kmap_wait(km, s)) return 1;
+  BnEpi acc; acc.accum = 1;
+  if (dtype == LGS_F32) return conv_gather_op<float>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, &acc, packed, pack_mode);
+  return conv_gather_op<bf16_t>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, &acc, packed, pack_mode);
 }
 
 }  // extern "C"

@@ -10,7 +10,7 @@ import os
 from . import build as _build
 
 LGS_F32, LGS_BF16 = 0, 1
-ABI_VERSION = 5     # LGS_ABI_VERSION of include/lgs_engine.h
+ABI_VERSION = 6     # LGS_ABI_VERSION of include/lgs_engine.h
 
 
 class PackDesc(ctypes.Structure):
@@ -29,7 +29,7 @@ EXPORTS = [
     "lgs_manager_parent_of", "lgs_manager_map_size", "lgs_manager_get_coords", "lgs_manager_kernel_map",
     "lgs_kmap_export",
     "lgs_conv_workspace_bytes", "lgs_conv_bn_partial_rows", "lgs_conv_forward", "lgs_conv_dgrad", "lgs_conv_wgrad",
-    "lgs_conv_wgrad_supports_stride",
+    "lgs_conv_wgrad_supports_stride", "lgs_conv_dgrad_can_accumulate", "lgs_conv_dgrad_accumulate",
     "lgs_conv_pack_desc", "lgs_pack_weights_batch",
     "lgs_bn_workspace_bytes", "lgs_bn_forward", "lgs_bn_backward",
     "lgs_bn_stats", "lgs_bn_sync_combine", "lgs_bn_apply", "lgs_bn_backward_reduce", "lgs_bn_backward_apply",
@@ -83,6 +83,8 @@ def lib():
         "lgs_label_vote": [vp, i64, vp, vp, i64, i64, vp, vp],
         "lgs_conv_wgrad": [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp],
         "lgs_conv_wgrad_supports_stride": [vp, ci, ci, ci, ci, ci],
+        "lgs_conv_dgrad_can_accumulate": [vp, ci, ci, ci, ci],
+        "lgs_conv_dgrad_accumulate": [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, vp],
         "lgs_bn_forward": [vp, i64, ci, vp, vp, cf, cf, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, vp, i64, vp],
         "lgs_bn_backward": [vp, vp, vp, i64, i64, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, i64, vp],
         "lgs_bn_stats": [vp, i64, ci, vp, ci, vp, vp, ci, vp, vp],

@@ -260,7 +260,10 @@ class HipKernelMap:
             return out, ((part, piv) if part is not None else None)
         return out
 
-    def conv_dgrad(self, gout, weight, transposed, pack_cache=None):
+    def conv_dgrad(self, gout, weight, transposed, pack_cache=None, accumulate_into=None):
+        """accumulate_into: a caller-owned contiguous [n_in, cin] tensor t (the gradient of a residual branch); the result is
+        t += dgrad, rounded like "dgrad, then add", formed in the kernel epilogue where the launch shape has one
+        (lgs_conv_dgrad_accumulate; t itself is returned) and by an add into the fresh dgrad tensor otherwise."""
         L = engine.lib()
         gout = gout.contiguous()
         w = weight.detach().reshape(self.K, -1, weight.shape[-1]).contiguous().float()
@@ -268,12 +271,17 @@ class HipKernelMap:
         n_in, n_out = self._rows(transposed)
         assert gout.shape[0] == n_out and gout.shape[1] == cout
         dt = _dtype_code(gout)
+        acc = accumulate_into
+        fuse = (acc is not None and acc.is_contiguous() and acc.dtype == gout.dtype and tuple(acc.shape) == (n_in, cin)
+                and L.lgs_conv_dgrad_can_accumulate(self.h, int(transposed), cin, cout, dt))
         with _dev(gout.device):
-            gin = torch.empty((n_in, cin), dtype=gout.dtype, device=gout.device)
+            gin = acc if fuse else torch.empty((n_in, cin), dtype=gout.dtype, device=gout.device)
             ws = _ws(L.lgs_conv_workspace_bytes(self.h, cin, cout, dt, 1), gout.device)
             pk, mode = get_packed().lookup(pack_cache, self, 1, transposed, weight, w, cin, cout, dt)
-            engine.check(L.lgs_conv_dgrad(self.h, int(transposed), _ptr(gout), cout, _ptr(w), cin, _ptr(gin), dt, _ptr(ws),
-                                          _ptr(pk), int(mode), _stream()))
+            fn = L.lgs_conv_dgrad_accumulate if fuse else L.lgs_conv_dgrad
+            engine.check(fn(self.h, int(transposed), _ptr(gout), cout, _ptr(w), cin, _ptr(gin), dt, _ptr(ws), _ptr(pk), int(mode), _stream()))
+            if acc is not None and not fuse:
+                gin += acc
         return gin
 
     def conv_wgrad(self, x, gout, transposed, out=None, stream=None):

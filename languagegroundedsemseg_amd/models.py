@@ -58,7 +58,8 @@ class BasicBlock(nn.Module):
 #   forward   conv1 -> norm1+ReLU -> conv2 -> [downsample conv 1x1
 #             -> its norm] -> norm2 + residual (+ ReLU)
 #   backward  norm2 -> {wgrad2 on the side stream, dgrad2} -> norm1 -> {wgrad1, dgrad1} [-> downsample norm -> {wgrad, dgrad}]
-#             -> ONE in-place add of the residual branch's gradient (autograd's accumulation of the two branches, same rounding)
+#             with the residual branch's gradient added in dgrad1's epilogue (lgs_conv_dgrad_accumulate: autograd's
+#             accumulation of the two branches, same rounding, without the elementwise pass)
 # It is taken only when every module of the block is a plain training-mode MinkowskiConvolution / MinkowskiBatchNorm on the
 # HIP backend with no hooks attached (the layer-wise parity tests hook the modules and so run the op-by-op path);
 # LGS_BLOCK_FUSED=0 turns it off.
@@ -185,12 +186,11 @@ class _BasicBlockFunction(torch.autograd.Function):
             dxd, _, dgd, dbd = _bn_bwd(be, od, None, dres, gd, bd, pgd, pbd, std, 0, False, need[11] or need[12])
             gwd = conv_weight_grad(ctx.kmap1, x, dxd, False, pwd, wd.shape, wd.dtype) if need[10] else None
             if need[0]:
-                gin = kmap3.conv_dgrad(dx1, w1, False, pack_cache=pc1)
-                gin += ctx.kmap1.conv_dgrad(dxd, wd, False, pack_cache=pcd)
+                gin = kmap3.conv_dgrad(dx1, w1, False, pack_cache=pc1,
+                                       accumulate_into=ctx.kmap1.conv_dgrad(dxd, wd, False, pack_cache=pcd))
             return gin, None, None, None, gw1, dg1, db1, gw2, dg2, db2, gwd, dgd, dbd
         if need[0]:
-            gin = kmap3.conv_dgrad(dx1, w1, False, pack_cache=pc1)
-            gin += dres
+            gin = kmap3.conv_dgrad(dx1, w1, False, pack_cache=pc1, accumulate_into=dres)
         return gin, None, None, None, gw1, dg1, db1, gw2, dg2, db2
 
 

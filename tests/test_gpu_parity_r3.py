@@ -340,3 +340,33 @@ def test_block_fast_path_is_the_op_by_op_path(name, dtype, bucketed):
             assert torch.equal(ga[k], gb[k]), k
         for k in ba:
             assert torch.equal(ba[k], bb[k]), k
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("cin,cout,ks,n_target,voxel", [(32, 32, 3, 9000, 0.05), (96, 96, 3, 80000, 0.02), (64, 128, 1, 9000, 0.05),
+                                                         (256, 256, 3, 3000, 0.1), (512, 512, 3, 80000, 0.02)])
+def test_dgrad_accumulate_is_dgrad_then_add(dtype, cin, cout, ks, n_target, voxel):
+    """lgs_conv_dgrad_accumulate (t += dgrad in the kernel epilogue) must give, BIT FOR BIT, what the two-step form gives
+    (store dgrad in the feature dtype, then add): every tile configuration incl. the slot-split small maps; shapes without the
+    epilogue (the 2-D blocked wide kernel: 512 -> 512 on a large map) take the add inside HipKernelMap.conv_dgrad"""
+    from languagegroundedsemseg_amd import engine
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    if dtype == torch.float32 and cin >= 256:
+        pytest.skip("wide shapes are bf16 shapes")
+    coords, _, _ = make_batch([4], voxel=voxel, n_target=n_target)
+    c = torch.from_numpy(coords).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    x = ME.SparseTensor(torch.randn(coords.shape[0], cin, generator=g).to(DEV).to(dtype), c)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=ks, stride=1, dimension=3).to(DEV)
+    mgr, key = x.coordinate_manager, x.coordinate_map_key
+    kmap = mgr.kernel_map_handle(key, key, ks)
+    gout = torch.randn(coords.shape[0], cout, generator=g).to(DEV).to(dtype)
+    t = torch.randn(coords.shape[0], cin, generator=g).to(DEV).to(dtype)
+    two_step = kmap.conv_dgrad(gout, conv.kernel, False) + t
+    can = engine.lib().lgs_conv_dgrad_can_accumulate(kmap.h, 0, cin, cout, engine.LGS_BF16 if dtype == torch.bfloat16 else engine.LGS_F32)
+    assert can == (0 if (cin >= 512 and n_target >= 80000) else 1)
+    t2 = t.clone()
+    fused = kmap.conv_dgrad(gout, conv.kernel, False, accumulate_into=t2)
+    assert (fused.data_ptr() == t2.data_ptr()) == bool(can)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, two_step)
