@@ -384,13 +384,16 @@ inline int reduce_blocks(int64_t n, int64_t *rows_per_block) {
 // ------------------------------------------------------------------------------------------------ one launch per direction
 // A BatchNorm direction is three dependent steps (column sums over all rows -> fold + finish the statistics -> elementwise
 // apply): three launches per direction made 372 of the compute stream's 596 launches per training step, most of them on
-// coarse levels where a launch is a few microseconds of work.  The fused kernels run the three steps in ONE launch of <= 512
+// coarse levels where a launch is a few microseconds of work.  The fused kernels run the three steps in ONE launch of <= 256
 // co-resident workgroups separated by two grid-wide barriers (arrive = agent-scope add on a counter, wait = spin on
 // it); a workgroup applies to the SAME slab of rows it reduced, walking it backwards, so the rows it read last in step 1 are
 // the first it needs in step 3 (L2 / Infinity Cache hits instead of a second HBM pass on the large levels).
-// Co-residency: 512 workgroups x 256 threads at <= 128 VGPRs is half of what the chip holds (256 CUs x 4), so two such kernels
-// from different streams / processes can spin at the same time without starving each other's unscheduled workgroups.
-constexpr int kFusedMaxBlocks = 512;
+// Co-residency: 256 workgroups x 256 threads at <= 128 VGPRs is a quarter of what the chip holds (256 CUs x 4), so such kernels
+// from different streams / processes can spin at the same time without starving each other's unscheduled workgroups.  The cap
+// is 256 and not 512 because the weight-gradient kernel on the side stream owns whole CUs (all registers, all LDS) for up to a
+// millisecond: every workgroup of a barrier kernel has to find a free CU before ANY of them gets past the first barrier
+// (measured in the 8-scene step, layers <= 24 MB fused: 30.9 ms with 512 workgroups, 29.8 ms with 256, 30.0 ms unfused).
+constexpr int kFusedMaxBlocks = 256;
 
 // Values that cross workgroups inside a fused kernel (scratch rows, statistics) are written and read with agent-scope
 // accesses (sc1: coherent across the eight XCDs' L2s) instead of fencing: a release / acquire fence at agent scope writes back
@@ -703,8 +706,10 @@ inline bool bn_fused_on(int64_t tensor_bytes) {
   return on && tensor_bytes <= (max_mb << 20);
 }
 inline int fused_blocks(int64_t n, int64_t *rows_per_block) {
+  static const int cap_env = getenv("LGS_BN_FUSED_BLOCKS") ? atoi(getenv("LGS_BN_FUSED_BLOCKS")) : 0;   // tuning knob
+  const int cap = cap_env > 0 && cap_env < kFusedMaxBlocks ? cap_env : kFusedMaxBlocks;
   int64_t nb = (n + 127) / 128;
-  if (nb > kFusedMaxBlocks) nb = kFusedMaxBlocks;
+  if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
   int64_t rpb = (n + nb - 1) / nb;
   if (rpb < 1) rpb = 1;
