@@ -278,10 +278,10 @@ def cpu_baseline(seconds_budget=30.0, model_name="Res16UNet34C", voxels=150000):
 
 def pmc_traffic(dom_key, args):
     """HBM bytes per launch of the dominant kernel.  STATIC: read from the committed PMC passes of this round
-    (profiles/r02_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected with rocprofv3 --pmc in separate passes, read side
+    (profiles/rNN_pmc_traffic.json, newest round first: FETCH_SIZE / WRITE_SIZE collected with rocprofv3 --pmc in separate passes, read side
     doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for the default workload they were collected on, null
     otherwise.  It is not measured inside this run (PMC collection needs the profiler)."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
