@@ -109,9 +109,10 @@ class ConvLog:
                     return orig(self, *a, **k)
                 M = n_pairs(self) if log.mode == "all" else log.M_of.get(key, 0)
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
+                st = k.get("stream")          # weight gradients are enqueued on the side stream explicitly
+                s.record(st) if st is not None else s.record()
                 out = orig(self, *a, **k)
-                e.record()
+                e.record(st) if st is not None else e.record()
                 log.rows.append(dict(kind=kind, M=M, n_out=n_out, cin=cin, cout=cout, K=self.K, ev=(s, e),
                                      e=a[0].element_size(), key=key))
                 return out
