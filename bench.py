@@ -555,6 +555,10 @@ def main():
         raise RuntimeError("bench.py needs an MI355X (the engine has no CPU fallback)")
     if args.same_device:
         local_rank = 0
+        # ranks sharing ONE GPU (dry run of the N > 1 logic only): the grid-barrier BatchNorm kernels assume that all their
+        # workgroups become resident promptly, which another process filling the same CUs does not allow (measured: 697 ms per
+        # step with --sync-bn 0); the three-launch path has no such assumption
+        os.environ.setdefault("LGS_BN_FUSED", "0")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:

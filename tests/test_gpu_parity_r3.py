@@ -62,22 +62,31 @@ def _trajectory(device, dtype, coords, feats, labels, steps, product_optimizer):
     return np.array(losses)
 
 
+TRAJ_SCENE = dict(seeds=[3], voxel=0.05, n_target=12000)
+
+
 def test_bf16_storage_trains_like_fp32_over_30_steps():
     """evidence that the HEADLINE dtype (bf16 feature storage, fp32 masters / accumulation / BN statistics) optimises the
     same objective: HIP fp32 follows the fp32 oracle step for step, HIP bf16 stays inside a band around them and reaches
     the same loss level"""
     from languagegroundedsemseg_amd.synthetic import make_batch
     from test_gpu_parity_r2 import structured_labels
-    coords, feats, _ = make_batch([3], voxel=0.05, n_target=12000)
+    coords, feats, _ = make_batch(**TRAJ_SCENE)
     labels = structured_labels(coords)
     steps = 30
     h32 = _trajectory(DEV, torch.float32, coords, feats, labels, steps, True)
     h16 = _trajectory(DEV, torch.bfloat16, coords, feats, labels, steps, True)
+    # the oracle's 30-step curve is recorded (tests/golden/make_trajectory.py: ~5 min of CPU); its first 3 steps are re-run
+    # live and must reproduce the record -- same scene, same weights, same oracle
+    rec = np.load(os.path.join(G, "trajectory_14a.npz"))
+    o32 = rec["oracle_fp32"]
+    assert int(rec["voxels"]) == coords.shape[0] and o32.shape[0] == steps
     prev = ME.set_backend(OracleBackend("torch"))
     try:
-        o32 = _trajectory("cpu", torch.float32, coords, feats, labels, steps, False)
+        live = _trajectory("cpu", torch.float32, coords, feats, labels, 3, False)
     finally:
         ME.set_backend(prev)
+    assert np.abs(live - o32[:3]).max() < 1e-4 * o32[0], (live, o32[:3])
     np.set_printoptions(precision=4, linewidth=200)
     print("oracle fp32:", o32)
     print("HIP    fp32:", h32)
