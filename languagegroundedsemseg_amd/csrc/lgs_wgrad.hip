@@ -922,7 +922,13 @@ inline PsPlan ps_plan(const View &v, int cg, int cs) {
   // 85 lanes would put 33 workgroups on five of the XCDs and the 33rd runs alone in a second round (measured 2x).
   const int lds_wg = 2 * kPsChunk * tile_stride(32 * p.ncs) + (v.K == 27 ? 5 * ps_wave_lds(3) + 3 * ps_wave_lds(4) : 8 * ps_wave_lds(1));
   const int wg_per_cu = v.K == 27 ? 1 : (2 * lds_wg <= 160 * 1024 ? 2 : 1);
-  const int per_xcd = 32 * wg_per_cu, n_sl = p.n_cg * p.n_cs;
+  // CUs per XCD the kernel fills: 20 of 32 (LGS_PS_CUS: tuning knob).  A workgroup owns its CU (all registers, all LDS) for the
+  // whole launch, and the kernel runs next to the dgrad / BatchNorm chain of the compute stream: with every CU taken, each
+  // compute-stream kernel waits for weight-gradient workgroups to retire before it gets anywhere.  Leaving 12 CUs per XCD makes
+  // the weight gradients ~1.3 x longer on their own stream (which has the slack) and the 8-scene step 0.7 ms shorter
+  // (32: 29.97, 28: 29.6, 24: 29.4, 20: 29.27, 16: 29.36 ms; `finalize`, the side stream's tail, stays 0.40 ms down to 20)
+  static const int cus_env = getenv("LGS_PS_CUS") ? atoi(getenv("LGS_PS_CUS")) : 20;
+  const int per_xcd = (cus_env >= 4 && cus_env <= 32 ? cus_env : 32) * wg_per_cu, n_sl = p.n_cg * p.n_cs;
   p.xcd_map = n_sl <= per_xcd ? 1 : 0;
   int lanes = p.xcd_map ? 8 * (per_xcd / n_sl) : (8 * per_xcd) / n_sl;
   if (lanes < 1) lanes = 1;

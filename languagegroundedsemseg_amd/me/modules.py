@@ -395,8 +395,15 @@ class MinkowskiBatchNorm(nn.Module):
             return out
         elif hasattr(backend, "bn_apply") and bn.affine and bn.track_running_stats and x.is_cuda:
             # eval mode on the engine too (inference / validation passes, BN frozen during fine-tuning)
-            with torch.no_grad():
-                stats = torch.cat([bn.running_mean.float(), torch.rsqrt(bn.running_var.float() + bn.eps)])
+            # [running_mean | 1/sqrt(running_var + eps)], rebuilt only when the running statistics were written (a frozen trunk
+            # otherwise launches three tiny torch kernels per norm and step: 186 launches for Res16UNet34C)
+            key = (bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.eps)
+            cached = getattr(self, "_eval_stats", None)
+            if cached is None or cached[0] != key or cached[1].device != x.device:
+                with torch.no_grad():
+                    stats = torch.cat([bn.running_mean.float(), torch.rsqrt(bn.running_var.float() + bn.eps)])
+                self._eval_stats = cached = (key, stats)
+            stats = cached[1]
             y = EvalBatchNormFunction.apply(x, bn.weight, bn.bias, res, stats, relu, backend)
         else:   # CPU oracle backend of the tests / norms without affine parameters
             y = bn(x.float()).to(x.dtype) if x.dtype != torch.float32 else bn(x)
