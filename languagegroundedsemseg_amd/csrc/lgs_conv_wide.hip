@@ -81,10 +81,11 @@ struct WideIter {
   }
 };
 
+template <bool TRACE>
 __global__ __launch_bounds__(512, 2) void k_conv_wide(View v, const bf16_t *__restrict__ in, int cin_real, int nc64,
                                                        const u32x4 *__restrict__ wp, int nb_total, int ncp, int nbp,
                                                        bf16_t *__restrict__ out, int cout_real, const float *__restrict__ bias,
-                                                       unsigned in_bytes, unsigned w_bytes, int in_ld, int gc64, int ny, int dbg,
+                                                       unsigned in_bytes, unsigned w_bytes, int in_ld, int gc64, int ny, int dbg_arg,
                                                        unsigned long long *trace) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -339,7 +340,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_wide(View v, const bf16_t *__re
   // LGS_WIDE_TRACE=1 (debug): shader-clock stamps of one workgroup's waves 0 and 4, summed over the stages:
   // [0] wait for own DMA  [1] barrier  [2] first half (wm 0: weight DMA + blocks 0, 1;  wm 1: blocks 0, 1)
   // [3] second half (wm 0: blocks 2, 3;  wm 1: gathers + blocks 2, 3)  [4] stages  [5] active blocks
-  const bool tr = trace != nullptr && blockIdx.x == 8 * 40 && (wave == 0 || wave == 4);
+  // TRACE is a template parameter: five wave-uniform `if (tr)` tests per stage are ~10 scalar instructions per wave on the CU's
+  // shared scalar unit, which the stage loop is short of (SQ_INSTS_SALU 172 M vs SQ_INSTS_MFMA 69 M per launch)
+  const int dbg = TRACE ? dbg_arg : 0;          // knock-out / trace builds only: the production instance has no such tests
+  const bool tr = TRACE && trace != nullptr && blockIdx.x == 8 * 40 && (wave == 0 || wave == 4);
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
   while (have) {
     const bool more = it.next();                                   // `it` now names stage s+1
@@ -436,7 +440,8 @@ int launch_conv_wide(const View &v, const void *in, int cin_real, int in_ld, con
               "sparse conv: a feature or weight tensor of 4 GiB or more is beyond the 32-bit buffer-descriptor path");
   static bool attr_set = false;
   if (!attr_set) {
-    LGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wide), hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds));
+    LGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wide<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds));
+    LGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds));
     attr_set = true;
   }
   const int nc64 = (cin_real + 63) / 64, ny = nbp / 8;
@@ -453,9 +458,14 @@ int launch_conv_wide(const View &v, const void *in, int cin_real, int in_ld, con
   static unsigned long long *trace = nullptr;
   if (want_trace && !trace) { LGS_HIP(hipMalloc(&trace, 12 * sizeof(unsigned long long))); }
   if (want_trace) LGS_HIP(hipMemsetAsync(trace, 0, 12 * sizeof(unsigned long long), s));
-  hipLaunchKernelGGL(k_conv_wide, dim3(nwg), dim3(512), kWideLds, s, v, reinterpret_cast<const bf16_t *>(in), cin_real, nc64,
-                     reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, reinterpret_cast<bf16_t *>(out), cout_real, bias,
-                     (unsigned)in_bytes64, (unsigned)w_bytes64, ld, gc64 > 0 ? gc64 : nc64, ny, dbg, trace);
+  if (want_trace || dbg != 0)
+    hipLaunchKernelGGL(k_conv_wide<true>, dim3(nwg), dim3(512), kWideLds, s, v, reinterpret_cast<const bf16_t *>(in), cin_real, nc64,
+                       reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, reinterpret_cast<bf16_t *>(out), cout_real, bias,
+                       (unsigned)in_bytes64, (unsigned)w_bytes64, ld, gc64 > 0 ? gc64 : nc64, ny, dbg, trace);
+  else
+    hipLaunchKernelGGL(k_conv_wide<false>, dim3(nwg), dim3(512), kWideLds, s, v, reinterpret_cast<const bf16_t *>(in), cin_real, nc64,
+                       reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, reinterpret_cast<bf16_t *>(out), cout_real, bias,
+                       (unsigned)in_bytes64, (unsigned)w_bytes64, ld, gc64 > 0 ? gc64 : nc64, ny, dbg, trace);
   LGS_HIP(hipGetLastError());
   if (want_trace) {
     unsigned long long h[12];
