@@ -132,7 +132,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_wide(View v, const bf16_t *__re
   }
   smask = __builtin_amdgcn_readfirstlane(smask);
   kw_single = __builtin_amdgcn_readfirstlane(kw_single);
-  int32_t *l_idx = reinterpret_cast<int32_t *>(smem + kWideIdxOff);
+  // the kernel-map rows are kept in LDS as BYTE OFFSETS of the gathered rows (row * row stride; 0xfffff000 = no neighbour: any
+  // offset built on it is out of the buffer's range and reads zeros), computed once per tile instead of once per stage
+  constexpr unsigned kNoRow = 0xfffff000u;
+  const unsigned row_bytes_p = (unsigned)in_ld * 2u;
+  uint32_t *l_idx = reinterpret_cast<uint32_t *>(smem + kWideIdxOff);
   unsigned char *l_act = reinterpret_cast<unsigned char *>(smem + kWideActOff);
   {
     const int r = tid & (kWideTM - 1), par = tid >> 8;        // threads 0..255: even offsets, 256..511: odd offsets
@@ -146,11 +150,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_wide(View v, const bf16_t *__re
 #pragma unroll
       for (int i = 0; i < 14; ++i) {
         const int sl = 2 * i + par;
-        if (sl < 27 && ((smask >> sl) & 1u)) l_idx[sl * kWideTM + r] = tmp[i];
+        if (sl < 27 && ((smask >> sl) & 1u)) l_idx[sl * kWideTM + r] = tmp[i] >= 0 ? (uint32_t)tmp[i] * row_bytes_p : kNoRow;
       }
     } else if (par == 0) {
       const int64_t p = pos_wg + r;
-      l_idx[r] = p < v.n_in ? (int32_t)p : -1;
+      l_idx[r] = p < v.n_in ? (uint32_t)p * row_bytes_p : kNoRow;
     }
   }
   __syncthreads();
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wide(View v, const bf16_t *__re
 #pragma unroll 1
   for (int s2 = 0; s2 < 28; s2 += 2) {
     const int sl = s2 + h;
-    const bool ok = sl < 27 && ((smask >> sl) & 1u) && l_idx[sl * kWideTM + wave * 32 + vx] >= 0;
+    const bool ok = sl < 27 && ((smask >> sl) & 1u) && l_idx[sl * kWideTM + wave * 32 + vx] != kNoRow;
     const uint64_t b = __ballot(ok);
     if (lane == 0) {
       l_act[s2 * 8 + wave] = (b & 0xffffffffull) != 0ull;
@@ -190,7 +194,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_wide(View v, const bf16_t *__re
   constexpr unsigned kOOB = 0xfffff000u;
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(in), 0, (int)in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(wp), 0, (int)w_bytes, 0x00020000);
-  const unsigned row_bytes = (unsigned)in_ld * 2u;
 
   // ---- DMA side.  ROLES: the two waves of a SIMD (w, w + 4: wm = 0 / 1) run complementary schedules, so that one of them
   // multiplies while the other sits in the vector-memory issue queue (every wave issuing its DMA right behind the barrier and
@@ -221,19 +224,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_wide(View v, const bf16_t *__re
   auto issue_a = [&](int slot, uint32_t st, int c64, int buf) __attribute__((always_inline)) {
     char *adst = smem + kWideAOff + buf * kWideA + wq * 8192;
     const unsigned cb = (unsigned)(c64 * 128), lim = (unsigned)cin_real * 2u;
+    // pieces beyond the row's channels (the last 64-channel stage of e.g. 544 channels) must read zeros, not the next row
+    const unsigned c0 = cb + g_src0, c1 = cb + g_src1;
+    const bool ok0 = c0 + 16u <= lim, ok1 = c1 + 16u <= lim;
     const unsigned ird = idx_rd + (unsigned)(slot * kWideTM * 4);
 #define LGS_WIDE_GATHER4(JJ0)                                                                                               \
     {                                                                                                                       \
-      int32_t r0, r1, r2, r3;                                                                                               \
+      uint32_t r0, r1, r2, r3;                                                                                              \
       asm volatile("ds_read_b32 %0, %4 offset:%5\n\tds_read_b32 %1, %4 offset:%6\n\tds_read_b32 %2, %4 offset:%7\n\t"      \
                    "ds_read_b32 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"                                                   \
                    : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)                                                             \
                    : "v"(ird), "n"((JJ0) * 32), "n"((JJ0) * 32 + 32), "n"((JJ0) * 32 + 64), "n"((JJ0) * 32 + 96) : "memory"); \
-      const unsigned c0 = cb + g_src0, c1 = cb + g_src1;                                                                    \
-      const unsigned o0 = (r0 >= 0 && c0 + 16u <= lim) ? (unsigned)r0 * row_bytes + c0 : kOOB;                              \
-      const unsigned o1 = (r1 >= 0 && c1 + 16u <= lim) ? (unsigned)r1 * row_bytes + c1 : kOOB;                              \
-      const unsigned o2 = (r2 >= 0 && c0 + 16u <= lim) ? (unsigned)r2 * row_bytes + c0 : kOOB;                              \
-      const unsigned o3 = (r3 >= 0 && c1 + 16u <= lim) ? (unsigned)r3 * row_bytes + c1 : kOOB;                              \
+      const unsigned o0 = ok0 ? r0 + c0 : kOOB, o1 = ok1 ? r1 + c1 : kOOB, o2 = ok0 ? r2 + c0 : kOOB, o3 = ok1 ? r3 + c1 : kOOB;   \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, LGS_AS3(adst + (JJ0) * 1024), 16, o0, 0, 0, 0);                       \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, LGS_AS3(adst + (JJ0) * 1024 + 1024), 16, o1, 0, 0, 0);                \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, LGS_AS3(adst + (JJ0) * 1024 + 2048), 16, o2, 0, 0, 0);                \
