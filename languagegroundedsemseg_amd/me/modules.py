@@ -69,9 +69,10 @@ def conv_weight_grad(kmap, feats, gout, transposed, kparam, kshape, kdtype):
         return kmap.conv_wgrad(feats, gout, transposed).reshape(kshape).to(kdtype)
     if _DBG_WGRAD == "skip":
         return view                                      # profiling knob: no weight gradient at all
-    if _DBG_WGRAD == "inline":
+    if _DBG_WGRAD == "inline" or getattr(kmap.mgr, "inline_wgrad", False):
+        # small (host-bound) batches, or the profiling knob: weight gradient on the compute stream
         kmap.conv_wgrad(feats, gout, transposed, out=view.view(kmap.K, -1, kshape[-1]))
-        return view                                      # profiling knob: weight gradient on the compute stream
+        return view
     dev = gout.device
     side = backend.side_stream(dev)
     fork = backend.fork_event(dev)

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# the tests' scenes are small: keep their weight gradients on the SIDE stream (the path the 8-scene batch takes: fork / join
+# events, bucket-slot events of BucketedDDP) instead of the small-batch inline path; test_small_batches_inline_their_weight_gradients
+# covers the latter
+os.environ.setdefault("LGS_WGRAD_INLINE_BELOW", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -379,3 +379,32 @@ def test_dgrad_accumulate_is_dgrad_then_add(dtype, cin, cout, ks, n_target, voxe
     assert (fused.data_ptr() == t2.data_ptr()) == bool(can)
     torch.cuda.synchronize()
     assert torch.equal(fused, two_step)
+
+
+def test_small_batches_inline_their_weight_gradients(monkeypatch):
+    """batches below LGS_WGRAD_INLINE_BELOW input voxels run their weight gradients on the compute stream (host-bound regime);
+    the result must be the side-stream result bit for bit, through BucketedDDP's bucket slots"""
+    from languagegroundedsemseg_amd.ddp import BucketedDDP
+    from languagegroundedsemseg_amd.losses import fused_cross_entropy
+    from languagegroundedsemseg_amd.me import backend_hip
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    coords, feats, labels = make_batch([8], voxel=0.05, n_target=9000)
+    c, f = torch.from_numpy(coords).to(DEV), torch.from_numpy(feats).to(DEV).bfloat16()
+    l = torch.from_numpy(labels % 20).to(DEV)
+
+    def run(below):
+        monkeypatch.setattr(backend_hip, "_WGRAD_INLINE_BELOW", below)
+        m = deterministic_init(load_model("Res16UNet14A")(3, 20, Cfg()), 11).to(DEV).train()
+        ddp = BucketedDDP(m, bucket_mb=1.0)
+        ddp.zero_grad()
+        x = ME.SparseTensor(f, c)
+        assert x.coordinate_manager._m.inline_wgrad == (coords.shape[0] < below)
+        logits, _ = m(x)
+        fused_cross_entropy(logits.F, l, ignore_index=-1).backward()
+        ddp.finalize()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters()}
+
+    side, inline = run(0), run(1 << 30)
+    for k in side:
+        assert torch.equal(side[k], inline[k]), k
