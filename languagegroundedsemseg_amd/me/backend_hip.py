@@ -433,7 +433,11 @@ class HipBackend:
     # lgs_bn_forward can write its output into a column slice of a wider buffer (zero-copy ME.cat; LGS_NO_ZERO_COPY_CAT=1: A/B knob)
     bn_out_into = os.environ.get("LGS_NO_ZERO_COPY_CAT") is None
     # lgs_conv_forward can emit the following BatchNorm's statistics from its epilogue -- measured SLOWER in the step (31.5 vs 30.9 ms: the epilogue work on every conv costs more than the skipped column reduction saves), so off unless LGS_CONV_BN_STATS=1
-    conv_bn_stats = os.environ.get("LGS_CONV_BN_STATS") == "1"
+    conv_bn_stats = os.environ.get("LGS_CONV_BN_STATS") in ("1", "big")
+    conv_bn_stats_min_bytes = (24 << 20) if os.environ.get("LGS_CONV_BN_STATS") == "big" else 0   # experiment: large outputs only
+
+    def want_conv_bn_stats(self, n_rows, cout, esize):
+        return self.conv_bn_stats and n_rows * cout * esize >= self.conv_bn_stats_min_bytes
 
     def __init__(self):
         self._side = {}

@@ -229,7 +229,8 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
             kmap = mgr.kernel_map_handle(out_key, in_key, ks)
             transposed = True
         want = (bn is not None and bn.bn.training and bn.bn.affine and input.F.is_cuda and self.bias is None
-                and getattr(get_backend(), "conv_bn_stats", False))
+                and getattr(get_backend(), "conv_bn_stats", False)
+                and get_backend().want_conv_bn_stats(mgr.size(out_key), self.out_channels, input.F.element_size()))
         if want:
             pivot = bn.bn.running_mean if bn.bn.track_running_stats else None
             holder = _StatsHolder()

@@ -138,7 +138,8 @@ class _BasicBlockFunction(torch.autograd.Function):
         be = ME.get_backend()
         n1, n2 = blk.norm1.bn, blk.norm2.bn
         pc1, pc2 = blk.conv1._cache_for(x), blk.conv2._cache_for(x)
-        want = bool(getattr(be, "conv_bn_stats", False))   # the conv epilogue also emits the next norm's statistics (off by default)
+        # the conv epilogue also emits the next norm's statistics (off by default)
+        want = bool(getattr(be, "conv_bn_stats", False)) and be.want_conv_bn_stats(x.shape[0], w1.shape[-1], x.element_size())
         o1, s1 = kmap3.conv_forward(x, w1, None, False, bn_pivot=n1.running_mean, want_bn_stats=True, pack_cache=pc1) if want else \
             (kmap3.conv_forward(x, w1, None, False, pack_cache=pc1), None)
         y1, st1 = _bn_fwd(be, o1, n1, g1, b1, None, True, s1)
