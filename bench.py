@@ -25,9 +25,11 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts: see languagegroundedsemseg_amd/__init__.py
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

@@ -443,6 +443,12 @@ int arena_acquire(lgs_manager *m) {
     if (q[i].cap >= need) {
       ArenaBlock b = q[i];
       q.erase(q.begin() + (long)i);
+      if (getenv("LGS_ARENA_DBG")) {
+        int pending = 0;
+        for (hipEvent_t e : b.ready) pending += hipEventQuery(e) == hipSuccess ? 0 : 1;
+        fprintf(stderr, "[arena] reuse block %zu of %zu (cap %zu MB, need %zu MB): %d of %zu events still pending\n", i, q.size() + 1, b.cap >> 20,
+                need >> 20, pending, b.ready.size());
+      }
       for (hipEvent_t e : b.ready) { (void)hipStreamWaitEvent(m->ms, e, 0); (void)hipEventDestroy(e); }
       m->arena = b.base; m->arena_cap = b.cap;
       return 0;
@@ -455,6 +461,7 @@ int arena_acquire(lgs_manager *m) {
     }
   }
   const size_t cap = (need + need / 4 + (2u << 20)) / (2u << 20) * (2u << 20);
+  if (getenv("LGS_ARENA_DBG")) fprintf(stderr, "[arena] hipMalloc %zu MB (need %zu MB, %zu queued)\n", cap >> 20, need >> 20, q.size());
   void *p = nullptr;
   if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return 0; }   // no block: this manager uses the pool
   m->arena = reinterpret_cast<char *>(p); m->arena_cap = cap;

@@ -7,6 +7,7 @@ import pytest
 # events, bucket-slot events of BucketedDDP) instead of the small-batch inline path; test_small_batches_inline_their_weight_gradients
 # covers the latter
 os.environ.setdefault("LGS_WGRAD_INLINE_BELOW", "0")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # as languagegroundedsemseg_amd/__init__.py sets it (before the HIP runtime starts)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
