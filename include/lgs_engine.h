@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LGS_ABI_VERSION 6
+#define LGS_ABI_VERSION 7
 
 enum lgs_dtype { LGS_F32 = 0, LGS_BF16 = 1 };
 
@@ -244,6 +244,15 @@ int lgs_clip_loss_backward(const void *feat, int64_t n, int c, const float *anch
                            const int64_t *neg, int k_neg, int64_t ignore_label, const float *inv_norm_f, const float *d_pos,
                            const float *d_neg, const float *g_dpos, const float *g_dneg, void *grad_feat, int dtype,
                            void *stream);
+/* lgs_clip_loss_backward_anchors: the same upstream gradient w.r.t. the NORMALISED anchors, for models that learn a projection of
+ *   the text anchors (/root/reference/models/clip_models.py:192-200, Res16UNet34CR_Proj):
+ *   grad_anchors_t[c][a8] (float32, a8 = n_anchor rounded up to 8; column a = d loss / d t^_a) = F^T G, G the 4-sparse matrix
+ *   dL/dS (-g_dpos at the class, -g_dneg / k_neg at each negative, zero rows for ignored labels), as ONE launch of the weight-
+ *   gradient kernels over the identity map (fixed summation order).  The caller applies d t^ -> d t (the anchor normalisation). */
+int64_t lgs_clip_anchor_grad_workspace_bytes(int64_t n, int c, int n_anchor, int dtype);
+int lgs_clip_loss_backward_anchors(const void *feat, int64_t n, int c, int n_anchor, const int64_t *labels, const int64_t *neg,
+                                   int k_neg, int64_t ignore_label, const float *inv_norm_f, const float *g_dpos,
+                                   const float *g_dneg, float *grad_anchors_t, int dtype, void *workspace, void *stream);
 
 /* ---- fused SGD step on a flat parameter / gradient bucket -----------------------------------------
  * torch.optim.SGD's update rule as the reference configures it (/root/reference/lib/solvers.py: momentum 0.9,

@@ -1127,6 +1127,87 @@ int conv_wgrad_f32path(const View &v, const void *in_v, int cin, const void *gou
 
 using namespace lgs;
 
+namespace lgs {
+// ---- gradient of the CLIP text-anchor loss w.r.t. the (normalised) anchors: d/dT^ = G^T F^, with G[n, a] the 4-sparse upstream
+// gradient dL/dS[n, a] (-g_dpos at the voxel's class, -g_dneg / K at each of its K negatives; zero rows for ignored voxels).
+// That is the weight gradient of the 1x1 "convolution" S = F^ T^^T, so it runs on the weight-gradient kernels: the coefficient
+// rows (already scaled by 1/|f_n|, so that the RAW features are the other operand) are materialised once in the feature dtype
+// and the identity-map launch of k_wgrad_bf16 / k_wgrad_f32 contracts them with the features (fixed summation order).
+template <typename T>
+__global__ void k_clip_coef_rows(const int64_t *__restrict__ labels, const int64_t *__restrict__ neg, int k_neg, int64_t ignore,
+                                 const float *__restrict__ inv_norm, const float *__restrict__ g_dpos, const float *__restrict__ g_dneg,
+                                 int64_t n, int n_anchor, int a_ld, T *__restrict__ G) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int64_t lab = labels[r];
+  if (lab == ignore || lab < 0 || lab >= n_anchor) return;          // the row stays zero (memset)
+  const float inv = inv_norm[r];
+  const float gp = g_dpos ? -g_dpos[r] * inv : 0.f;
+  const float gn = g_dneg ? -g_dneg[r] * inv / (float)k_neg : 0.f;
+  T *row = G + r * (int64_t)a_ld;
+  // <= 8 entries; an anchor that occurs more than once (a negative drawn twice, or equal to the class) gets the sum
+  int64_t idx[8]; float val[8]; int m = 0;
+  idx[m] = lab; val[m] = gp; ++m;
+  for (int j = 0; j < k_neg && j < 7; ++j) {
+    const int64_t a = neg[r * k_neg + j];
+    if (a < 0 || a >= n_anchor) continue;
+    int q = 0;
+    for (; q < m; ++q) if (idx[q] == a) break;
+    if (q < m) val[q] += gn; else { idx[m] = a; val[m] = gn; ++m; }
+  }
+  for (int q = 0; q < m; ++q) {
+    if constexpr (sizeof(T) == 4) row[idx[q]] = val[q]; else row[idx[q]] = f32_to_bf16(val[q]);
+  }
+}
+inline View clip_identity_view(int64_t n) {
+  View v;
+  v.n_pad = pad_rows(n); v.n_out = n; v.n_in = n; v.KS = 1; v.K = 1;
+  return v;
+}
+}  // namespace lgs
+
+extern "C" {
+
+int64_t lgs_clip_anchor_grad_workspace_bytes(int64_t n, int c, int n_anchor, int dtype) {
+  const int a8 = (n_anchor + 7) / 8 * 8;
+  const View v = clip_identity_view(n);
+  const WgradPlan p = wgrad_plan(v, c, a8, dtype);
+  return align256((int64_t)p.S * p.cin_pad * p.cout_pad * 4) + align256(n * (int64_t)a8 * esize(dtype)) + 512;
+}
+
+int lgs_clip_loss_backward_anchors(const void *feat, int64_t n, int c, int n_anchor, const int64_t *labels, const int64_t *neg,
+                                   int k_neg, int64_t ignore_label, const float *inv_norm_f, const float *g_dpos,
+                                   const float *g_dneg, float *grad_anchors_t, int dtype, void *workspace, void *stream) {
+  LGS_REQUIRE(feat && labels && neg && inv_norm_f && grad_anchors_t && workspace, "lgs_clip_loss_backward_anchors: null argument");
+  LGS_REQUIRE(dtype == LGS_F32 || dtype == LGS_BF16, "lgs_clip_loss_backward_anchors: unknown dtype");
+  LGS_REQUIRE(c % (dtype == LGS_BF16 ? 8 : 4) == 0 && k_neg >= 1 && k_neg <= 7 && n_anchor >= 1,
+              "lgs_clip_loss_backward_anchors: feature dim on the 16-byte grid, 1..7 negatives");
+  hipStream_t s = (hipStream_t)stream;
+  const int a8 = (n_anchor + 7) / 8 * 8;
+  if (n == 0) {
+    LGS_HIP(hipMemsetAsync(grad_anchors_t, 0, sizeof(float) * (size_t)c * a8, s));
+    return 0;
+  }
+  const View v = clip_identity_view(n);
+  const WgradPlan p = wgrad_plan(v, c, a8, dtype);
+  char *ws = reinterpret_cast<char *>(workspace);
+  void *G = ws + align256((int64_t)p.S * p.cin_pad * p.cout_pad * 4);
+  LGS_HIP(hipMemsetAsync(G, 0, (size_t)n * a8 * esize(dtype), s));
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  if (dtype == LGS_F32)
+    hipLaunchKernelGGL((k_clip_coef_rows<float>), blocks, 256, 0, s, labels, neg, k_neg, ignore_label, inv_norm_f, g_dpos, g_dneg, n,
+                       n_anchor, a8, reinterpret_cast<float *>(G));
+  else
+    hipLaunchKernelGGL((k_clip_coef_rows<bf16_t>), blocks, 256, 0, s, labels, neg, k_neg, ignore_label, inv_norm_f, g_dpos, g_dneg, n,
+                       n_anchor, a8, reinterpret_cast<bf16_t *>(G));
+  LGS_HIP(hipGetLastError());
+  // grad_anchors_t[c][a8] = F^T G   (transposed: the caller reads column a as d/dT^_a)
+  if (dtype == LGS_F32) return conv_wgrad_f32path<float>(v, feat, c, G, a8, grad_anchors_t, workspace, s);
+  return conv_wgrad_bf16(v, feat, c, G, a8, grad_anchors_t, workspace, s);
+}
+
+}  // extern "C"
+
 extern "C" {
 
 int lgs_conv_wgrad_supports_stride(const lgs_kmap *km, int transposed, int cin, int cout, int dtype, int in_row_stride) {

@@ -10,7 +10,7 @@ import os
 from . import build as _build
 
 LGS_F32, LGS_BF16 = 0, 1
-ABI_VERSION = 6     # LGS_ABI_VERSION of include/lgs_engine.h
+ABI_VERSION = 7     # LGS_ABI_VERSION of include/lgs_engine.h
 
 
 class PackDesc(ctypes.Structure):
@@ -35,6 +35,7 @@ EXPORTS = [
     "lgs_bn_stats", "lgs_bn_sync_combine", "lgs_bn_apply", "lgs_bn_backward_reduce", "lgs_bn_backward_apply",
     "lgs_clip_similarity", "lgs_clip_workspace_bytes",
     "lgs_clip_loss_workspace_bytes", "lgs_clip_loss_forward", "lgs_clip_loss_backward",
+    "lgs_clip_anchor_grad_workspace_bytes", "lgs_clip_loss_backward_anchors",
     "lgs_ce_forward_backward",
     "lgs_voxelize", "lgs_label_vote", "lgs_cluster_workspace_bytes", "lgs_cluster", "lgs_sgd_step",
 ]
@@ -96,6 +97,7 @@ def lib():
         "lgs_ce_forward_backward": [vp, i64, ci, vp, i64, vp, vp, vp, ci, vp],
         "lgs_clip_loss_forward": [vp, i64, ci, vp, ci, vp, vp, ci, i64, vp, vp, vp, vp, vp, vp, ci, vp, vp],
         "lgs_clip_loss_backward": [vp, i64, ci, vp, ci, vp, vp, ci, i64, vp, vp, vp, vp, vp, vp, ci, vp],
+        "lgs_clip_loss_backward_anchors": [vp, i64, ci, ci, vp, vp, ci, i64, vp, vp, vp, vp, ci, vp, vp],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -111,6 +113,8 @@ def lib():
     L.lgs_clip_workspace_bytes.argtypes = [ci, ci, ci]
     L.lgs_clip_loss_workspace_bytes.restype = i64
     L.lgs_clip_loss_workspace_bytes.argtypes = [ci, ci, ci]
+    L.lgs_clip_anchor_grad_workspace_bytes.restype = i64
+    L.lgs_clip_anchor_grad_workspace_bytes.argtypes = [i64, ci, ci, ci]
     if L.lgs_abi_version() != ABI_VERSION:
         raise RuntimeError("liblgs_engine.so ABI version mismatch")
     _lib = L

@@ -83,6 +83,7 @@ class _ClipLossFused(torch.autograd.Function):
         be = get_backend()
         d_pos, d_neg, pred, saved, sim = be.clip_loss_forward(feats, anchors, labels, neg, ignore_label, want_sim)
         ctx.ignore_label = ignore_label
+        ctx.anchors = anchors if anchors.requires_grad else None      # a learned projection of the anchors (clip_models.py:192-200)
         ctx.save_for_backward(*saved, d_pos, d_neg)
         ctx.mark_non_differentiable(pred)
         if sim is None:
@@ -93,8 +94,16 @@ class _ClipLossFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_dpos, g_dneg, _gp, _gs):
         *saved, d_pos, d_neg = ctx.saved_tensors
-        gf = get_backend().clip_loss_backward(tuple(saved), d_pos, d_neg, g_dpos, g_dneg, ctx.ignore_label)
-        return gf, None, None, None, None, None
+        be = get_backend()
+        gf = be.clip_loss_backward(tuple(saved), d_pos, d_neg, g_dpos, g_dneg, ctx.ignore_label) if ctx.needs_input_grad[0] else None
+        ga = None
+        if ctx.anchors is not None and ctx.needs_input_grad[1]:
+            # d/dT^ = G^T F^ on the weight-gradient kernels (lgs_clip_loss_backward_anchors), then through t^ = t / |t|
+            gt = be.clip_loss_backward_anchors(tuple(saved), g_dpos, g_dneg, ctx.ignore_label)
+            tn = saved[1]
+            an = ctx.anchors.detach().float().norm(dim=1, keepdim=True).clamp_min(1e-12)
+            ga = ((gt - (gt * tn).sum(1, keepdim=True) * tn) / an).to(ctx.anchors.dtype)
+        return gf, ga, None, None, None, None
 
 
 def feature_sim(output_feats, anchor_feats):
@@ -159,15 +168,16 @@ class ContrastiveLanguageLoss(nn.Module):
         if neg_indices is None:
             neg_indices = self.sample_negatives(labels)
         be = get_backend()
-        fused = (hasattr(be, "clip_loss_forward") and not anchor_feats.requires_grad and features.is_cuda
+        fused = (hasattr(be, "clip_loss_forward") and features.is_cuda
+                 and (not anchor_feats.requires_grad or hasattr(be, "clip_loss_backward_anchors"))
                  and anchor_feats.shape[0] % 4 == 0 and 4 <= anchor_feats.shape[0] <= be.CLIP_LOSS_MAX_ANCHORS
                  and 1 <= neg_indices.shape[1] <= 7)
         if fused:
             d_pos, d_neg, pred, sim = _ClipLossFused.apply(features, anchor_feats, labels, neg_indices, self.ignore_label,
                                                            bool(return_similarity))
         else:
-            # learned anchor projections (gradient w.r.t. the anchors), > 224 anchors, or the CPU oracle backend of the
-            # tests: dense similarity matrix + index gathers
+            # > 224 anchors, more than 7 negatives, or the CPU oracle backend of the tests: dense similarity matrix + index
+            # gathers (learned anchor projections take the fused path too: lgs_clip_loss_backward_anchors)
             sim = clip_similarity(features, anchor_feats)         # [N, num_labels] -- the MFMA contraction
             valid = labels != self.ignore_label
             lab = labels.clamp_min(0)

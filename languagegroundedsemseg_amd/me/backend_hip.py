@@ -662,6 +662,24 @@ class HipBackend:
                                                   _dtype_code(feats), _stream()))
         return gf
 
+    def clip_loss_backward_anchors(self, saved, g_dpos, g_dneg, ignore_label):
+        """-> d loss / d t^ [n_anchor, c] float32 (gradient w.r.t. the NORMALISED anchors): lgs_clip_loss_backward_anchors"""
+        L = engine.lib()
+        feats, tn, labels, neg, inv = saved
+        n, c = feats.shape
+        na = tn.shape[0]
+        a8 = (na + 7) // 8 * 8
+        dt = _dtype_code(feats)
+        with _dev(feats.device):
+            gt = torch.empty((c, a8), dtype=torch.float32, device=feats.device)
+            gp = g_dpos.contiguous().float() if g_dpos is not None else None
+            gn = g_dneg.contiguous().float() if g_dneg is not None else None
+            ws = _ws(L.lgs_clip_anchor_grad_workspace_bytes(n, c, na, dt), feats.device)
+            engine.check(L.lgs_clip_loss_backward_anchors(_ptr(feats), n, c, na, _ptr(labels), _ptr(neg), int(neg.shape[1]),
+                                                          int(ignore_label), _ptr(inv), _ptr(gp), _ptr(gn), _ptr(gt), dt, _ptr(ws),
+                                                          _stream()))
+        return gt[:, :na].t()
+
     # ---- fused softmax cross-entropy: lgs_ce_forward_backward
     def cross_entropy(self, logits, labels, ignore_index, want_grad=True, grad_scale=None):
         """mean CE over the non-ignored rows.  want_grad=False: loss only; grad_scale (device scalar): gradient only,

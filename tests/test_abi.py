@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), "missing export " + s
     assert sorted(engine.EXPORTS) == syms, "engine.EXPORTS out of sync with the header"
-    assert engine.lib().lgs_abi_version() == engine.ABI_VERSION == 6
+    assert engine.lib().lgs_abi_version() == engine.ABI_VERSION == 7
 
 
 def declared_prototypes():

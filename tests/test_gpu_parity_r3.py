@@ -408,3 +408,64 @@ def test_small_batches_inline_their_weight_gradients(monkeypatch):
     side, inline = run(0), run(1 << 30)
     for k in side:
         assert torch.equal(side[k], inline[k]), k
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("n,c,na,k", [(5000, 96, 200, 3), (3001, 512, 200, 3), (700, 32, 20, 7)])
+def test_learned_anchor_gradient_on_the_fused_loss(dtype, tol, n, c, na, k):
+    """models with a learned projection of the text anchors (clip_models.py:192-200, Res16UNet34CR_Proj) need d loss / d anchors:
+    the fused kernel path (lgs_clip_loss_backward_anchors: G^T F on the weight-gradient kernels) against the dense
+    formulation in fp64 (the reference's feat_dist + hinge, ContrastiveLanguageLoss.py:73-95,113-146), feature gradient included"""
+    from languagegroundedsemseg_amd.losses import ContrastiveLanguageLoss
+    g = torch.Generator().manual_seed(n + c)
+    feats = torch.randn(n, c, generator=g)
+    anchors = torch.randn(na, c, generator=g)
+    labels = torch.randint(-1, na, (n,), generator=g)
+    neg = torch.randint(0, na, (n, k), generator=g)          # duplicates and negatives equal to the class do occur
+    crit = ContrastiveLanguageLoss(num_labels=na, num_negative_samples=k)
+    f_h = feats.to(DEV).to(dtype).requires_grad_(True)
+    a_h = anchors.to(DEV).requires_grad_(True)
+    loss, _, _ = crit(f_h, labels.to(DEV), a_h, neg_indices=neg.to(DEV))
+    loss.backward()
+    assert a_h.grad is not None and f_h.grad is not None
+    # fp64 reference on the values the kernel saw
+    f64 = f_h.detach().double().cpu().requires_grad_(True)
+    a64 = anchors.double().requires_grad_(True)
+    sim = torch.nn.functional.normalize(f64, dim=1) @ torch.nn.functional.normalize(a64, dim=1).t()
+    valid = labels != -1
+    lab = labels.clamp_min(0)
+    d_pos = torch.where(valid, 1.0 - sim.gather(1, lab[:, None]).squeeze(1), torch.zeros((), dtype=torch.float64))
+    d_neg = torch.where(valid, 1.0 - sim.gather(1, neg).mean(1), torch.zeros((), dtype=torch.float64))
+    ref = torch.relu(d_pos - crit.pos_thresh).mean() + crit.neg_weight * torch.relu(crit.neg_thresh - d_neg).mean()
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < (1e-5 if dtype == torch.float32 else 2e-3)
+    ga, gr = a_h.grad.double().cpu().numpy(), a64.grad.numpy()
+    assert rel_l2(ga, gr) < tol, rel_l2(ga, gr)
+    gf, gfr = f_h.grad.double().cpu().numpy(), f64.grad.numpy()
+    assert rel_l2(gf, gfr) < (2e-5 if dtype == torch.float32 else 2e-2), rel_l2(gf, gfr)
+
+
+def test_res16unet34cr_proj_step_trains_the_anchor_projection():
+    """clip_models.py:186-200: the projected anchors carry a gradient -- through the fused loss kernels, not the dense matrix"""
+    from languagegroundedsemseg_amd.losses import ContrastiveLanguageLoss
+    from languagegroundedsemseg_amd.me import backend_hip
+    from languagegroundedsemseg_amd.synthetic import make_batch, text_anchors
+    coords, feats, labels = make_batch([2], voxel=0.05, n_target=6000)
+    m = deterministic_init(load_model("Res16UNet34CR_Proj")(3, 20, Cfg()), 5).to(DEV).train()
+    m.representation_only(True)
+    anchors = torch.from_numpy(text_anchors(200, 512)).to(DEV)
+    crit = ContrastiveLanguageLoss(num_labels=200, num_negative_samples=3)
+    calls = []
+    orig = backend_hip.HipBackend.clip_loss_backward_anchors
+    backend_hip.HipBackend.clip_loss_backward_anchors = lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1]
+    try:
+        out, proj = m(ME.SparseTensor(torch.from_numpy(feats).to(DEV).bfloat16(), torch.from_numpy(coords).to(DEV)), anchors)
+        assert proj.shape == (200, m.PLANES[7]) and proj.requires_grad
+        loss, _, _ = crit(out.F, torch.from_numpy(labels).to(DEV), proj)
+        loss.backward()
+    finally:
+        backend_hip.HipBackend.clip_loss_backward_anchors = orig
+    assert calls, "the anchor gradient did not come from the fused path"
+    gw = m.projection_layer.weight.grad
+    assert gw is not None and torch.isfinite(gw).all() and float(gw.abs().max()) > 0
+    assert m.conv0p1s1.kernel.grad is not None and torch.isfinite(m.conv0p1s1.kernel.grad).all()
