@@ -40,7 +40,10 @@ def _dev(device):
 
 
 def _ptr(t):
-    return _vp(t.data_ptr()) if t is not None else _vp(None)
+    """device address as a plain int (None = NULL): every engine entry point has its argtypes declared (engine.py, checked against
+    the header by tests/test_abi.py), so ctypes converts -- building a c_void_p object per argument cost ~1 ms of host time per
+    step (2500 pointer arguments)"""
+    return t.data_ptr() if t is not None else None
 
 
 def _dtype_code(t):
@@ -78,6 +81,16 @@ def _row_strided(t, c):
 
 
 _WS = {}
+_BN_WSB = {}
+
+
+def _bn_ws_bytes(L, n, c):
+    b = _BN_WSB.get((n, c))
+    if b is None:
+        if len(_BN_WSB) > 4096:
+            _BN_WSB.clear()
+        b = _BN_WSB[(n, c)] = L.lgs_bn_workspace_bytes(n, c)
+    return b
 # input voxels per batch below which weight gradients are not moved to the side stream (LGS_WGRAD_INLINE_BELOW: tuning knob;
 # one 145 k-voxel scene per step: 11.2 -> 10.4 ms, the 1.2 M-voxel batch keeps the side stream: 29.9 vs 30.9 ms)
 _WGRAD_INLINE_BELOW = int(os.environ.get("LGS_WGRAD_INLINE_BELOW", "400000"))
@@ -151,9 +164,12 @@ class PackedWeights:
         """-> (packed buffer or None, pack_mode)"""
         if not self.enabled or cache is None:
             return None, 0
-        L = engine.lib()
-        d = engine.PackDesc()
-        engine.check(L.lgs_conv_pack_desc(km.h, int(op), int(transposed), int(cin), int(cout), int(dt), ctypes.byref(d)))
+        ck = (op, transposed, cin, cout, dt)
+        d = km._pdesc.get(ck)          # the layout of a launch shape on this map: asked once per map, layers share maps
+        if d is None:
+            d = engine.PackDesc()
+            engine.check(engine.lib().lgs_conv_pack_desc(km.h, int(op), int(transposed), int(cin), int(cout), int(dt), ctypes.byref(d)))
+            km._pdesc[ck] = d
         if d.bytes == 0:
             return None, 0
         key = (op, int(transposed), dt, d.ncp, d.nbp, d.K, cin, cout)
@@ -213,6 +229,15 @@ class HipKernelMap:
     def __init__(self, mgr, handle, in_key, out_key, ks):
         self.mgr, self.h, self.in_key, self.out_key, self.ks = mgr, handle, in_key, out_key, ks
         self.K = ks ** 3
+        self._wsb = {}            # lgs_conv_workspace_bytes per (cin, cout, dtype, op): several layers share a map
+        self._pdesc = {}          # lgs_conv_pack_desc per (op, transposed, cin, cout, dtype)
+
+    def _ws_bytes(self, L, cin, cout, dt, op):
+        key = (cin, cout, dt, op)
+        b = self._wsb.get(key)
+        if b is None:
+            b = self._wsb[key] = L.lgs_conv_workspace_bytes(self.h, cin, cout, dt, op)
+        return b
 
     def export(self):
         L = engine.lib()
@@ -232,13 +257,21 @@ class HipKernelMap:
         n_out = self.mgr.map_size(self.out_key)
         return (n_out, n_in) if transposed else (n_in, n_out)
 
+    def _w32(self, weight):
+        """-> (fp32 contiguous weight tensor whose address the engine reads, cin, cout); the usual case (an fp32 contiguous
+        parameter) is the parameter itself: only its address and shape are used, no view objects are built"""
+        cout = weight.shape[-1]
+        if weight.dtype == torch.float32 and weight.is_contiguous():
+            return weight, weight.numel() // (self.K * cout), cout
+        w = weight.detach().reshape(self.K, -1, cout).contiguous().float()
+        return w, w.shape[1], cout
+
     def conv_forward(self, x, weight, bias, transposed, bn_pivot=None, want_bn_stats=False, pack_cache=None):
         """want_bn_stats: also return the per-tile BatchNorm statistics of the output (None if this launch shape cannot
         produce them) -> (out, (partials [rows, 2, cout], pivot) | None)"""
         _require_dev(x, "features")
         L = engine.lib()
-        w = weight.detach().reshape(self.K, -1, weight.shape[-1]).contiguous().float()
-        cin, cout = w.shape[1], w.shape[2]
+        w, cin, cout = self._w32(weight)
         # the skip half of a zero-copy ME.cat is a column slice of the concat buffer: gathered in place through a row stride
         ld = _row_strided(x, cin) if (cin % (8 if x.dtype == torch.bfloat16 else 4) == 0 and cout % 4 == 0) else None
         if ld is None:
@@ -249,7 +282,7 @@ class HipKernelMap:
         part = None
         with _dev(x.device):
             out = torch.empty((n_out, cout), dtype=x.dtype, device=x.device)
-            ws = _ws(L.lgs_conv_workspace_bytes(self.h, cin, cout, dt, 0), x.device)
+            ws = _ws(self._ws_bytes(L, cin, cout, dt, 0), x.device)
             b = bias.detach().reshape(-1).contiguous().float() if bias is not None else None
             if want_bn_stats:
                 rows = L.lgs_conv_bn_partial_rows(self.h, int(transposed), cout, dt)
@@ -269,8 +302,7 @@ class HipKernelMap:
         (lgs_conv_dgrad_accumulate; t itself is returned) and by an add into the fresh dgrad tensor otherwise."""
         L = engine.lib()
         gout = gout.contiguous()
-        w = weight.detach().reshape(self.K, -1, weight.shape[-1]).contiguous().float()
-        cin, cout = w.shape[1], w.shape[2]
+        w, cin, cout = self._w32(weight)
         n_in, n_out = self._rows(transposed)
         assert gout.shape[0] == n_out and gout.shape[1] == cout
         dt = _dtype_code(gout)
@@ -279,7 +311,7 @@ class HipKernelMap:
                 and L.lgs_conv_dgrad_can_accumulate(self.h, int(transposed), cin, cout, dt))
         with _dev(gout.device):
             gin = acc if fuse else torch.empty((n_in, cin), dtype=gout.dtype, device=gout.device)
-            ws = _ws(L.lgs_conv_workspace_bytes(self.h, cin, cout, dt, 1), gout.device)
+            ws = _ws(self._ws_bytes(L, cin, cout, dt, 1), gout.device)
             pk, mode = get_packed().lookup(pack_cache, self, 1, transposed, weight, w, cin, cout, dt)
             fn = L.lgs_conv_dgrad_accumulate if fuse else L.lgs_conv_dgrad
             engine.check(fn(self.h, int(transposed), _ptr(gout), cout, _ptr(w), cin, _ptr(gin), dt, _ptr(ws), _ptr(pk), int(mode), _stream()))
@@ -317,7 +349,7 @@ class HipKernelMap:
                 gw = torch.empty((self.K, cin, cout), dtype=torch.float32, device=x.device)
             if out is None and stream is not None:
                 gw.record_stream(stream)
-            ws = _ws(L.lgs_conv_workspace_bytes(self.h, cin, cout, dt, 2), x.device, stream)
+            ws = _ws(self._ws_bytes(L, cin, cout, dt, 2), x.device, stream)
             engine.check(L.lgs_conv_wgrad(self.h, int(transposed), _ptr(x), cin, _ptr(gout), cout, _ptr(gw), dt, _ptr(ws),
                                           int(ld or 0), raw))
         return gw
@@ -509,7 +541,7 @@ class HipBackend:
                 y = torch.empty_like(x)
             stats = torch.empty(2 * c, dtype=torch.float32, device=x.device)
             res = residual.contiguous() if residual is not None else None
-            ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
+            ws = _ws(_bn_ws_bytes(L, n, c), x.device)
             engine.check(L.lgs_bn_forward(_ptr(x), n, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
                                           _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(res), int(relu), _ptr(y),
                                           _ptr(stats), dt, _ptr(ws), _ptr(part), int(part.shape[0]) if part is not None else 0,
@@ -539,7 +571,7 @@ class HipBackend:
             dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_residual else None
             dgamma = dgamma_out if dgamma_out is not None else torch.empty(c, dtype=torch.float32, device=x.device)
             dbeta = dbeta_out if dbeta_out is not None else torch.empty(c, dtype=torch.float32, device=x.device)
-            ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
+            ws = _ws(_bn_ws_bytes(L, n, c), x.device)
             engine.check(L.lgs_bn_backward(_ptr(x), _ptr(y), _ptr(dy), int(dy_ld), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), int(relu), _ptr(dx),
                                            _ptr(dres), _ptr(dgamma), _ptr(dbeta), dt, _ptr(ws), int(y_ld), _stream()))
         return dx, dres, dgamma, dbeta
@@ -553,7 +585,7 @@ class HipBackend:
         part, piv = conv_stats if conv_stats is not None else (None, None)
         with _dev(x.device):
             out = torch.empty(2 * c + 1, dtype=torch.float32, device=x.device)
-            ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
+            ws = _ws(_bn_ws_bytes(L, n, c), x.device)
             engine.check(L.lgs_bn_stats(_ptr(x), n, c, _ptr(out), _dtype_code(x), _ptr(ws), _ptr(part),
                                         int(part.shape[0]) if part is not None else 0, _ptr(piv), _stream()))
         return out
@@ -586,7 +618,7 @@ class HipBackend:
         n, c = x.shape
         with _dev(x.device):
             sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
-            ws = _ws(L.lgs_bn_workspace_bytes(n, c), x.device)
+            ws = _ws(_bn_ws_bytes(L, n, c), x.device)
             engine.check(L.lgs_bn_backward_reduce(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), int(relu), _ptr(sums),
                                                   _ptr(dgamma_out), _ptr(dbeta_out), _dtype_code(x), _ptr(ws), _stream()))
         return sums
