@@ -25,7 +25,9 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts: see languagegroundedsemseg_amd/__init__.py
+# before the HIP runtime starts (see languagegroundedsemseg_amd/__init__.py); ranks SHARING one GPU (--same-device dry runs) keep
+# the runtime's 4: 2 x 8 queues oversubscribe the device's hardware queues (two gloo ranks on one GPU: 136 vs 520 ms per step)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4" if "--same-device" in sys.argv else "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

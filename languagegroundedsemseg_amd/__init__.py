@@ -16,7 +16,8 @@ import os as _os
 # compute stream, so every `SparseTensor(...)` (its insert returns a count to the host) blocked the host until the GPU had
 # finished the previous training step (one 145 k-voxel scene per step: 11.5 vs 10.4 ms).  The variable is read when the HIP
 # runtime initialises, i.e. at the process's first device call: it has to be set before that (importing this package first
-# is enough; an explicit setting by the user wins).
+# is enough; an explicit setting by the user wins).  One process per GPU is assumed, as everywhere in this build: several processes
+# time-sharing a GPU should keep the default (2 x 8 queues oversubscribe the device: 136 vs 520 ms per step in the two-rank dry run).
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 __version__ = "0.1.0"
