@@ -33,6 +33,11 @@ template <> struct Vec<float> {
   __device__ static void store(float *p, const float (&v)[4]) {
     *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
+  __device__ static void store_nt(float *p, const float (&v)[4]) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 x = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(x, reinterpret_cast<f4 *>(p));
+  }
 };
 template <> struct Vec<bf16_t> {
   static constexpr int W = 8;
@@ -49,6 +54,15 @@ template <> struct Vec<bf16_t> {
     x.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
     x.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
     *reinterpret_cast<uint4 *>(p) = x;
+  }
+  __device__ static void store_nt(bf16_t *p, const float (&v)[8]) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 x;
+    x.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    x.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    x.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+    x.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    __builtin_nontemporal_store(x, reinterpret_cast<u4 *>(p));
   }
 };
 
@@ -309,7 +323,7 @@ __global__ __launch_bounds__(kNT) void k_bn_apply(const T *__restrict__ x, const
       if (res) o += ra[k];
       xa[k] = (relu && o < 0.f) ? 0.f : o;
     }
-    Vec<T>::store(y + r * y_ld + cg * W, xa);
+    Vec<T>::store_nt(y + r * y_ld + cg * W, xa);
     if (two) {
 #pragma unroll
       for (int k = 0; k < W; ++k) {
@@ -317,7 +331,7 @@ __global__ __launch_bounds__(kNT) void k_bn_apply(const T *__restrict__ x, const
         if (res) o += rb[k];
         xb[k] = (relu && o < 0.f) ? 0.f : o;
       }
-      Vec<T>::store(y + r2 * y_ld + cg * W, xb);
+      Vec<T>::store_nt(y + r2 * y_ld + cg * W, xb);
     }
   }
 }
@@ -360,13 +374,13 @@ __global__ __launch_bounds__(kNT) void k_bn_bwd_apply(const T *__restrict__ x, c
 #pragma unroll
       for (int k = 0; k < W; ++k) gv[k] = ((xv[k] - mean[k]) * sc[k] + bt[k]) > 0.f ? gv[k] : 0.f;  // same expression as k_bn_apply
     }
-    if (dres) Vec<T>::store(dres + o, gv);
+    if (dres) Vec<T>::store_nt(dres + o, gv);
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       const float xh = (xv[k] - mean[k]) * istd[k];
       xv[k] = gi[k] * (gv[k] - m1[k] - xh * m2[k]);
     }
-    Vec<T>::store(dx + o, xv);
+    Vec<T>::store_nt(dx + o, xv);
   }
 }
 
