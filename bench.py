@@ -521,6 +521,47 @@ def secondary_block(workload, model_name, dtype, coords, feats, labels, device, 
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_command(n, argv, script=None, port=None):
+    """The command `python bench.py --gpus N ...` re-executes itself as when nobody set up ranks for it (main.py:192-195:
+    the reference hands `gpus=N` to Lightning, which spawns one process per GPU; here that is torch.distributed.run)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port or _free_port()),
+            script or os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv, script=None, extra_env=None):
+    """Run N ranks of `script` (this file) on this node, one per GPU, and return the launcher's exit code.  Rank 0's single
+    JSON line goes to our stdout unchanged (children inherit it)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL / tensor sharing)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env["LGS_BENCH_SELF_LAUNCHED"] = "1"
+    env.update(extra_env or {})
+    return subprocess.call(launch_command(n, argv, script), env=env)
+
+
+def resolve_world(gpus, environ):
+    """-> ("launch", gpus) when this process must spawn the ranks itself, ("rank", world) when it IS a rank.  `--gpus N` is the
+    contract: a rank whose WORLD_SIZE disagrees with it is a mis-launch and raises instead of printing n_gpus of something else."""
+    if "WORLD_SIZE" not in environ:
+        if gpus > 1:
+            return "launch", gpus
+        return "rank", 1
+    world = int(environ["WORLD_SIZE"])
+    if world != gpus:
+        raise RuntimeError("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it as `python bench.py --gpus N` or under "
+                           "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (gpus, world))
+    return "rank", world
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -552,9 +593,13 @@ def main():
     if args.model is None:
         args.model = "Res16UNet34C" if args.workload == "ce" else "Res16UNet34D"
 
+    mode, world = resolve_world(args.gpus, os.environ)
+    if mode == "launch":
+        if not args.same_device and torch.cuda.device_count() < args.gpus:
+            raise RuntimeError("bench.py --gpus %d: this node exposes %d GPUs" % (args.gpus, torch.cuda.device_count()))
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X (the engine has no CPU fallback)")
     if args.same_device:
@@ -648,16 +693,22 @@ def main():
         "final_loss": final_loss,
         "phases": res["phases"],
     }
+    # one record per rank (also at N = 1, so that the schema of the line does not depend on N): where a step spends its time
+    # (compute-stream phases, the part of the bucket all-reduces that backward did not hide, the compute-stream stalls inside
+    # SyncBN's small collectives)
+    mine = {"rank": rank, "phases": res["phases"], "ddp": ddp.timing_summary(args.steps), "ms_per_step": res["dt"] / args.steps * 1e3}
     if world > 1:
-        # one record per rank: where a multi-GPU step spends its time (compute-stream phases, the part of the bucket
-        # all-reduces that backward did not hide, the compute-stream stalls inside SyncBN's small collectives)
-        mine = {"rank": rank, "phases": res["phases"], "ddp": ddp.timing_summary(args.steps), "ms_per_step": res["dt"] / args.steps * 1e3}
         allr = [None] * world
         dist.all_gather_object(allr, mine)
-        out["per_rank"] = allr
-        out["rccl_ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                             "bucket_collectives_per_step": mine["ddp"]["bucket_collectives_per_step"] if mine["ddp"] else None,
-                             "syncbn_collectives_per_step": mine["ddp"]["syncbn_collectives_per_step"] if mine["ddp"] else None}
+        assert dist.get_world_size() == args.gpus
+    else:
+        allr = [mine]
+    out["per_rank"] = allr
+    out["rccl_ranks"] = {"world_size": dist.get_world_size() if world > 1 else 1,
+                         "backend": dist.get_backend() if world > 1 else None,
+                         "self_launched": os.environ.get("LGS_BENCH_SELF_LAUNCHED") == "1",
+                         "bucket_collectives_per_step": mine["ddp"]["bucket_collectives_per_step"] if mine["ddp"] else None,
+                         "syncbn_collectives_per_step": mine["ddp"]["syncbn_collectives_per_step"] if mine["ddp"] else None}
 
     if clog is not None and res["disc"] is not None:
         out["roofline"] = roofline_report(clog, res["disc"], args.dtype, args.workload, args.steps, ms_per_step, n_vox,
