@@ -607,7 +607,7 @@ def main():
         # ranks sharing ONE GPU (dry run of the N > 1 logic only): the grid-barrier BatchNorm kernels assume that all their
         # workgroups become resident promptly, which another process filling the same CUs does not allow (measured: 697 ms per
         # step with --sync-bn 0); the three-launch path has no such assumption
-        os.environ.setdefault("LGS_BN_FUSED", "0")
+        os.environ.setdefault("LGS_BN_FUSED", "0")      # initial value of the engine's BN_FUSED knob (csrc/lgs_tuning.hip)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -638,11 +638,6 @@ def main():
     ctx = make_ctx(args.workload, args.model, coords, device)
     model, ddp, opt = make_trainer(args.model, dtype, device, world, args, ctx)
 
-    if os.environ.get("LGS_COMPUTE_CUMASK"):      # experiment knob: confine the compute stream to a CU partition
-        from languagegroundedsemseg_amd.me.backend_hip import masked_stream
-        cs = masked_stream(device, [int(w, 16) for w in os.environ["LGS_COMPUTE_CUMASK"].split(",")])
-        cs.wait_stream(torch.cuda.current_stream())
-        torch.cuda.set_stream(cs)
     if args.compute_priority != 0:
         hp = torch.cuda.Stream(device=device, priority=args.compute_priority)
         hp.wait_stream(torch.cuda.current_stream())

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LGS_ABI_VERSION 7
+#define LGS_ABI_VERSION 8
 
 enum lgs_dtype { LGS_F32 = 0, LGS_BF16 = 1 };
 
@@ -50,6 +50,22 @@ typedef struct lgs_kmap lgs_kmap;       /* one cached kernel map (owned by its m
 /* ---- library ---------------------------------------------------------------------------- */
 int lgs_abi_version(void);
 const char *lgs_last_error(void);
+
+/* ---- tuning table and dispatch counters (csrc/lgs_tuning.hip) -----------------------------
+ * No counterpart in the reference (MinkowskiEngine exposes no such hooks): this is the engine's ONE table of tuning and
+ * debugging knobs (which used to be scattered getenv calls) and the test hook the parity suite needs to prove coverage.
+ *   lgs_tuning_set / get : knob by name ("WW_MIN_ROWS" or "LGS_WW_MIN_ROWS"); initial value = environment LGS_<NAME>, else the
+ *                          default.  Unknown name -> error.  Knobs take effect at the next launch.
+ *   lgs_tuning_describe  : "NAME\tdefault\tvalue\tdoc\n" per knob into buf (at most cap bytes incl. NUL); returns bytes needed.
+ *   lgs_debug_dispatch_counts : "count\tlaunch site\n" for every kernel launch site hit since the last reset (site = kernel
+ *                          expression + template bindings, e.g. "k_wgrad_ps<KIND,NCS> [KIND=0,NCS=3]"); reset != 0 zeroes them.
+ *                          tests/test_gpu_dispatch_coverage.py: every site the benchmarked steps of bench.py dispatch
+ *                          (/root/reference/scripts/train_models.sh, text_representation_train.sh) must also be dispatched
+ *                          by a parity test.                                                  */
+int lgs_tuning_set(const char *name, int64_t value);
+int lgs_tuning_get(const char *name, int64_t *value);
+int64_t lgs_tuning_describe(char *buf, int64_t cap);
+int64_t lgs_debug_dispatch_counts(char *buf, int64_t cap, int reset);
 
 /* ---- coordinate manager ------------------------------------------------------------------
  * replaces: ME.SparseTensor(features, coordinates) -> CoordinateManager.insert_and_map

@@ -169,12 +169,12 @@ int lgs_cluster(const float *xyz, const int32_t *batch_idx, const int32_t *seman
   const float inv_r = 1.0f / (radius * 1.0001f), r2 = radius * radius;
   LGS_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(int32_t), s));
   LGS_HIP(hipMemsetAsync(size, 0, sizeof(int32_t) * n, s));
-  hipLaunchKernelGGL(k_cell_keys, nb, 256, 0, s, xyz, batch_idx, n, inv_r, keys, vals, scal);
+  LGS_KLAUNCH(k_cell_keys, nb, 256, 0, s, xyz, batch_idx, n, inv_r, keys, vals, scal);
   LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, keys, skeys, vals, svals, (size_t)n, 0, 64, s));
-  hipLaunchKernelGGL(k_iota, nb, 256, 0, s, parent, n);
-  hipLaunchKernelGGL(k_union_neighbours, nb, 256, 0, s, xyz, batch_idx, semantic_label, skeys, svals, n, inv_r, r2, parent);
-  hipLaunchKernelGGL(k_flatten_count, nb, 256, 0, s, parent, n, size);
-  hipLaunchKernelGGL(k_component_out, nb, 256, 0, s, parent, size, n, threshold, component, scal + 1);
+  LGS_KLAUNCH(k_iota, nb, 256, 0, s, parent, n);
+  LGS_KLAUNCH(k_union_neighbours, nb, 256, 0, s, xyz, batch_idx, semantic_label, skeys, svals, n, inv_r, r2, parent);
+  LGS_KLAUNCH(k_flatten_count, nb, 256, 0, s, parent, n, size);
+  LGS_KLAUNCH(k_component_out, nb, 256, 0, s, parent, size, n, threshold, component, scal + 1);
   int32_t h[2] = {0, 0};
   LGS_HIP(hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, s));
   LGS_HIP(hipStreamSynchronize(s));

@@ -32,6 +32,23 @@ void set_error(const std::string &msg);
     }                                                                              \
   } while (0)
 
+// ---- tuning table + dispatch counters (lgs_tuning.hip)
+enum Tune {
+  T_WW_MIN_ROWS, T_WW_RANGE, T_WGRAD_WIDE, T_BN_FUSED, T_BN_FUSED_MAX_MB, T_BN_FUSED_BLOCKS, T_PS_CUS, T_PS_WIDE3, T_WGRAD_PS,
+  T_MASK_WINDOW, T_CONV_SPLIT, T_SMALL_CFG, T_WIDE_GC64, T_WIDE_DBG, T_WIDE_TRACE, T_ARENA_DBG, T_CONV_WIDE, T_HALO, T_HALO_MIN_ROWS,
+  T_COUNT
+};
+int64_t tune(Tune t);                                                   // current value (environment LGS_<NAME> at start, lgs_tuning_set later)
+int dispatch_site(const char *kernel_text, const char *pretty_function);   // registers a launch site once -> its index
+void dispatch_hit(int site);
+// every kernel launch of the engine: counted per launch site (kernel expression + template bindings of the enclosing function)
+#define LGS_KLAUNCH(kernel, ...)                                                                 \
+  do {                                                                                           \
+    static const int _lgs_site = lgs::dispatch_site(#kernel, __PRETTY_FUNCTION__);               \
+    lgs::dispatch_hit(_lgs_site);                                                                \
+    hipLaunchKernelGGL(kernel, __VA_ARGS__);                                                     \
+  } while (0)
+
 constexpr int kPadRows = 256;  // every position array is padded to a multiple of this
 constexpr int kGroup = 64;     // rows per mask / tile_k entry (one wavefront of positions)
 

@@ -189,12 +189,7 @@ template <> __device__ inline float sq16<float>(const u32x4 &f, float s) {
 
 // ------------------------------------------------------------------------------------ forward / dgrad
 // Tile: WM x WN waves; each wave owns RB*32 positions x NCB*32 output channels.
-// PW = true (RB = 1, 3^3 maps): PER-WAVE OFFSET MASKS.  Every wave walks only the offsets at which ITS 32 rows have a neighbour
-// (ballot over the parked gather rows) -- in the tile-wide schedule 45 % of all gather instructions of the level-0 96 -> 96
-// launch were 32-row blocks without a single neighbour, issued as out-of-range loads to keep the schedule static, and the
-// kernel sits on the vector-memory instruction rate.  The weights stay tile-wide: slabs are staged for the offsets of the
-// TILE in the same order by everybody, a wave that has nothing at an offset just takes part in staging and barriers.
-template <typename T, int RB, int NCB, int WM, int WN, int SC, int D, int EPI = 0, bool PW = false>
+template <typename T, int RB, int NCB, int WM, int WN, int SC, int D, int EPI = 0>
 __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__restrict__ in, int cin_real, int nc,
                                                              const u32x4 *__restrict__ wp, int nb_total,
                                                              int ncp, int nbp,
@@ -205,7 +200,6 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
                                                              unsigned in_bytes, unsigned w_bytes, int64_t zstride,
                                                              ClipEpi ce, BnEpi be, int gc, int in_ld) {
   static_assert(EPI == 0 || (RB == 1 && WN == 1), "the CLIP epilogue owns whole rows: one row block, all columns per wave");
-  static_assert(!PW || (RB == 1 && EPI == 0), "per-wave offset masks: one 32-row block per wave");
   // SC = 32-channel chunks per weight SLAB: the weights of (offset, slab) are staged in LDS once per workgroup
   // and one barrier separates slabs, while the gathered feature fragments stream chunk by chunk through a
   // D-deep register ring (loads issued D-1 chunks = several hundred MFMA cycles ahead of their use) that runs
@@ -235,7 +229,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   // Eight-wave tiles (one 32-row block per wave) INTERLEAVE the tile's rows over the waves (row i -> wave i % 8): the
   // rows are sorted by neighbourhood shape, so contiguous blocks would leave whole waves without work at an offset while
   // the others run their MFMAs, and everybody meets at the next slab barrier.
-  constexpr bool ILV = (WM == 8 && RB == 1 && EPI == 0 && !PW);   // (per-wave masks want rows of one neighbourhood shape in one wave)
+  constexpr bool ILV = (WM == 8 && RB == 1 && EPI == 0);
   auto row_of = [&](int rb) __attribute__((always_inline)) { return ILV ? vx * WM + wm : wm * RB * 32 + rb * 32 + vx; };
   const int nb_wg = blockIdx.y * WB;  // first cout block of the workgroup
   const int nb_w = nb_wg + wn * NCB;  // first cout block of this wave
@@ -286,7 +280,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   // touches every gathered row in sixteen 64-byte pieces per offset and comes back to it ~14 offsets later: the rows of
   // the co-resident tiles plus 14 MB of weights do not fit the XCD's 4 MB L2 (PMC: L2 hit 51 %, 19x the compulsory HBM
   // bytes); with 128-channel groups a row's 256-byte segment serves all offsets back to back.
-  uint32_t fmask = smask;        // offsets the FEATURE side of this wave walks (PW: set below, once the gather rows are parked)
+  const uint32_t fmask = smask;  // offsets the feature side walks
   uint32_t rem = smask;
   int islot = -1, gbase = 0, gend = min(gc, nc), ichunk = gend;  // forces "advance to first slot" on the first call
   int32_t idx_i[RB];
@@ -407,8 +401,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   int ncs = 0;               // chunks in the current slab
   bool wnext = false;        // is a following slab prefetched in wreg?
   int issued = 0, computed = 0;
-  int rslot = -1, rslab = -1;   // PW: offset / slab index of the RESIDENT weight slab, and of the prefetched one
-  int pslot = -1, pslab = -1;
+  int pslab = -1;               // slab index of the prefetched weight slab
   // Prologue: the first weight slab and ALL index loads of the tile are in flight together, one barrier publishes
   // both (a slot-by-slot index copy loop was a chain of ~16 dependent global-load latencies at the head of every
   // workgroup -- a quarter of its lifetime -- and the first weight fetch only started behind it).
@@ -441,24 +434,10 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   if (whave) {
     wstage(0, wreg);
     ncs = min(SC, nc - wslab * SC);
-    rslot = wslot; rslab = wslab;
     wnext = wadvance();
-    if (wnext) { pslot = wslot; pslab = wslab; wissue(wreg); }
+    if (wnext) { pslab = wslab; wissue(wreg); }
   }
   __syncthreads();   // indices and the first weight slab are visible
-  if constexpr (PW) {
-    // offsets at which this wave's 32 rows have any neighbour
-    uint32_t wm_ = 0;
-#pragma unroll
-    for (int sl = 0; sl < 27; ++sl) {
-      if ((smask >> sl) & 1u) {
-        const bool ok = l_idx[sl * TM + row_of(0)] >= 0;
-        if (__ballot(ok) != 0ull) wm_ |= 1u << sl;
-      }
-    }
-    fmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)wm_);
-    rem = fmask;
-  }
   const int total = __builtin_popcount(fmask) * nc;  // chunks of this wave
 #pragma unroll
   for (int d = 0; d < D - 1; ++d) {
@@ -474,60 +453,10 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     cc = 0;
     if (wnext) {
       ncs = min(SC, nc - pslab * SC);
-      rslot = pslot; rslab = pslab;
       wnext = wadvance();
-      if (wnext) { pslot = wslot; pslab = wslab; wissue(wreg); }
-    } else {
-      rslot = -1;
+      if (wnext) { pslab = wslab; wissue(wreg); }
     }
   };
-  if constexpr (PW) {
-    // compute-side iterator of this wave (same sequence as advance(), D - 1 items behind it)
-    uint32_t crem = fmask;
-    int cslot = -1, cgbase = 0, cgend = min(gc, nc), cchunk = cgend;
-    auto cadvance = [&]() __attribute__((always_inline)) {
-      if (++cchunk < cgend) return;
-      if (crem == 0) {
-        cgbase = cgend;
-        if (cgbase >= nc) { cslot = -1; return; }
-        cgend = min(cgbase + gc, nc);
-        crem = fmask;
-      }
-      cslot = __builtin_ctz(crem);
-      crem &= crem - 1;
-      cchunk = cgbase;
-    };
-    if (total > 0) cadvance();
-    // walk the TILE's slabs until the one this wave's next item needs is resident (everybody crosses the same barriers)
-    auto seek = [&]() __attribute__((always_inline)) {
-      while (!(rslot == cslot && (cchunk / SC) == rslab)) slab_end();
-    };
-    while (total - issued >= D) {
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
-        seek();
-        advance();
-        issue(F[(d + D - 1) % D], act[(d + D - 1) % D]);
-        compute(buf, cchunk - rslab * SC, F[d], act[d]);
-        cadvance();
-      }
-      issued += D;
-      computed += D;
-    }
-    while (computed < total) {
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
-        if (computed < total) {
-          seek();
-          if (issued < total) { advance(); issue(F[(d + D - 1) % D], act[(d + D - 1) % D]); ++issued; }
-          compute(buf, cchunk - rslab * SC, F[d], act[d]);
-          cadvance();
-          ++computed;
-        }
-      }
-    }
-    while (rslot >= 0) slab_end();     // the tile's remaining slabs: staging duty and barriers only
-  } else {
   // steady state: every sub-step issues one chunk and computes one chunk UNCONDITIONALLY, so the compiler can
   // count outstanding loads (s_waitcnt vmcnt(N), N > 0) instead of draining the queue before every MFMA group
   while (total - issued >= D) {
@@ -552,7 +481,6 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
         if (++cc == ncs) slab_end();
       }
     }
-  }
   }
 
   if constexpr (EPI == 1) {
@@ -754,27 +682,18 @@ GatherCfg gather_cfg(const View &v, int nb_total) {
     if (nb_total >= 5 && nb_total <= 7 && v.nbr == nullptr) return {6, kF32 ? 1 : 2, 7, 128};
     if (nb_total == 1) return {0, kF32 ? 2 : 4, 1, 256};
     if (nb_total == 2) return {1, kF32 ? 2 : 4, 2, 256};
-    // id 20 (round 3, bf16 3^3 maps, LGS_PW=1): eight waves of 32 positions x 96 channels with PER-WAVE offset masks (no gather
-    // instructions for 32-row blocks without a neighbour).  Parity-green, measured SLOWER than the tile-wide schedule of id 2
-    // (L0 96 -> 96 forward 0.825 vs 0.645 ms stand-alone, step 31.7 vs 29.8 ms), so off by default
-    static const int pw_cfg = getenv("LGS_PW") ? atoi(getenv("LGS_PW")) : 0;   // experiment knob
-    if (!kF32 && pw_cfg && nb_total == 3 && v.KS > 1 && v.nbr != nullptr) return {20, 4, 3, 256};
     if (nb_total == 3 || (nb_total % 3 == 0 && nb_total % 4 != 0)) return {2, kF32 ? 2 : 4, 3, 256};
-    // wide outputs (>= 256 channels, e.g. the 512-d CLIP representation model): 256 positions x 256 channels per
-    // 8-wave workgroup -- every staged weight fragment serves two row blocks and the rows are gathered half as often
-    // (id 16: eight waves of 32 positions x 256 channels -- no two waves gather the same rows; id 15, the earlier 4 x 2
-    // wave layout with 64 x 128 per wave, stays selectable: LGS_WIDE_CFG=15.  512->512 at L0: 12.0 vs 12.2 ms, 256->256
-    // at L1: 1.00 vs 1.06 ms)
-    // id 17 (round 3): the 2-D blocked LDS-DMA kernel of lgs_conv_wide.hip; 15 / 16 stay selectable for A/B runs
-    static const int wide_cfg = getenv("LGS_WIDE_CFG") ? atoi(getenv("LGS_WIDE_CFG")) : 17;   // tuning knob
-    if (!kF32 && wide_cfg == 17 && (nb_total % 8 == 0 || nb_total >= 16) && !(v.KS == 1 && v.nbr == nullptr && nb_total < 16))
+    // wide outputs (>= 256 channels, e.g. the 512-d CLIP representation model): id 17 = the 2-D blocked LDS-DMA kernel of
+    // lgs_conv_wide.hip (round 3; L0 512 -> 512: 9.4 ms); id 16 = eight waves of 32 positions x 256 channels on this kernel
+    // (round 2: 12.0 ms; still what 1x1 layers below 512 output channels and CONV_WIDE=0 take)
+    if (!kF32 && tune(T_CONV_WIDE) != 0 && (nb_total % 8 == 0 || nb_total >= 16) && !(v.KS == 1 && v.nbr == nullptr && nb_total < 16))
       return {17, 2, 8, 256};
-    if (!kF32 && nb_total % 8 == 0) return {wide_cfg == 15 ? 15 : 16, 2, 8, 256};
+    if (!kF32 && nb_total % 8 == 0) return {16, 2, 8, 256};
     if (!kF32) return {7, 2, 4, 128};   // bf16: 128-position tiles, 4 column blocks per wave at 3 waves/SIMD
     return {3, kF32 ? 1 : 2, 4, 256};
   }
   if (nb_total == 1) return {4, kF32 ? 2 : 4, 1, 64};
-  static const int small_override = getenv("LGS_SMALL_CFG") ? atoi(getenv("LGS_SMALL_CFG")) : 0;  // tuning knob
+  const int small_override = (int)tune(T_SMALL_CFG);  // tuning knob
   if (!kF32 && small_override == 5) return {5, 4, 2, 64};
   if (!kF32 && small_override == 9) return {9, 4, 4, 64};
   if (!kF32 && small_override == 10) return {10, 4, 2, 64};
@@ -836,20 +755,19 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
   // bf16 storage only: the fp32 path is the parity mode and keeps ONE accumulator per output (a different summation
   // order moves results by ~1e-7, which BatchNorm over a handful of coarse rows with near-zero variance amplifies into
   // ReLU gate flips against the oracle -- measured on the 14A fixture)
-  static const bool no_split = getenv("LGS_NO_SPLIT") != nullptr;   // debugging knob (read once)
+  const bool no_split = tune(T_CONV_SPLIT) == 0;   // debugging knob
   const bool can_split = !no_split && sizeof(T) == 2 && zpartial && !out_f32 && v.KS > 1 && K == 27 && split_partial_bytes(K, v.n_out, cout_real) > 0;
   const int64_t zstride = v.n_out * (int64_t)cout_real;
   bool did_split = false;
   constexpr bool kF32 = (sizeof(T) == 4);
   // channel groups of the reduction (see the kernel): rows wider than 8 chunks (256 channels) are walked in 4-chunk groups
-  static const int gc_env = getenv("LGS_CONV_GC") ? atoi(getenv("LGS_CONV_GC")) : 0;   // tuning knob: 0 = automatic
-  const int gc = gc_env > 0 ? ((gc_env + 3) / 4 * 4) : (nc > 8 ? 4 : nc);
+  const int gc = nc > 8 ? 4 : nc;
 #define LGS_LAUNCH(RB, NCB, WM, WN, SC, D)                                                                        \
   do {                                                                                                            \
     dim3 grid((unsigned)(v.n_pad / (WM * RB * 32)), (unsigned)((nb_total + WN * NCB - 1) / (WN * NCB)));         \
     did_split = can_split && (int64_t)grid.x * grid.y < 600;   /* the chip holds >= 512 of these workgroups */    \
     if (did_split) grid.z = 3;                                                                                    \
-    hipLaunchKernelGGL((k_conv_gather<T, RB, NCB, WM, WN, SC, D>), grid, dim3(WM *WN * 64), 0, s, v, in, cin_real, nc,    \
+    LGS_KLAUNCH((k_conv_gather<T, RB, NCB, WM, WN, SC, D>), grid, dim3(WM *WN * 64), 0, s, v, in, cin_real, nc,    \
                        reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, out, cout_real, did_split ? nullptr : bias, \
                        did_split ? zpartial : out_f32, row_scale, in_bytes, w_bytes, zstride, ClipEpi(),           \
                        bn_epi(bn, did_split), gc, in_ld > 0 ? in_ld : cin_real);                                  \
@@ -870,16 +788,6 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
     case 4: LGS_LAUNCH(1, 1, 2, 1, (kF32 ? 2 : 4), (kF32 ? 4 : 8)); break;
     case 6: LGS_LAUNCH(1, 7, 4, 1, (kF32 ? 1 : 2), (kF32 ? 3 : 4)); break;
     case 7: LGS_LAUNCH(1, 4, 4, 1, 2, 4); break;
-    case 15: LGS_LAUNCH(2, 4, 4, 2, 2, 3); break;
-    case 20:
-      if constexpr (!kF32) {
-        dim3 grid((unsigned)(v.n_pad / 256), (unsigned)((nb_total + 2) / 3));
-        hipLaunchKernelGGL((k_conv_gather<T, 1, 3, 8, 1, 4, 6, 0, true>), grid, dim3(512), 0, s, v, in, cin_real, nc,
-                           reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, out, cout_real, bias, out_f32, row_scale, in_bytes,
-                           w_bytes, zstride, ClipEpi(), bn ? *bn : BnEpi(), gc, in_ld > 0 ? in_ld : cin_real);
-        if (bn_rows) *bn_rows = (int)grid.x;
-      }
-      break;
     case 16: LGS_LAUNCH(1, 8, 8, 1, 2, 4); break;
     case 8: LGS_LAUNCH(1, 2, 4, 1, 4, 6); break;
     case 9: LGS_LAUNCH(1, 2, 2, 2, 4, 6); break;
@@ -890,7 +798,7 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
 #undef LGS_LAUNCH
   if (did_split) {
     const int64_t n4 = zstride / 4;
-    if (n4 > 0) hipLaunchKernelGGL((k_sum_partials<T>), (unsigned)((n4 + 255) / 256), 256, 0, s, zpartial, n4, zstride, bias, cout_real, out,
+    if (n4 > 0) LGS_KLAUNCH((k_sum_partials<T>), (unsigned)((n4 + 255) / 256), 256, 0, s, zpartial, n4, zstride, bias, cout_real, out,
                                    (bn && bn->accum) ? 1 : 0);
   }
   LGS_HIP(hipGetLastError());
@@ -906,7 +814,7 @@ int bn_partial_rows_t(const View &v, int K, int o_real) {
   const GatherCfg cfg = gather_cfg<T>(v, nb_total);
   if (cfg.id == 17) return 0;        // the wide kernel has no statistics epilogue
   const int64_t gx = v.n_pad / cfg.tm, gy = (nb_total + cfg.wb - 1) / cfg.wb;
-  static const bool no_split = getenv("LGS_NO_SPLIT") != nullptr;
+  const bool no_split = tune(T_CONV_SPLIT) == 0;
   const bool split = sizeof(T) == 2 && !no_split && v.KS > 1 && K == 27 &&
                      split_partial_bytes(K, v.n_out, o_real) > 0 && gx * gy < 600;
   return split ? 0 : (int)gx;
@@ -944,7 +852,7 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
     if (rc) return rc;
     int64_t tot = v.n_out * (int64_t)o_real;
     if (tot > 0)
-      hipLaunchKernelGGL((k_unpad_rows<T>), (unsigned)((tot + 255) / 256), 256, 0, s, tmp, v.n_out, o_real, o4,
+      LGS_KLAUNCH((k_unpad_rows<T>), (unsigned)((tot + 255) / 256), 256, 0, s, tmp, v.n_out, o_real, o4,
                          reinterpret_cast<T *>(out_v));
     LGS_HIP(hipGetLastError());
     return 0;
@@ -957,7 +865,7 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
     T *padded = reinterpret_cast<T *>(ws + wbytes);
     const int g_al = (g_real + EPL - 1) / EPL * EPL;
     int64_t tot = v.n_in * g_al;
-    if (tot > 0) hipLaunchKernelGGL((k_pad_rows<T>), (unsigned)((tot + 255) / 256), 256, 0, s, in, v.n_in, g_real, g_al, padded);
+    if (tot > 0) LGS_KLAUNCH((k_pad_rows<T>), (unsigned)((tot + 255) / 256), 256, 0, s, in, v.n_in, g_real, g_al, padded);
     in = padded;
     g_stride = g_al;
   }
@@ -966,7 +874,7 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
   if (packed_ext && o_real % 4 == 0 && g_real % EPL == 0) wp = reinterpret_cast<uint4 *>(packed_ext);
   else pack_mode = 0;
   if (pack_mode != 2)
-    hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, weight, K, cin_w, cout_w, transposed_w,
+    LGS_KLAUNCH((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, weight, K, cin_w, cout_w, transposed_w,
                        v.mirror, g_real, w_o_real, ncp, nbp, wp);
   LGS_HIP(hipGetLastError());
   // fp32 partial images of the slot split live behind the packed weights and the padded input
@@ -1025,15 +933,15 @@ int clip_similarity_t(const void *feat, int64_t n, int c, const float *anchors, 
   off += align256((int64_t)(nc + 3) * (nb_total + 3) * LD * 64 * 16);
   float *inv = inv_norm_f ? inv_norm_f : reinterpret_cast<float *>(ws + off);
   const T *f = reinterpret_cast<const T *>(feat);
-  hipLaunchKernelGGL(k_normalize_anchors, na, 64, 0, s, anchors, na, c, tn);
+  LGS_KLAUNCH(k_normalize_anchors, na, 64, 0, s, anchors, na, c, tn);
   View v;
   v.n_pad = pad_rows(n); v.n_out = n; v.n_in = n; v.KS = 1; v.K = 1;
   const GatherCfg cfg = gather_cfg<T>(v, nb_total);
   const int ncp = (nc + cfg.sc - 1) / cfg.sc * cfg.sc, nbp = (nb_total + cfg.wb - 1) / cfg.wb * cfg.wb;
   int64_t total = (int64_t)ncp * nbp * LD * 64;
   // T^[a][c] read as w[o = a][g = c]  ("transposed" form of the packer with cin_w = na, cout_w = c)
-  hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, tn, 1, na, c, 1, 0, c, na, ncp, nbp, wp);
-  hipLaunchKernelGGL((k_row_invnorm<T>), (unsigned)((n * 64 + 255) / 256), 256, 0, s, f, n, c, inv);
+  LGS_KLAUNCH((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, tn, 1, na, c, 1, 0, c, na, ncp, nbp, wp);
+  LGS_KLAUNCH((k_row_invnorm<T>), (unsigned)((n * 64 + 255) / 256), 256, 0, s, f, n, c, inv);
   LGS_HIP(hipGetLastError());
   return launch_gather<T>(v, cfg, f, c, nc, wp, nb_total, ncp, nbp, 1, (T *)nullptr, na, nullptr, s, sim, inv);
 }
@@ -1055,10 +963,10 @@ int clip_loss_forward_t(const void *feat, int64_t n, int c, const float *anchors
   const int ncp = (nc + sc - 1) / sc * sc, nbp = ncb;
   char *ws = reinterpret_cast<char *>(workspace);
   uint4 *wp = reinterpret_cast<uint4 *>(ws);
-  hipLaunchKernelGGL(k_normalize_anchors, na, 64, 0, s, anchors, na, c, anchors_n);
+  LGS_KLAUNCH(k_normalize_anchors, na, 64, 0, s, anchors, na, c, anchors_n);
   int64_t total = (int64_t)ncp * nbp * LD * 64;
   // T^[a][c] read as w[o = a][g = c]  ("transposed" form of the packer with cin_w = na, cout_w = c)
-  hipLaunchKernelGGL((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, anchors_n, 1, na, c, 1, 0, c, na, ncp, nbp, wp);
+  LGS_KLAUNCH((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, anchors_n, 1, na, c, 1, 0, c, na, ncp, nbp, wp);
   View v;
   v.n_pad = pad_rows(n); v.n_out = n; v.n_in = n; v.KS = 1; v.K = 1;
   const uint64_t in_bytes64 = (uint64_t)n * (uint64_t)c * sizeof(T), w_bytes64 = (uint64_t)total * 16;
@@ -1068,7 +976,7 @@ int clip_loss_forward_t(const void *feat, int64_t n, int c, const float *anchors
   const T *f = reinterpret_cast<const T *>(feat);
   dim3 grid((unsigned)(v.n_pad / 128), 1);
 #define LGS_CLIP(NCB, SC, D)                                                                                              \
-  hipLaunchKernelGGL((k_conv_gather<T, 1, NCB, 4, 1, SC, D, 1>), grid, dim3(256), 0, s, v, f, c, nc,                      \
+  LGS_KLAUNCH((k_conv_gather<T, 1, NCB, 4, 1, SC, D, 1>), grid, dim3(256), 0, s, v, f, c, nc,                      \
                      reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, (T *)nullptr, na, (const float *)nullptr, sim, \
                      (const float *)nullptr, (unsigned)in_bytes64, (unsigned)w_bytes64, (int64_t)0, ce, BnEpi(), nc, c)
   switch (ncb) {
@@ -1140,7 +1048,7 @@ int lgs_conv_pack_desc(const lgs_kmap *km, int op, int transposed, int cin, int 
 int lgs_pack_weights_batch(const lgs_pack_desc *descs_device, int n, int64_t max_total, void *stream) {
   LGS_REQUIRE(descs_device && n > 0 && max_total > 0, "lgs_pack_weights_batch: bad argument");
   dim3 grid((unsigned)((max_total + 255) / 256), (unsigned)n);
-  hipLaunchKernelGGL(k_pack_weights_batch, grid, 256, 0, (hipStream_t)stream, descs_device);
+  LGS_KLAUNCH(k_pack_weights_batch, grid, 256, 0, (hipStream_t)stream, descs_device);
   LGS_HIP(hipGetLastError());
   return 0;
 }

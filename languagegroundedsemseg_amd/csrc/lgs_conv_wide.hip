@@ -448,24 +448,24 @@ int launch_conv_wide(const View &v, const void *in, int cin_real, int in_ld, con
   }
   const int nc64 = (cin_real + 63) / 64, ny = nbp / 8;
   // knock-out builds for attribution (results are wrong): 1 = no LDS reads / MFMAs, 4 = no gathers, 8 = no weight DMA
-  static const int dbg = getenv("LGS_WIDE_DBG") ? atoi(getenv("LGS_WIDE_DBG")) : 0;
-  static const int gc_env = getenv("LGS_WIDE_GC64") ? atoi(getenv("LGS_WIDE_GC64")) : 1;   // tuning knob: 64-channel stages per reduction group
+  const int dbg = (int)tune(T_WIDE_DBG);
+  const int gc_env = (int)tune(T_WIDE_GC64);   // tuning knob: 64-channel stages per reduction group
   gc64 = gc_env > 0 ? gc_env : gc64;
   unsigned nwg = (unsigned)(v.n_pad / kWideTM) * (unsigned)ny;
   if (8 % ny == 0) {      // every XCD owns one channel tile and a slice of the position tiles (see the kernel): pad the slices
     const unsigned ntile = (unsigned)(v.n_pad / kWideTM), g = 8u / (unsigned)ny, per = (ntile + g - 1) / g;
     nwg = per * 8u;
   }
-  static const bool want_trace = getenv("LGS_WIDE_TRACE") != nullptr;      // debug: per-phase shader-clock sums of one workgroup
+  const bool want_trace = tune(T_WIDE_TRACE) != 0;      // debug: per-phase shader-clock sums of one workgroup
   static unsigned long long *trace = nullptr;
   if (want_trace && !trace) { LGS_HIP(hipMalloc(&trace, 12 * sizeof(unsigned long long))); }
   if (want_trace) LGS_HIP(hipMemsetAsync(trace, 0, 12 * sizeof(unsigned long long), s));
   if (want_trace || dbg != 0)
-    hipLaunchKernelGGL(k_conv_wide<true>, dim3(nwg), dim3(512), kWideLds, s, v, reinterpret_cast<const bf16_t *>(in), cin_real, nc64,
+    LGS_KLAUNCH(k_conv_wide<true>, dim3(nwg), dim3(512), kWideLds, s, v, reinterpret_cast<const bf16_t *>(in), cin_real, nc64,
                        reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, reinterpret_cast<bf16_t *>(out), cout_real, bias,
                        (unsigned)in_bytes64, (unsigned)w_bytes64, ld, gc64 > 0 ? gc64 : nc64, ny, dbg, trace);
   else
-    hipLaunchKernelGGL(k_conv_wide<false>, dim3(nwg), dim3(512), kWideLds, s, v, reinterpret_cast<const bf16_t *>(in), cin_real, nc64,
+    LGS_KLAUNCH(k_conv_wide<false>, dim3(nwg), dim3(512), kWideLds, s, v, reinterpret_cast<const bf16_t *>(in), cin_real, nc64,
                        reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, reinterpret_cast<bf16_t *>(out), cout_real, bias,
                        (unsigned)in_bytes64, (unsigned)w_bytes64, ld, gc64 > 0 ? gc64 : nc64, ny, dbg, trace);
   LGS_HIP(hipGetLastError());

@@ -123,10 +123,10 @@ extern "C" int lgs_ce_forward_backward(const void *logits, int64_t n, int c, con
   hipStream_t s = (hipStream_t)stream;
   const unsigned blocks = (unsigned)((n * 32 + 255) / 256);
   if (dtype == LGS_F32)
-    hipLaunchKernelGGL((k_ce_fwd_bwd<float>), blocks, 256, 0, s, (const float *)logits, n, c, labels, ignore_index, scale, loss_rows,
+    LGS_KLAUNCH((k_ce_fwd_bwd<float>), blocks, 256, 0, s, (const float *)logits, n, c, labels, ignore_index, scale, loss_rows,
                        (float *)dlogits);
   else if (dtype == LGS_BF16)
-    hipLaunchKernelGGL((k_ce_fwd_bwd<bf16_t>), blocks, 256, 0, s, (const bf16_t *)logits, n, c, labels, ignore_index, scale, loss_rows,
+    LGS_KLAUNCH((k_ce_fwd_bwd<bf16_t>), blocks, 256, 0, s, (const bf16_t *)logits, n, c, labels, ignore_index, scale, loss_rows,
                        (bf16_t *)dlogits);
   else
     LGS_REQUIRE(false, "lgs_ce_forward_backward: unknown dtype");
@@ -201,10 +201,10 @@ extern "C" int lgs_clip_loss_backward(const void *feat, int64_t n, int c, const 
   const int64_t threads = n * (int64_t)(c / W);
   const unsigned blocks = (unsigned)((threads + 255) / 256);
   if (dtype == LGS_F32)
-    hipLaunchKernelGGL((k_clip_loss_bwd<float>), blocks, 256, 0, s, (const float *)feat, n, c, anchors_n, n_anchor, labels, neg, k_neg,
+    LGS_KLAUNCH((k_clip_loss_bwd<float>), blocks, 256, 0, s, (const float *)feat, n, c, anchors_n, n_anchor, labels, neg, k_neg,
                        ignore_label, inv_norm_f, d_pos, d_neg, g_dpos, g_dneg, (float *)grad_feat);
   else if (dtype == LGS_BF16)
-    hipLaunchKernelGGL((k_clip_loss_bwd<bf16_t>), blocks, 256, 0, s, (const bf16_t *)feat, n, c, anchors_n, n_anchor, labels, neg,
+    LGS_KLAUNCH((k_clip_loss_bwd<bf16_t>), blocks, 256, 0, s, (const bf16_t *)feat, n, c, anchors_n, n_anchor, labels, neg,
                        k_neg, ignore_label, inv_norm_f, d_pos, d_neg, g_dpos, g_dneg, (bf16_t *)grad_feat);
   else
     LGS_REQUIRE(false, "lgs_clip_loss_backward: unknown dtype");
@@ -253,7 +253,7 @@ extern "C" int lgs_sgd_step(float *params, const float *grads, float *momentum_b
                 reinterpret_cast<uintptr_t>(mask)) & 15u) == 0, "lgs_sgd_step: buffers must be 16-byte aligned");
   if (n == 0) return 0;
   const int64_t threads = (n + 3) / 4;
-  hipLaunchKernelGGL(lgs::k_sgd_step, (unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream, params, grads, momentum_buf,
+  LGS_KLAUNCH(lgs::k_sgd_step, (unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream, params, grads, momentum_buf,
                      mask, n, lr, momentum, dampening, weight_decay, first_step);
   LGS_HIP(hipGetLastError());
   return 0;

@@ -443,7 +443,7 @@ int arena_acquire(lgs_manager *m) {
     if (q[i].cap >= need) {
       ArenaBlock b = q[i];
       q.erase(q.begin() + (long)i);
-      if (getenv("LGS_ARENA_DBG")) {
+      if (tune(T_ARENA_DBG)) {
         int pending = 0;
         for (hipEvent_t e : b.ready) pending += hipEventQuery(e) == hipSuccess ? 0 : 1;
         fprintf(stderr, "[arena] reuse block %zu of %zu (cap %zu MB, need %zu MB): %d of %zu events still pending\n", i, q.size() + 1, b.cap >> 20,
@@ -461,7 +461,7 @@ int arena_acquire(lgs_manager *m) {
     }
   }
   const size_t cap = (need + need / 4 + (2u << 20)) / (2u << 20) * (2u << 20);
-  if (getenv("LGS_ARENA_DBG")) fprintf(stderr, "[arena] hipMalloc %zu MB (need %zu MB, %zu queued)\n", cap >> 20, need >> 20, q.size());
+  if (tune(T_ARENA_DBG)) fprintf(stderr, "[arena] hipMalloc %zu MB (need %zu MB, %zu queued)\n", cap >> 20, need >> 20, q.size());
   void *p = nullptr;
   if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return 0; }   // no block: this manager uses the pool
   m->arena = reinterpret_cast<char *>(p); m->arena_cap = cap;
@@ -512,9 +512,9 @@ int ensure_hash(lgs_manager *m, CoordMap &cm, hipStream_t s) {
   cm.hcap = cap;
   if (dalloc(m, &cm.hkeys, cap, s)) return 1;
   if (dalloc(m, &cm.hvals, cap, s)) return 1;
-  hipLaunchKernelGGL(k_hash_fill, nblk(cap), 256, 0, s, cm.hkeys, cap);
+  LGS_KLAUNCH(k_hash_fill, nblk(cap), 256, 0, s, cm.hkeys, cap);
   if (cm.n > 0)
-    hipLaunchKernelGGL(k_hash_insert, nblk(cm.n), 256, 0, s, cm.skeys, cm.order, cm.n, cm.hkeys, cm.hvals,
+    LGS_KLAUNCH(k_hash_insert, nblk(cm.n), 256, 0, s, cm.skeys, cm.order, cm.n, cm.hkeys, cm.hvals,
                        (uint64_t)(cap - 1));
   LGS_HIP(hipGetLastError());
   return 0;
@@ -613,7 +613,7 @@ int lgs_manager_insert(lgs_manager *m, const int32_t *coords, int64_t n, int64_t
   if (dalloc(m, &keys, n, s) || dalloc(m, &skeys, n, s) || dalloc(m, &vals, n, s) || dalloc(m, &svals, n, s) ||
       dalloc(m, &head, n, s) || dalloc(m, &runid, n, s) || dalloc(m, &is_first, n, s) || dalloc(m, &urow, n + 1, s))
     return 1;
-  hipLaunchKernelGGL(k_pack_keys, nblk(n), 256, 0, s, coords, n, keys, vals, m->d_err);
+  LGS_KLAUNCH(k_pack_keys, nblk(n), 256, 0, s, coords, n, keys, vals, m->d_err);
   {
     size_t tb = 0;
     LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, skeys, vals, svals, (size_t)n, 0, 64, s));
@@ -622,8 +622,8 @@ int lgs_manager_insert(lgs_manager *m, const int32_t *coords, int64_t n, int64_t
     LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, keys, skeys, vals, svals, (size_t)n, 0, 64, s));
     if (dfree_now(m, tmp, s)) return 1;
   }
-  hipLaunchKernelGGL(k_heads, nblk(n), 256, 0, s, skeys, n, ~0ull, head);
-  hipLaunchKernelGGL(k_mark_first, nblk(n), 256, 0, s, svals, head, n, is_first);
+  LGS_KLAUNCH(k_heads, nblk(n), 256, 0, s, skeys, n, ~0ull, head);
+  LGS_KLAUNCH(k_mark_first, nblk(n), 256, 0, s, svals, head, n, is_first);
   if (scan_incl(m, head, runid, n, s)) return 1;
   {  // exclusive scan of is_first = inclusive shifted: urow[0]=0, urow[i+1] = incl[i]
     LGS_HIP(hipMemsetAsync(urow, 0, sizeof(int32_t), s));
@@ -638,9 +638,9 @@ int lgs_manager_insert(lgs_manager *m, const int32_t *coords, int64_t n, int64_t
   int64_t nu = h_nu;
   cm.n = nu; cm.n_pad = pad_rows(nu);
   if (dalloc(m, &cm.coords, nu * 4, s) || dalloc(m, &cm.order, nu, s) || dalloc(m, &cm.skeys, nu, s)) return 1;
-  hipLaunchKernelGGL(k_emit_unique, nblk(n), 256, 0, s, coords, is_first, urow, n, cm.coords, unique_index);
-  hipLaunchKernelGGL(k_emit_sorted, nblk(n), 256, 0, s, skeys, svals, head, runid, urow, n, cm.skeys, cm.order);
-  if (inverse) hipLaunchKernelGGL(k_emit_inverse, nblk(n), 256, 0, s, svals, runid, cm.order, n, inverse);
+  LGS_KLAUNCH(k_emit_unique, nblk(n), 256, 0, s, coords, is_first, urow, n, cm.coords, unique_index);
+  LGS_KLAUNCH(k_emit_sorted, nblk(n), 256, 0, s, skeys, svals, head, runid, urow, n, cm.skeys, cm.order);
+  if (inverse) LGS_KLAUNCH(k_emit_inverse, nblk(n), 256, 0, s, svals, runid, cm.order, n, inverse);
   LGS_HIP(hipGetLastError());
   if (dfree_now(m, keys, s) || dfree_now(m, skeys, s) || dfree_now(m, vals, s) || dfree_now(m, svals, s) ||
       dfree_now(m, head, s) || dfree_now(m, runid, s) || dfree_now(m, is_first, s) || dfree_now(m, urow, s))
@@ -674,7 +674,7 @@ int lgs_manager_stride2(lgs_manager *m, int in_key, void *stream, int *out_key, 
   uint64_t keep = ~(7ull << (3 * f.log2ts));
   int32_t *head, *cincl;
   if (dalloc(m, &head, n, s) || dalloc(m, &cincl, n, s)) return 1;
-  hipLaunchKernelGGL(k_heads, nblk(n), 256, 0, s, f.skeys, n, keep, head);
+  LGS_KLAUNCH(k_heads, nblk(n), 256, 0, s, f.skeys, n, keep, head);
   if (scan_incl(m, head, cincl, n, s)) return 1;
   int32_t h_nc = 0;
   LGS_HIP(hipMemcpyAsync(&h_nc, cincl + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -684,7 +684,7 @@ int lgs_manager_stride2(lgs_manager *m, int in_key, void *stream, int *out_key, 
   if (dalloc(m, &c.coords, nc * 4, s) || dalloc(m, &c.skeys, nc, s) || dalloc(m, &c.cstart, nc + 1, s) ||
       dalloc(m, &c.fine_cidx, n, s))
     return 1;
-  hipLaunchKernelGGL(k_emit_coarse, nblk(n), 256, 0, s, f.skeys, head, cincl, n, keep, c.skeys, c.coords, c.cstart,
+  LGS_KLAUNCH(k_emit_coarse, nblk(n), 256, 0, s, f.skeys, head, cincl, n, keep, c.skeys, c.coords, c.cstart,
                      c.fine_cidx);
   LGS_HIP(hipGetLastError());
   if (dfree_now(m, head, s) || dfree_now(m, cincl, s)) return 1;
@@ -748,10 +748,10 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
           dalloc(m, &nbr_tmp, 27 * ci.n_pad, s) || dalloc(m, &pmask, ci.n_pad, s) || dalloc(m, &keys, ci.n_pad, s) ||
           dalloc(m, &skeys2, ci.n_pad, s) || dalloc(m, &vals, ci.n_pad, s) || dalloc(m, &perm, ci.n_pad, s))
         return 1;
-      hipLaunchKernelGGL(k_build_map3, (unsigned)(ci.n_pad / 256), 256, 0, s, ci.skeys, ci.n, ci.n_pad, ci.ts, ci.hkeys,
+      LGS_KLAUNCH(k_build_map3, (unsigned)(ci.n_pad / 256), 256, 0, s, ci.skeys, ci.n, ci.n_pad, ci.ts, ci.hkeys,
                          ci.hvals, (uint64_t)(ci.hcap - 1), nbr_tmp, pmask);
-      static const int window = getenv("LGS_MASK_WINDOW") ? atoi(getenv("LGS_MASK_WINDOW")) : kMaskWindow;   // tuning knob
-      hipLaunchKernelGGL(k_mask_sort_keys, (unsigned)(ci.n_pad / 256), 256, 0, s, pmask, ci.n, ci.n_pad, window, keys, vals);
+      const int window = (int)tune(T_MASK_WINDOW);   // tuning knob (default kMaskWindow)
+      LGS_KLAUNCH(k_mask_sort_keys, (unsigned)(ci.n_pad / 256), 256, 0, s, pmask, ci.n, ci.n_pad, window, keys, vals);
       {
         size_t tb = 0;
         LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, 64, s));
@@ -760,7 +760,7 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
         LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, 64, s));
         if (dfree_now(m, tmp, s)) return 1;
       }
-      hipLaunchKernelGGL(k_permute_map3, (unsigned)(ci.n_pad / 256), 256, 0, s, nbr_tmp, pmask, perm, ci.order, ci.n, ci.n_pad,
+      LGS_KLAUNCH(k_permute_map3, (unsigned)(ci.n_pad / 256), 256, 0, s, nbr_tmp, pmask, perm, ci.order, ci.n, ci.n_pad,
                          nbr, orow, mask);
       LGS_HIP(hipGetLastError());
       if (dfree_now(m, nbr_tmp, s) || dfree_now(m, pmask, s) || dfree_now(m, keys, s) || dfree_now(m, skeys2, s) ||
@@ -782,7 +782,7 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
     if (ci.n > 0) {
       int32_t *nbr8; uint32_t *mask;
       if (dalloc(m, &nbr8, 8 * co.n_pad, s) || dalloc(m, &mask, co.n_pad / kGroup, s)) return 1;
-      hipLaunchKernelGGL(k_build_map2_coarse, (unsigned)(co.n_pad / 256), 256, 0, s, ci.skeys, ci.order, co.cstart, co.n,
+      LGS_KLAUNCH(k_build_map2_coarse, (unsigned)(co.n_pad / 256), 256, 0, s, ci.skeys, ci.order, co.cstart, co.n,
                          co.n_pad, shift, nbr8, mask);
       vf.nbr = nbr8; vf.mask64 = mask;
       // grouped fine view
@@ -793,7 +793,7 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
           dalloc(m, &g_out, gp, s) || dalloc(m, &tile_k, gp / kGroup, s))
         return 1;
       LGS_HIP(hipMemsetAsync(cnt, 0, 8 * sizeof(int32_t), s));
-      hipLaunchKernelGGL(k_child_keys, nblk(n), 256, 0, s, ci.skeys, n, shift, kk, pp, cnt);
+      LGS_KLAUNCH(k_child_keys, nblk(n), 256, 0, s, ci.skeys, n, shift, kk, pp, cnt);
       {
         size_t tb = 0;
         LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, kk, kks, pp, pps, (size_t)n, 0, 3, s));
@@ -802,11 +802,11 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
         LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, kk, kks, pp, pps, (size_t)n, 0, 3, s));
         if (dfree_now(m, tmp, s)) return 1;
       }
-      hipLaunchKernelGGL(k_group_offsets, 1, 64, 0, s, cnt, goff, gsrc);
-      hipLaunchKernelGGL(k_fill_i32, nblk(gp), 256, 0, s, g_nbr, gp, -1);
-      hipLaunchKernelGGL(k_fill_i32, nblk(gp), 256, 0, s, g_out, gp, -1);
-      hipLaunchKernelGGL(k_fill_i32, nblk(gp / kGroup), 256, 0, s, tile_k, gp / kGroup, -1);
-      hipLaunchKernelGGL(k_build_map2_fine, nblk(n), 256, 0, s, kks, pps, n, goff, gsrc, co.fine_cidx, ci.order, g_nbr,
+      LGS_KLAUNCH(k_group_offsets, 1, 64, 0, s, cnt, goff, gsrc);
+      LGS_KLAUNCH(k_fill_i32, nblk(gp), 256, 0, s, g_nbr, gp, -1);
+      LGS_KLAUNCH(k_fill_i32, nblk(gp), 256, 0, s, g_out, gp, -1);
+      LGS_KLAUNCH(k_fill_i32, nblk(gp / kGroup), 256, 0, s, tile_k, gp / kGroup, -1);
+      LGS_KLAUNCH(k_build_map2_fine, nblk(n), 256, 0, s, kks, pps, n, goff, gsrc, co.fine_cidx, ci.order, g_nbr,
                          g_out, tile_k);
       LGS_HIP(hipGetLastError());
       vb.nbr = g_nbr; vb.out_row = g_out; vb.tile_k = tile_k; vb.n_pad = gp;
@@ -836,8 +836,8 @@ int lgs_kmap_export(lgs_kmap *km, int32_t *ek, int32_t *ein, int32_t *eout, void
   if (raw_alloc(m, (void **)&cnt, sizeof(int32_t), s)) return 1;
   LGS_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), s));
   if (v.n_pad > 0) {
-    if (ek) hipLaunchKernelGGL(k_view_export, nblk(v.n_pad), 256, 0, s, v, cnt, ek, ein, eout);
-    else hipLaunchKernelGGL(k_view_count, nblk(v.n_pad), 256, 0, s, v, cnt);
+    if (ek) LGS_KLAUNCH(k_view_export, nblk(v.n_pad), 256, 0, s, v, cnt, ek, ein, eout);
+    else LGS_KLAUNCH(k_view_count, nblk(v.n_pad), 256, 0, s, v, cnt);
   }
   int32_t h = 0;
   LGS_HIP(hipMemcpyAsync(&h, cnt, sizeof(int32_t), hipMemcpyDeviceToHost, s));

@@ -713,15 +713,40 @@ inline unsigned *fused_counter() {
   return ring[dev] + (next[dev].fetch_add(1) % kCtrSlots);
 }
 inline bool bn_fused_on(int64_t tensor_bytes) {
-  static const bool on = getenv("LGS_BN_FUSED") == nullptr || atoi(getenv("LGS_BN_FUSED")) != 0;   // A/B knob: 0 = three launches
+  const bool on = tune(T_BN_FUSED) != 0;   // A/B knob: 0 = three launches
   // above ~24 MB a direction is bandwidth-bound and the three-launch path's 4096-workgroup apply streams faster than 512
   // resident workgroups can (1.2 M rows x 96 ch bf16 forward: 0.135 ms vs 0.181 ms fused); below, launches dominate
-  static const int64_t max_mb = getenv("LGS_BN_FUSED_MAX_MB") ? atoll(getenv("LGS_BN_FUSED_MAX_MB")) : 24;
+  const int64_t max_mb = tune(T_BN_FUSED_MAX_MB);
   return on && tensor_bytes <= (max_mb << 20);
 }
-inline int fused_blocks(int64_t n, int64_t *rows_per_block) {
-  static const int cap_env = getenv("LGS_BN_FUSED_BLOCKS") ? atoi(getenv("LGS_BN_FUSED_BLOCKS")) : 0;   // tuning knob
-  const int cap = cap_env > 0 && cap_env < kFusedMaxBlocks ? cap_env : kFusedMaxBlocks;
+// Workgroups a grid-barrier kernel may be launched with: every one of them must be RESIDENT at the same time, or the resident
+// ones spin on the barrier for workgroups the dispatcher can never place (a hard GPU hang).  The bound is the kernel's own
+// occupancy on THIS device x its CU count (a CPX partition of the chip has 32-38 CUs, not 256), halved for headroom against
+// another stream's kernels holding CUs, cached per (device, kernel).  Below 16 the fused path is not worth it: 0 = use the
+// three-launch path.  What this cannot see: HSA_CU_MASK-style external masks and other PROCESSES on the same GPU -- those
+// setups must run with the tuning knob BN_FUSED=0 (bench.py --same-device does).
+inline int fused_cap(const void *kernel) {
+  static std::mutex mu;
+  static std::vector<std::pair<std::pair<int, const void *>, int>> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto &e : cache)
+    if (e.first.first == dev && e.first.second == kernel) return e.second;
+  int per_cu = 0, cus = 0, cap = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kNT, 0) == hipSuccess &&
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+    cap = per_cu * cus / 2;
+  else
+    (void)hipGetLastError();
+  if (cap > kFusedMaxBlocks) cap = kFusedMaxBlocks;
+  if (cap < 16) cap = 0;
+  cache.push_back({{dev, kernel}, cap});
+  return cap;
+}
+inline int fused_blocks(int64_t n, int64_t *rows_per_block, int cap) {
+  const int cap_env = (int)tune(T_BN_FUSED_BLOCKS);   // tuning knob: 0 = the device bound
+  if (cap_env > 0 && cap_env < cap) cap = cap_env;
   int64_t nb = (n + 127) / 128;
   if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
@@ -739,13 +764,13 @@ int stats_partials(const T *x, int64_t n, int c, const float *partials, int part
     int nb = partial_rows < 128 ? partial_rows : 128;
     const int rpb = (partial_rows + nb - 1) / nb;
     nb = (partial_rows + rpb - 1) / rpb;
-    hipLaunchKernelGGL(k_partial_reduce, nb, 256, 0, s, partials, partial_rows, 2 * c, rpb, scratch);
+    LGS_KLAUNCH(k_partial_reduce, nb, 256, 0, s, partials, partial_rows, 2 * c, rpb, scratch);
     *nb_out = nb;
     return 0;
   }
   int64_t rpb;
   const int nb = reduce_blocks(n, &rpb);
-  hipLaunchKernelGGL((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, n, c, 0,
+  LGS_KLAUNCH((k_colreduce<T, 0>), nb, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, n, c, 0,
                      rpb, scratch, (int64_t)c, (int64_t)c);
   *nb_out = nb;
   return 0;
@@ -761,29 +786,30 @@ int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const flo
   float *scratch = reinterpret_cast<float *>(workspace);  // caller-owned: no allocator call (and no implicit sync) here
   const T *x = reinterpret_cast<const T *>(xv);
   const int pm = (partials && partial_rows > 0) ? 1 : 0;
-  if (bn_fused_on(n * (int64_t)c * (int64_t)sizeof(T))) {
+  const int fcap = bn_fused_on(n * (int64_t)c * (int64_t)sizeof(T)) ? fused_cap(reinterpret_cast<const void *>(&k_bn_fwd_fused<T>)) : 0;
+  if (fcap > 0) {
     unsigned *ctr = fused_counter();
     LGS_REQUIRE(ctr != nullptr, "lgs_bn_forward: could not allocate the grid-barrier counters");
     int64_t rpb;
-    const int grid = fused_blocks(n, &rpb);
+    const int grid = fused_blocks(n, &rpb, fcap);
     int prpb = 0, nfold = grid;
     if (pm) {
       int pnb = partial_rows < 128 ? partial_rows : 128;
       prpb = (partial_rows + pnb - 1) / pnb;
       nfold = (partial_rows + prpb - 1) / prpb;
     }
-    hipLaunchKernelGGL((k_bn_fwd_fused<T>), grid, kNT, 0, s, x, reinterpret_cast<const T *>(res), n, c, gamma, beta, eps, momentum, rm, rv, nbt,
+    LGS_KLAUNCH((k_bn_fwd_fused<T>), grid, kNT, 0, s, x, reinterpret_cast<const T *>(res), n, c, gamma, beta, eps, momentum, rm, rv, nbt,
                        stats, relu, reinterpret_cast<T *>(yv), y_ld, scratch, pm ? partials : (const float *)nullptr, partial_rows, prpb, nfold,
                        pivot, rpb, ctr);
     LGS_HIP(hipGetLastError());
     return 0;
   }
   stats_partials<T>(x, n, c, partials, partial_rows, scratch, s, &nb);
-  hipLaunchKernelGGL((k_fold_fwd<T>), (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, x, nb, c, n, eps, momentum, rm, rv, nbt, stats, pm, pivot);
+  LGS_KLAUNCH((k_fold_fwd<T>), (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, x, nb, c, n, eps, momentum, rm, rv, nbt, stats, pm, pivot);
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
-    hipLaunchKernelGGL((k_bn_apply<T>), grid, kNT, 0, s, x, reinterpret_cast<const T *>(res), n, c, gamma, beta, stats, relu,
+    LGS_KLAUNCH((k_bn_apply<T>), grid, kNT, 0, s, x, reinterpret_cast<const T *>(res), n, c, gamma, beta, stats, relu,
                        reinterpret_cast<T *>(yv), y_ld);
   }
   LGS_HIP(hipGetLastError());
@@ -801,23 +827,24 @@ int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, in
   float *scratch = reinterpret_cast<float *>(workspace);
   float *sums = scratch + (size_t)2 * c * nb;
   const T *x = reinterpret_cast<const T *>(xv), *y = reinterpret_cast<const T *>(yv), *dy = reinterpret_cast<const T *>(dyv);
-  if (bn_fused_on(n * (int64_t)c * (int64_t)sizeof(T))) {
+  const int fcap = bn_fused_on(n * (int64_t)c * (int64_t)sizeof(T)) ? fused_cap(reinterpret_cast<const void *>(&k_bn_bwd_fused<T>)) : 0;
+  if (fcap > 0) {
     unsigned *ctr = fused_counter();
     LGS_REQUIRE(ctr != nullptr, "lgs_bn_backward: could not allocate the grid-barrier counters");
     int64_t frpb;
-    const int grid = fused_blocks(n, &frpb);
-    hipLaunchKernelGGL((k_bn_bwd_fused<T>), grid, kNT, 0, s, x, y, dy, n, c, gamma, beta, stats, relu, reinterpret_cast<T *>(dxv),
+    const int grid = fused_blocks(n, &frpb, fcap);
+    LGS_KLAUNCH((k_bn_bwd_fused<T>), grid, kNT, 0, s, x, y, dy, n, c, gamma, beta, stats, relu, reinterpret_cast<T *>(dxv),
                        reinterpret_cast<T *>(dresv), dgamma, dbeta, scratch, scratch + (size_t)2 * c * grid, dy_ld, y_ld, frpb,
                        n > 0 ? 1.f / (float)n : 0.f, ctr);
     LGS_HIP(hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, x, y, dy, stats, gamma, beta, n, c, relu, rpb, scratch, dy_ld, y_ld);
-  hipLaunchKernelGGL(k_fold_bwd, (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, nb, c, dgamma, dbeta, sums);
+  LGS_KLAUNCH((k_colreduce<T, 1>), nb, kNT, 0, s, x, y, dy, stats, gamma, beta, n, c, relu, rpb, scratch, dy_ld, y_ld);
+  LGS_KLAUNCH(k_fold_bwd, (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, nb, c, dgamma, dbeta, sums);
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
-    hipLaunchKernelGGL((k_bn_bwd_apply<T>), grid, kNT, 0, s, x, y, dy, n, c, gamma, beta, stats, sums, n > 0 ? 1.f / (float)n : 0.f, relu, reinterpret_cast<T *>(dxv),
+    LGS_KLAUNCH((k_bn_bwd_apply<T>), grid, kNT, 0, s, x, y, dy, n, c, gamma, beta, stats, sums, n > 0 ? 1.f / (float)n : 0.f, relu, reinterpret_cast<T *>(dxv),
                        reinterpret_cast<T *>(dresv), dy_ld, (const float *)nullptr, y_ld);
   }
   LGS_HIP(hipGetLastError());
@@ -834,7 +861,7 @@ int bn_stats_t(const void *xv, int64_t n, int c, float *mean_m2, void *workspace
   const T *x = reinterpret_cast<const T *>(xv);
   const int pm = (partials && partial_rows > 0) ? 1 : 0;
   stats_partials<T>(x, n, c, partials, partial_rows, scratch, s, &nb);
-  hipLaunchKernelGGL((k_fold_stats<T>), (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, x, nb, c, n, mean_m2, pm, pivot);
+  LGS_KLAUNCH((k_fold_stats<T>), (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, x, nb, c, n, mean_m2, pm, pivot);
   LGS_HIP(hipGetLastError());
   return 0;
 }
@@ -846,7 +873,7 @@ int bn_apply_t(const void *xv, int64_t n, int c, const float *gamma, const float
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
-    hipLaunchKernelGGL((k_bn_apply<T>), grid, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(res), n, c,
+    LGS_KLAUNCH((k_bn_apply<T>), grid, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(res), n, c,
                        gamma, beta, stats, relu, reinterpret_cast<T *>(yv), (int64_t)c);
   }
   LGS_HIP(hipGetLastError());
@@ -861,9 +888,9 @@ int bn_bwd_reduce_t(const void *xv, const void *yv, const void *dyv, int64_t n, 
   int nb = reduce_blocks(n, &rpb);
   float *scratch = reinterpret_cast<float *>(workspace);
   float *tmp = scratch + (size_t)2 * c * nb;  // dgamma/dbeta land here when the caller does not want them
-  hipLaunchKernelGGL((k_colreduce<T, 1>), nb, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
+  LGS_KLAUNCH((k_colreduce<T, 1>), nb, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
                      reinterpret_cast<const T *>(dyv), stats, gamma, beta, n, c, relu, rpb, scratch, (int64_t)c, (int64_t)c);
-  hipLaunchKernelGGL(k_fold_bwd, (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, nb, c, dgamma ? dgamma : tmp + c, dbeta ? dbeta : tmp, sums);
+  LGS_KLAUNCH(k_fold_bwd, (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, nb, c, dgamma ? dgamma : tmp + c, dbeta ? dbeta : tmp, sums);
   LGS_HIP(hipGetLastError());
   return 0;
 }
@@ -876,7 +903,7 @@ int bn_bwd_apply_t(const void *xv, const void *yv, const void *dyv, int64_t n, i
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
-    hipLaunchKernelGGL((k_bn_bwd_apply<T>), grid, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
+    LGS_KLAUNCH((k_bn_bwd_apply<T>), grid, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
                        reinterpret_cast<const T *>(dyv), n, c, gamma, beta, stats, sums, inv_n_total, relu, reinterpret_cast<T *>(dxv),
                        reinterpret_cast<T *>(dresv), (int64_t)c, inv_n_dev, (int64_t)c);
   }
@@ -907,7 +934,7 @@ int lgs_bn_apply(const void *x, int64_t n, int c, const float *gamma, const floa
 int lgs_bn_sync_combine(const float *all_stats, int world, int c, float eps, float momentum, float *running_mean,
                         float *running_var, int64_t *num_batches_tracked, float *stats, float *inv_n_total, void *stream) {
   LGS_REQUIRE(all_stats && stats && world > 0 && c > 0, "lgs_bn_sync_combine: bad argument");
-  hipLaunchKernelGGL(k_sync_combine, (unsigned)((c + 127) / 128), 128, 0, (hipStream_t)stream, all_stats, world, c, eps, momentum,
+  LGS_KLAUNCH(k_sync_combine, (unsigned)((c + 127) / 128), 128, 0, (hipStream_t)stream, all_stats, world, c, eps, momentum,
                      running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), stats, inv_n_total);
   LGS_HIP(hipGetLastError());
   return 0;

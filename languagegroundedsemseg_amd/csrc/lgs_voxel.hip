@@ -65,7 +65,7 @@ int lgs_voxelize(const float *points, int64_t n, const double *affine, int batch
   if (n == 0) return 0;
   Affine A;
   for (int i = 0; i < 12; ++i) A.a[i] = affine[i];
-  hipLaunchKernelGGL(k_voxelize, (unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream, points, n, A, batch, coords);
+  LGS_KLAUNCH(k_voxelize, (unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream, points, n, A, batch, coords);
   LGS_HIP(hipGetLastError());
   return 0;
 }
@@ -76,8 +76,8 @@ int lgs_label_vote(const int64_t *labels, int64_t n, const int64_t *unique_index
               "lgs_label_vote: bad argument");
   if (n == 0 || n_unique == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_label_init, (unsigned)((n_unique + 255) / 256), 256, 0, s, labels, unique_index, n_unique, labels_out);
-  hipLaunchKernelGGL(k_label_vote, (unsigned)((n + 255) / 256), 256, 0, s, labels, n, unique_index, inverse, ignore_label, labels_out);
+  LGS_KLAUNCH(k_label_init, (unsigned)((n_unique + 255) / 256), 256, 0, s, labels, unique_index, n_unique, labels_out);
+  LGS_KLAUNCH(k_label_vote, (unsigned)((n + 255) / 256), 256, 0, s, labels, n, unique_index, inverse, ignore_label, labels_out);
   LGS_HIP(hipGetLastError());
   return 0;
 }

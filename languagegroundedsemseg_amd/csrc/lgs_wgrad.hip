@@ -908,7 +908,7 @@ inline PsPlan ps_plan(const View &v, int cg, int cs) {
   // gather instructions are what a wide-channel launch is made of (PMC at 512 x 512: 83 M vector-memory instructions
   // for 68 M MFMAs): from 8 blocks on, 3-block slices are used even when the last one is partly padding (16 blocks:
   // 6 slices instead of 8, 12 % padded MFMAs)
-  static const bool wide3 = getenv("LGS_PS_WIDE3") == nullptr || atoi(getenv("LGS_PS_WIDE3")) != 0;   // tuning knob
+  const bool wide3 = tune(T_PS_WIDE3) != 0;
   // (512 -> 512 at L0: 18.7 -> 15.0 ms, 640 -> 512: 33.3 -> 19.3 ms; at 8 blocks only when the slices exceed an XCD's CUs
   // anyway -- 256 x 256 keeps its 32 XCD-local two-block slices: 1.21 vs 1.34 ms at L1)
   const bool three = nbs % 3 == 0 || (wide3 && (nbs >= 12 || (nbs >= 8 && (p.cg_pad / 32) * ((nbs + 2) / 3) > 32)));
@@ -922,12 +922,12 @@ inline PsPlan ps_plan(const View &v, int cg, int cs) {
   // 85 lanes would put 33 workgroups on five of the XCDs and the 33rd runs alone in a second round (measured 2x).
   const int lds_wg = 2 * kPsChunk * tile_stride(32 * p.ncs) + (v.K == 27 ? 5 * ps_wave_lds(3) + 3 * ps_wave_lds(4) : 8 * ps_wave_lds(1));
   const int wg_per_cu = v.K == 27 ? 1 : (2 * lds_wg <= 160 * 1024 ? 2 : 1);
-  // CUs per XCD the kernel fills: 20 of 32 (LGS_PS_CUS: tuning knob).  A workgroup owns its CU (all registers, all LDS) for the
+  // CUs per XCD the kernel fills: 20 of 32 (tuning knob PS_CUS).  A workgroup owns its CU (all registers, all LDS) for the
   // whole launch, and the kernel runs next to the dgrad / BatchNorm chain of the compute stream: with every CU taken, each
   // compute-stream kernel waits for weight-gradient workgroups to retire before it gets anywhere.  Leaving 12 CUs per XCD makes
   // the weight gradients ~1.3 x longer on their own stream (which has the slack) and the 8-scene step 0.7 ms shorter
   // (32: 29.97, 28: 29.6, 24: 29.4, 20: 29.27, 16: 29.36 ms; `finalize`, the side stream's tail, stays 0.40 ms down to 20)
-  static const int cus_env = getenv("LGS_PS_CUS") ? atoi(getenv("LGS_PS_CUS")) : 20;
+  const int cus_env = (int)tune(T_PS_CUS);
   const int per_xcd = (cus_env >= 4 && cus_env <= 32 ? cus_env : 32) * wg_per_cu, n_sl = p.n_cg * p.n_cs;
   p.xcd_map = n_sl <= per_xcd ? 1 : 0;
   int lanes = p.xcd_map ? 8 * (per_xcd / n_sl) : (8 * per_xcd) / n_sl;
@@ -944,8 +944,7 @@ inline PsPlan ps_plan(const View &v, int cg, int cs) {
   return p;
 }
 inline bool ps_enabled() {
-  static const bool on = getenv("LGS_WGRAD_OLD") == nullptr;   // debugging knob: force the pair-list kernel
-  return on;
+  return tune(T_WGRAD_PS) != 0;   // debugging knob: 0 forces the pair-list kernel
 }
 
 int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype) {
@@ -988,7 +987,7 @@ int launch_wgrad_bf16(const View &v, const WgradPlan &p, const bf16_t *in, int c
   const int n_ranges = p.n_ranges, n_lanes = p.S;
   const int KG = (v.K + p.kpw - 1) / p.kpw;
   const unsigned nblocks = (unsigned)(((n_lanes + 7) / 8) * 8 * KG * n_tasks);
-  hipLaunchKernelGGL((k_wgrad_bf16<NCI, NCO, D, OCC>), dim3(nblocks), 256, 4 * WAVE_BYTES, s, v, in, cin, go, cout, p.cin_pad,
+  LGS_KLAUNCH((k_wgrad_bf16<NCI, NCO, D, OCC>), dim3(nblocks), 256, 4 * WAVE_BYTES, s, v, in, cin, go, cout, p.cin_pad,
                      p.cout_pad, p.span, p.kpw, p.n_ci_tasks, n_tasks, n_ranges, n_lanes, partial, (unsigned)in_b, (unsigned)go_b);
   return 0;
 }
@@ -1004,7 +1003,7 @@ int launch_wgrad_ps(const PsArgs &a, const PsPlan &p, hipStream_t s) {
     attr_set = true;
   }
   const unsigned nblocks = (unsigned)((p.xcd_map ? ((p.n_lanes + 7) / 8) * 8 : p.n_lanes) * p.n_cg * p.n_cs);
-  hipLaunchKernelGGL((k_wgrad_ps<KIND, NCS>), dim3(nblocks), 512, LDS, s, a);
+  LGS_KLAUNCH((k_wgrad_ps<KIND, NCS>), dim3(nblocks), 512, LDS, s, a);
   return 0;
 }
 
@@ -1044,7 +1043,7 @@ int conv_wgrad_ps(const View &v, int transposed, const bf16_t *in, int cin, cons
   }
   if (rc) return rc;
   const int64_t total = (int64_t)v.K * cg * ((cs + 3) / 4);
-  hipLaunchKernelGGL(k_wgrad_reduce_ps, (unsigned)((total + 255) / 256), 256, 0, s, a.partial, p.n_lanes, v.K, p.cg_pad, p.cs_pad, cg, cs,
+  LGS_KLAUNCH(k_wgrad_reduce_ps, (unsigned)((total + 255) / 256), 256, 0, s, a.partial, p.n_lanes, v.K, p.cg_pad, p.cs_pad, cg, cs,
                      transposed, gw);
   LGS_HIP(hipGetLastError());
   *done = true;
@@ -1071,7 +1070,7 @@ int conv_wgrad_bf16(const View &v, const void *in_v, int cin, const void *gout_v
     const int c8 = (cin + 7) / 8 * 8;
     bf16_t *padded = reinterpret_cast<bf16_t *>(wsb + pad_off);
     int64_t tot = v.n_in * (int64_t)c8;
-    if (tot > 0) hipLaunchKernelGGL(k_pad_rows_bf16, (unsigned)((tot + 255) / 256), 256, 0, s, in, v.n_in, cin, c8, padded);
+    if (tot > 0) LGS_KLAUNCH(k_pad_rows_bf16, (unsigned)((tot + 255) / 256), 256, 0, s, in, v.n_in, cin, c8, padded);
     in = padded;
     cin = c8;
     pad_off += align256(tot * 2);
@@ -1081,7 +1080,7 @@ int conv_wgrad_bf16(const View &v, const void *in_v, int cin, const void *gout_v
     const int c8 = (cout + 7) / 8 * 8;
     bf16_t *padded = reinterpret_cast<bf16_t *>(wsb + pad_off);
     int64_t tot = v.n_out * (int64_t)c8;
-    if (tot > 0) hipLaunchKernelGGL(k_pad_rows_bf16, (unsigned)((tot + 255) / 256), 256, 0, s, go, v.n_out, cout, c8, padded);
+    if (tot > 0) LGS_KLAUNCH(k_pad_rows_bf16, (unsigned)((tot + 255) / 256), 256, 0, s, go, v.n_out, cout, c8, padded);
     go = padded;
     cout = c8;
   }
@@ -1094,7 +1093,7 @@ int conv_wgrad_bf16(const View &v, const void *in_v, int cin, const void *gout_v
   { LGS_REQUIRE(false, "bf16 wgrad: no kernel instance for this tile"); }
 #undef LGS_WG
   int64_t total = (int64_t)v.K * cin_real * ((cout_real + 3) / 4);
-  hipLaunchKernelGGL(k_wgrad_reduce, (unsigned)((total + 255) / 256), 256, 0, s, partial, p.S, v.K, p.cin_pad, p.cout_pad, cin_real,
+  LGS_KLAUNCH(k_wgrad_reduce, (unsigned)((total + 255) / 256), 256, 0, s, partial, p.S, v.K, p.cin_pad, p.cout_pad, cin_real,
                      cout_real, gw);
   LGS_HIP(hipGetLastError());
   return 0;
@@ -1111,13 +1110,13 @@ int conv_wgrad_f32path(const View &v, const void *in_v, int cin, const void *gou
   int n_cig = (p.cin_pad / 32 + 3) / 4;
   dim3 grid((unsigned)p.S, (unsigned)v.K, (unsigned)(n_cot * n_cig));
   switch (p.ncb) {
-    case 4: hipLaunchKernelGGL((k_wgrad_f32<T, 4>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
-    case 3: hipLaunchKernelGGL((k_wgrad_f32<T, 3>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
-    case 2: hipLaunchKernelGGL((k_wgrad_f32<T, 2>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
-    default: hipLaunchKernelGGL((k_wgrad_f32<T, 1>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
+    case 4: LGS_KLAUNCH((k_wgrad_f32<T, 4>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
+    case 3: LGS_KLAUNCH((k_wgrad_f32<T, 3>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
+    case 2: LGS_KLAUNCH((k_wgrad_f32<T, 2>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
+    default: LGS_KLAUNCH((k_wgrad_f32<T, 1>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
   }
   int64_t total = (int64_t)v.K * cin * ((cout + 3) / 4);
-  hipLaunchKernelGGL(k_wgrad_reduce, (unsigned)((total + 255) / 256), 256, 0, s, partial, p.S, v.K, p.cin_pad, p.cout_pad, cin,
+  LGS_KLAUNCH(k_wgrad_reduce, (unsigned)((total + 255) / 256), 256, 0, s, partial, p.S, v.K, p.cin_pad, p.cout_pad, cin,
                      cout, gw);
   LGS_HIP(hipGetLastError());
   return 0;
@@ -1195,10 +1194,10 @@ int lgs_clip_loss_backward_anchors(const void *feat, int64_t n, int c, int n_anc
   LGS_HIP(hipMemsetAsync(G, 0, (size_t)n * a8 * esize(dtype), s));
   const unsigned blocks = (unsigned)((n + 255) / 256);
   if (dtype == LGS_F32)
-    hipLaunchKernelGGL((k_clip_coef_rows<float>), blocks, 256, 0, s, labels, neg, k_neg, ignore_label, inv_norm_f, g_dpos, g_dneg, n,
+    LGS_KLAUNCH((k_clip_coef_rows<float>), blocks, 256, 0, s, labels, neg, k_neg, ignore_label, inv_norm_f, g_dpos, g_dneg, n,
                        n_anchor, a8, reinterpret_cast<float *>(G));
   else
-    hipLaunchKernelGGL((k_clip_coef_rows<bf16_t>), blocks, 256, 0, s, labels, neg, k_neg, ignore_label, inv_norm_f, g_dpos, g_dneg, n,
+    LGS_KLAUNCH((k_clip_coef_rows<bf16_t>), blocks, 256, 0, s, labels, neg, k_neg, ignore_label, inv_norm_f, g_dpos, g_dneg, n,
                        n_anchor, a8, reinterpret_cast<bf16_t *>(G));
   LGS_HIP(hipGetLastError());
   // grad_anchors_t[c][a8] = F^T G   (transposed: the caller reads column a as d/dT^_a)

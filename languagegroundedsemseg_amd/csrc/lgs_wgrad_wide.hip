@@ -385,12 +385,13 @@ struct WwPlan {
 };
 inline WwPlan ww_plan(const View &v, int cin, int cout) {
   WwPlan p;
-  static const bool on = getenv("LGS_WGRAD_WIDE") == nullptr || atoi(getenv("LGS_WGRAD_WIDE")) != 0;   // A/B knob
-  // maps below ~200 k positions keep the position-stationary kernel (level 2, 81 k rows, 256 -> 256: 0.82 vs 0.31 ms)
-  if (!on || v.K != 27 || v.KS != 27 || v.nbr == nullptr || v.n_pad < 200000 || v.n_pad % kWwTile != 0) return p;
+  const bool on = tune(T_WGRAD_WIDE) != 0;   // A/B knob
+  // maps below ~200 k positions keep the position-stationary kernel (level 2, 81 k rows, 256 -> 256: 0.82 vs 0.31 ms); the
+  // parity tests lower WW_MIN_ROWS to send in-network layers of a 70 k-voxel scene through this kernel
+  if (!on || v.K != 27 || v.KS != 27 || v.nbr == nullptr || v.n_pad < tune(T_WW_MIN_ROWS) || v.n_pad % kWwTile != 0) return p;
   // positions per workgroup range (a whole number of 256-position tiles): small enough that the rows of the ranges in flight
   // fit the Infinity Cache, large enough that the fp32 partial tiles (256 KB per workgroup) stay a small part of the traffic
-  static const int range_env = getenv("LGS_WW_RANGE") ? atoi(getenv("LGS_WW_RANGE")) : 0;   // tuning knob
+  const int range_env = (int)tune(T_WW_RANGE);   // tuning knob
   p.chunk = range_env >= 256 ? range_env / 256 * 256 : 16384;
   if (cin < 256 || cout < 256 || cin % 8 != 0 || cout % 8 != 0) return p;
   while ((int64_t)27 * ((v.n_pad + p.chunk - 1) / p.chunk) * (((cin + 255) / 256) * 256) * (int64_t)(((cout + 255) / 256) * 256) * 4 > (3ll << 30))
@@ -427,9 +428,9 @@ int conv_wgrad_wide(const View &v, const void *in, int cin, int in_ld, const voi
   int32_t *pout = reinterpret_cast<int32_t *>(ws + 2 * p.cnt_b + 256 + p.pair_b);
   float *partial = reinterpret_cast<float *>(ws + 2 * p.cnt_b + 256 + 2 * p.pair_b);
   View vv = v; vv.mirror = 0;
-  hipLaunchKernelGGL(k_ww_count, dim3(p.ntile), dim3(256), 0, s, vv, p.ntile, cnt);
-  hipLaunchKernelGGL(k_ww_scan, dim3(27), dim3(256), 0, s, cnt, p.ntile, off, total);
-  hipLaunchKernelGGL(k_ww_write, dim3(p.ntile), dim3(256), 0, s, vv, p.ntile, off, (int64_t)v.n_pad, pin, pout);
+  LGS_KLAUNCH(k_ww_count, dim3(p.ntile), dim3(256), 0, s, vv, p.ntile, cnt);
+  LGS_KLAUNCH(k_ww_scan, dim3(27), dim3(256), 0, s, cnt, p.ntile, off, total);
+  LGS_KLAUNCH(k_ww_write, dim3(p.ntile), dim3(256), 0, s, vv, p.ntile, off, (int64_t)v.n_pad, pin, pout);
   static bool attr_set = false;
   if (!attr_set) {
     LGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_wide), hipFuncAttributeMaxDynamicSharedMemorySize, kWwLds));
@@ -440,9 +441,9 @@ int conv_wgrad_wide(const View &v, const void *in, int cin, int in_ld, const voi
   a.pin = pin; a.pout = pout; a.total = total; a.off = off; a.ntile = p.ntile; a.partial = partial; a.stride = v.n_pad;
   a.cin = cin; a.cout = cout; a.in_ld = ld; a.nchunk = p.nchunk; a.chunk = p.chunk; a.ci_pad = p.ti * 256; a.co_pad = p.tj * 256; a.ti = p.ti; a.tj = p.tj;
   a.in_bytes = (unsigned)in_b; a.go_bytes = (unsigned)go_b;
-  hipLaunchKernelGGL(k_wgrad_wide, dim3((unsigned)(27 * p.nchunk * p.ti * p.tj)), dim3(512), kWwLds, s, a);
+  LGS_KLAUNCH(k_wgrad_wide, dim3((unsigned)(27 * p.nchunk * p.ti * p.tj)), dim3(512), kWwLds, s, a);
   const int64_t tot = (int64_t)27 * cin * (cout / 4);
-  hipLaunchKernelGGL(k_wgrad_wide_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, partial, total, p.nchunk, p.chunk, a.ci_pad, a.co_pad,
+  LGS_KLAUNCH(k_wgrad_wide_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, partial, total, p.nchunk, p.chunk, a.ci_pad, a.co_pad,
                      cin, cout, gw);
   LGS_HIP(hipGetLastError());
   *done = true;

@@ -10,7 +10,7 @@ import os
 from . import build as _build
 
 LGS_F32, LGS_BF16 = 0, 1
-ABI_VERSION = 7     # LGS_ABI_VERSION of include/lgs_engine.h
+ABI_VERSION = 8     # LGS_ABI_VERSION of include/lgs_engine.h
 
 
 class PackDesc(ctypes.Structure):
@@ -25,6 +25,7 @@ _lib = None
 # every symbol include/lgs_engine.h declares; tests check the built library exports all of them
 EXPORTS = [
     "lgs_abi_version", "lgs_last_error",
+    "lgs_tuning_set", "lgs_tuning_get", "lgs_tuning_describe", "lgs_debug_dispatch_counts",
     "lgs_manager_create", "lgs_manager_destroy", "lgs_manager_insert", "lgs_manager_stride2",
     "lgs_manager_parent_of", "lgs_manager_map_size", "lgs_manager_get_coords", "lgs_manager_kernel_map",
     "lgs_kmap_export",
@@ -64,6 +65,8 @@ def lib():
     L.lgs_last_error.restype = ctypes.c_char_p
     L.lgs_last_error.argtypes = []
     sig = {
+        "lgs_tuning_set": [ctypes.c_char_p, i64],
+        "lgs_tuning_get": [ctypes.c_char_p, pi64],
         "lgs_manager_create": [ci, pvp],
         "lgs_manager_destroy": [vp],
         "lgs_manager_insert": [vp, vp, i64, vp, vp, vp, pi, pi64],
@@ -103,6 +106,10 @@ def lib():
         f = getattr(L, name)
         f.restype = ci
         f.argtypes = args
+    L.lgs_tuning_describe.restype = i64
+    L.lgs_tuning_describe.argtypes = [ctypes.c_char_p, i64]
+    L.lgs_debug_dispatch_counts.restype = i64
+    L.lgs_debug_dispatch_counts.argtypes = [ctypes.c_char_p, i64, ci]
     L.lgs_cluster_workspace_bytes.restype = i64
     L.lgs_cluster_workspace_bytes.argtypes = [i64]
     L.lgs_conv_workspace_bytes.restype = i64
@@ -125,3 +132,57 @@ def check(rc):
     if rc != 0:
         msg = lib().lgs_last_error()
         raise RuntimeError("lgs_engine: " + (msg.decode(errors="replace") if msg else "error %d" % rc))
+
+
+# ---- tuning table / dispatch counters (include/lgs_engine.h, csrc/lgs_tuning.hip)
+def tuning_set(name, value):
+    check(lib().lgs_tuning_set(name.encode(), int(value)))
+
+
+def tuning_get(name):
+    v = ctypes.c_int64()
+    check(lib().lgs_tuning_get(name.encode(), ctypes.byref(v)))
+    return int(v.value)
+
+
+class tuning:
+    """with engine.tuning(WW_MIN_ROWS=0): ...   -- set knobs for a block (tests), restore afterwards"""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        self.prev = {k: tuning_get(k) for k in self.knobs}
+        for k, v in self.knobs.items():
+            tuning_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            tuning_set(k, v)
+
+
+def tuning_table():
+    """-> [(name, default, value, doc)]"""
+    L = lib()
+    n = L.lgs_tuning_describe(None, 0)
+    buf = ctypes.create_string_buffer(int(n))
+    L.lgs_tuning_describe(buf, n)
+    rows = []
+    for line in buf.value.decode().splitlines():
+        name, d, v, doc = line.split("\t", 3)
+        rows.append((name, int(d), int(v), doc))
+    return rows
+
+
+def dispatch_counts(reset=False):
+    """-> {launch site: launches since the last reset}"""
+    L = lib()
+    cap = 1 << 19
+    buf = ctypes.create_string_buffer(cap)
+    L.lgs_debug_dispatch_counts(buf, cap, 1 if reset else 0)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        c, name = line.split("\t", 1)
+        out[name] = int(c)
+    return out

@@ -121,8 +121,11 @@ class ContrastiveLanguageLoss(nn.Module):
     Negatives are sampled on the device (no host loop / joblib pool / np.random), or passed explicitly."""
 
     def __init__(self, num_labels=200, num_negative_samples=3, pos_thresh=0.0, neg_thresh=0.6, neg_weight=1.0,
-                 ignore_label=-1, reduction="mean", uniform_sampling=True):
+                 ignore_label=-1, reduction="mean", uniform_sampling=True, distance_type="cos"):
         super().__init__()
+        if distance_type not in ("cos", "l1", "l2"):
+            raise ValueError("representation_distance_type must be 'cos', 'l1' or 'l2' (ContrastiveLanguageLoss.py:79-92), got %r" % (distance_type,))
+        self.distance_type = distance_type            # config.representation_distance_type (config.py:159; default 'cos')
         self.num_labels, self.K = num_labels, num_negative_samples
         self.pos_thresh, self.neg_thresh, self.neg_weight = pos_thresh, neg_thresh, neg_weight
         self.ignore_label, self.reduction = ignore_label, reduction
@@ -157,29 +160,56 @@ class ContrastiveLanguageLoss(nn.Module):
         idx = torch.minimum(r + (r >= own).long(), (n_present - 1).clamp_min(0))   # a single-class batch has no negatives: own class
         return cls_of_rank[idx]
 
-    def forward(self, features, labels, anchor_feats, neg_indices=None, return_similarity=False, return_pred=False):
+    def _raw_distances(self, features, anchors, labels, neg_indices, ignore_label):
+        """representation_distance_type 'l1' / 'l2' (ContrastiveLanguageLoss.py:79-86) on the raw, un-normalised vectors, without
+        the reference's [N, 1+K, C] gathers (9.8 GB at 1.2 M voxels x 512-d):
+          l2: mean_j sqrt(|f - t_j|^2 + 1e-7) with |f - t|^2 = |f|^2 - 2 f.t + |t|^2 from ONE dense [N, C] x [C, A] product;
+          l1: mean_j sum_c (f_c - t_jc) -- the reference sums SIGNED differences (no abs; reproduced as written) = sum(f) - sum(t_j).
+        Not the measured path (config.py:159 defaults to 'cos', which owns the fused kernels): plain torch device ops."""
+        f, t = features.float(), anchors.float()
+        lab = labels.clamp_min(0)
+        if self.distance_type == "l1":
+            fs, ts = f.sum(1), t.sum(1)
+            d_pos = fs - ts[lab]
+            d_neg = (fs[:, None] - ts[neg_indices]).mean(1)
+        else:
+            d2 = ((f * f).sum(1)[:, None] - 2.0 * (f @ t.t()) + (t * t).sum(1)[None, :]).clamp_min(0)
+            d_pos = torch.sqrt(d2.gather(1, lab[:, None]).squeeze(1) + 1e-7)
+            d_neg = torch.sqrt(d2.gather(1, neg_indices) + 1e-7).mean(1)
+        valid = labels != ignore_label
+        zero = torch.zeros((), dtype=d_pos.dtype, device=d_pos.device)
+        return torch.where(valid, d_pos, zero), torch.where(valid, d_neg, zero)
+
+    def forward(self, features, labels, anchor_feats, neg_indices=None, return_similarity=False, return_pred=False, ignore_label=None):
         """-> (loss, pos_loss, neg_loss[, sim][, pred]); pred = argmax_a <f^, t^_a>, what the reference's trainer gets from
-        feature_sim(...).argmax(1) (pl_RepresentationTrainer.py:237-238) -- here a by-product of the same pass."""
+        feature_sim(...).argmax(1) (pl_RepresentationTrainer.py:237-238) -- here a by-product of the same pass.
+        ignore_label: overrides self.ignore_label for this call (the [N, 2]-label adapter passes a sentinel that cannot collide
+        with a flattened (category, attribute) index)."""
         if features.dim() != 2:
             raise ValueError("`features` needs to be [n_points, feat_dim]")
         if anchor_feats.dim() == 3:                               # anchors with attributes: use the plain ones (:122-123)
             anchor_feats = anchor_feats[:, 0, :]
         labels = labels.long()
+        ign = self.ignore_label if ignore_label is None else ignore_label
         if neg_indices is None:
             neg_indices = self.sample_negatives(labels)
+        if self.distance_type != "cos":
+            if return_similarity or return_pred:
+                raise ValueError("similarity / arg-max outputs exist for the 'cos' distance only")
+            d_pos, d_neg = self._raw_distances(features, anchor_feats, labels, neg_indices, ign)
+            return self._hinge(d_pos, d_neg)
         be = get_backend()
         fused = (hasattr(be, "clip_loss_forward") and features.is_cuda
                  and (not anchor_feats.requires_grad or hasattr(be, "clip_loss_backward_anchors"))
                  and anchor_feats.shape[0] % 4 == 0 and 4 <= anchor_feats.shape[0] <= be.CLIP_LOSS_MAX_ANCHORS
                  and 1 <= neg_indices.shape[1] <= 7)
         if fused:
-            d_pos, d_neg, pred, sim = _ClipLossFused.apply(features, anchor_feats, labels, neg_indices, self.ignore_label,
-                                                           bool(return_similarity))
+            d_pos, d_neg, pred, sim = _ClipLossFused.apply(features, anchor_feats, labels, neg_indices, ign, bool(return_similarity))
         else:
             # > 224 anchors, more than 7 negatives, or the CPU oracle backend of the tests: dense similarity matrix + index
             # gathers (learned anchor projections take the fused path too: lgs_clip_loss_backward_anchors)
             sim = clip_similarity(features, anchor_feats)         # [N, num_labels] -- the MFMA contraction
-            valid = labels != self.ignore_label
+            valid = labels != ign
             lab = labels.clamp_min(0)
             d_pos = 1.0 - sim.gather(1, lab[:, None]).squeeze(1)
             d_neg = 1.0 - sim.gather(1, neg_indices).mean(1)
@@ -187,18 +217,23 @@ class ContrastiveLanguageLoss(nn.Module):
             d_pos = torch.where(valid, d_pos, zero)
             d_neg = torch.where(valid, d_neg, zero)
             pred = sim.detach().argmax(1) if return_pred else None
+        out = self._hinge(d_pos, d_neg)
+        if return_similarity:
+            out = out + (sim,)
+        if return_pred:
+            out = out + (pred,)
+        return out
+
+
+    def _hinge(self, d_pos, d_neg):
+        """ContrastiveLanguageLoss.py:185-192"""
         pos_loss = torch.relu(d_pos - self.pos_thresh)
         neg_loss = torch.relu(self.neg_thresh - d_neg)
         if self.reduction == "mean":
             loss = pos_loss.mean() + neg_loss.mean() * self.neg_weight
         else:
             loss = pos_loss + neg_loss * self.neg_weight
-        out = (loss, pos_loss, neg_loss)
-        if return_similarity:
-            out = out + (sim,)
-        if return_pred:
-            out = out + (pred,)
-        return out
+        return (loss, pos_loss, neg_loss)
 
 
 class ReferenceContrastiveLanguageLoss(ContrastiveLanguageLoss):
@@ -216,7 +251,10 @@ class ReferenceContrastiveLanguageLoss(ContrastiveLanguageLoss):
     (lgs_clip_loss_forward / lgs_clip_loss_backward); negatives are drawn on the device instead of the reference's
     per-class np.random.choice inside a joblib thread pool (whose draw order is not reproducible even with a seed).
     Category + attribute labels ([N, 2], :149-178) select the anchor (category, attribute) as the positive and plain
-    category anchors as negatives, like the reference; its latent augmentation (a pretrained AttributeFittingModel that is
+    category anchors as negatives, like the reference.  With clip_uniform_sampling=False the reference draws negatives from
+    `unique_targets_np[unique_targets_np != ut[0]]`, where unique_targets_np is an array of (category, attribute) PAIRS (:152-153,:173):
+    the comparison broadcasts over both columns and the "candidates" are a mix of category and attribute ids -- a reference bug;
+    this class draws from the other CATEGORIES present in the batch, which is what the 1-D branch (:141) does. its latent augmentation (a pretrained AttributeFittingModel that is
     not part of the hot path) is not reproduced and raises if configured."""
 
     def __init__(self, config, num_labels, temperature=0.07, base_temperature=0.07, reduction="mean", feature_dim=512):
@@ -224,15 +262,12 @@ class ReferenceContrastiveLanguageLoss(ContrastiveLanguageLoss):
         if k <= -1:
             k = num_labels                                            # :35-38
         dist_type = getattr(config, "representation_distance_type", "cos")
-        if dist_type != "cos":
-            raise NotImplementedError("representation_distance_type=%r: the engine implements the reference's default 'cos' "
-                                      "distance (config.py:159); l1 / l2 are not part of the measured path" % (dist_type,))
         super().__init__(num_labels=num_labels, num_negative_samples=k,
                          pos_thresh=float(getattr(config, "contrast_pos_thresh", 0.0)),
                          neg_thresh=float(getattr(config, "contrast_neg_thresh", 0.6)),
                          neg_weight=float(getattr(config, "contrast_neg_weight", 1.0)),
                          ignore_label=int(getattr(config, "ignore_label", -1)), reduction=reduction,
-                         uniform_sampling=bool(getattr(config, "clip_uniform_sampling", True)))
+                         uniform_sampling=bool(getattr(config, "clip_uniform_sampling", True)), distance_type=dist_type)
         self.config = config
         self.temperature, self.base_temperature, self.feature_dim = temperature, base_temperature, feature_dim
         self.num_negative_samples = k
@@ -251,8 +286,11 @@ class ReferenceContrastiveLanguageLoss(ContrastiveLanguageLoss):
             if neg_indices is None:
                 neg_indices = self.sample_negatives(cat)
             valid = cat != self.ignore_label
-            flat_lab = torch.where(valid, cat.clamp_min(0) * A + att, torch.full_like(cat, self.ignore_label))
-            out = super().forward(features, flat_lab, anchor_feats.reshape(-1, anchor_feats.shape[-1]), neg_indices=neg_indices * A)
+            # ignored rows become -1, which no flattened (category, attribute) index can equal -- a non-negative
+            # config.ignore_label (e.g. 255) would otherwise silently drop the valid pair whose flat index is 255
+            flat_lab = torch.where(valid, cat.clamp_min(0) * A + att, torch.full_like(cat, -1))
+            out = super().forward(features, flat_lab, anchor_feats.reshape(-1, anchor_feats.shape[-1]), neg_indices=neg_indices * A,
+                                  ignore_label=-1)
             return out[:3]
         return super().forward(features, labels, anchor_feats, neg_indices=neg_indices)[:3]
 

@@ -11,6 +11,7 @@ import weakref
 import torch
 
 from .. import engine
+from .. import tuning as _tuning
 
 _vp = ctypes.c_void_p
 
@@ -93,7 +94,7 @@ def _bn_ws_bytes(L, n, c):
     return b
 # input voxels per batch below which weight gradients are not moved to the side stream (LGS_WGRAD_INLINE_BELOW: tuning knob;
 # one 145 k-voxel scene per step: 11.2 -> 10.4 ms, the 1.2 M-voxel batch keeps the side stream: 29.9 vs 30.9 ms)
-_WGRAD_INLINE_BELOW = int(os.environ.get("LGS_WGRAD_INLINE_BELOW", "400000"))
+_WGRAD_INLINE_BELOW = _tuning.host("WGRAD_INLINE_BELOW")
 
 
 def _ws(nbytes, device, stream=None):
@@ -154,7 +155,7 @@ class PackedWeights:
         self.epoch = 0
         self._table = None          # (device copy of the descriptors, entry list, max_total)
         self._dirty = True
-        self.enabled = os.environ.get("LGS_NO_PACK_CACHE") is None
+        self.enabled = _tuning.host("PACK_CACHE") != 0
 
     def invalidate(self):
         """every cached image is re-packed from its parameter on next use"""
@@ -442,31 +443,23 @@ class HipManager:
         return km
 
 
-_HIPRT = None
-
-
-def masked_stream(device, words):
-    """torch stream object around a HIP stream created with a CU mask (list of 32-bit words, bit i = CU i enabled)"""
-    global _HIPRT
-    if _HIPRT is None:
-        _HIPRT = ctypes.CDLL("libamdhip64.so")
-    arr = (ctypes.c_uint32 * len(words))(*words)
-    st = ctypes.c_void_p()
-    with _dev(device):
-        rc = _HIPRT.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(len(words)), arr)
-    if rc != 0:
-        raise RuntimeError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
-    return torch.cuda.ExternalStream(st.value, device=device)
+def _written_by_engine(*tensors):
+    """The engine updated these tensors through raw pointers (running statistics, num_batches_tracked): bump their autograd
+    version counters so that everything keyed on `_version` -- MinkowskiBatchNorm's cached eval-mode [mean | invstd] vector,
+    torch's own saved-tensor checks -- sees the write (host-only, no launch)."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
 
 
 class HipBackend:
     name = "hip"
     bn_counts_batches = True    # lgs_bn_forward increments num_batches_tracked itself
-    # lgs_bn_forward can write its output into a column slice of a wider buffer (zero-copy ME.cat; LGS_NO_ZERO_COPY_CAT=1: A/B knob)
-    bn_out_into = os.environ.get("LGS_NO_ZERO_COPY_CAT") is None
+    # lgs_bn_forward can write its output into a column slice of a wider buffer (zero-copy ME.cat; host knob ZERO_COPY_CAT=0: A/B)
+    bn_out_into = _tuning.host("ZERO_COPY_CAT") != 0
     # lgs_conv_forward can emit the following BatchNorm's statistics from its epilogue -- measured SLOWER in the step (31.5 vs 30.9 ms: the epilogue work on every conv costs more than the skipped column reduction saves), so off unless LGS_CONV_BN_STATS=1
-    conv_bn_stats = os.environ.get("LGS_CONV_BN_STATS") in ("1", "big")
-    conv_bn_stats_min_bytes = (24 << 20) if os.environ.get("LGS_CONV_BN_STATS") == "big" else 0   # experiment: large outputs only
+    conv_bn_stats = _tuning.host("CONV_BN_STATS") in ("1", "big")
+    conv_bn_stats_min_bytes = (24 << 20) if _tuning.host("CONV_BN_STATS") == "big" else 0   # experiment: large outputs only
 
     def want_conv_bn_stats(self, n_rows, cout, esize):
         return self.conv_bn_stats and n_rows * cout * esize >= self.conv_bn_stats_min_bytes
@@ -505,17 +498,11 @@ class HipBackend:
         return ev
 
     def side_stream(self, device):
-        """second HIP stream per device: weight gradients run here, concurrently with the dgrad / BN chain.
-        LGS_WGRAD_CUMASK=<hex words, comma separated, least significant first> (experiment knob): create it with a CU mask
-        (hipExtStreamCreateWithCUMask), so that the position-stationary weight-gradient kernel -- which owns whole CUs --
-        is confined to a partition instead of evicting the compute stream's waves everywhere."""
+        """second HIP stream per device: weight gradients run here, concurrently with the dgrad / BN chain (CU-mask
+        partitions for it were measured in round 3: 37.8-57.9 vs 29.8 ms per step, removed)"""
         key = device.index if isinstance(device, torch.device) else torch.device(device).index
         if key not in self._side:
-            mask = os.environ.get("LGS_WGRAD_CUMASK")
-            if mask:
-                self._side[key] = masked_stream(device, [int(w, 16) for w in mask.split(",")])
-            else:
-                self._side[key] = torch.cuda.Stream(device=device)
+            self._side[key] = torch.cuda.Stream(device=device)
         return self._side[key]
 
     # ---- fused BN(+residual)(+ReLU): lgs_bn_forward / lgs_bn_backward
@@ -546,6 +533,7 @@ class HipBackend:
                                           _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(res), int(relu), _ptr(y),
                                           _ptr(stats), dt, _ptr(ws), _ptr(part), int(part.shape[0]) if part is not None else 0,
                                           _ptr(piv), int(y_ld), _stream()))
+        _written_by_engine(running_mean, running_var, num_batches_tracked)
         return y, stats
 
     def bn_backward(self, x, y, dy, gamma, beta, stats, relu, want_residual, dgamma_out=None, dbeta_out=None):
@@ -599,6 +587,7 @@ class HipBackend:
             inv_n = torch.empty(1, dtype=torch.float32, device=all_stats.device)
             engine.check(L.lgs_bn_sync_combine(_ptr(all_stats), int(world), int(c), float(eps), float(momentum), _ptr(running_mean),
                                                _ptr(running_var), _ptr(num_batches_tracked), _ptr(stats), _ptr(inv_n), _stream()))
+        _written_by_engine(running_mean, running_var, num_batches_tracked)
         return stats, inv_n
 
     def bn_apply(self, x, gamma, beta, stats, residual, relu):

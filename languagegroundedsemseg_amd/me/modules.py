@@ -14,8 +14,8 @@ from .core import SparseTensor, get_backend
 from .kernel import KernelGenerator, RegionType, convert_to_int_list
 
 
-import os as _os
-_DBG_WGRAD = _os.environ.get("LGS_DBG_WGRAD", "")   # "", "skip", "inline": step-time attribution experiments only
+from .. import tuning as _tuning
+_DBG_WGRAD = _tuning.host("DBG_WGRAD")   # "", "skip", "inline": step-time attribution experiments only
 
 
 class MinkowskiModuleBase(nn.Module):

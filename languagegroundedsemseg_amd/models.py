@@ -63,8 +63,8 @@ class BasicBlock(nn.Module):
 # It is taken only when every module of the block is a plain training-mode MinkowskiConvolution / MinkowskiBatchNorm on the
 # HIP backend with no hooks attached (the layer-wise parity tests hook the modules and so run the op-by-op path);
 # LGS_BLOCK_FUSED=0 turns it off.
-import os as _os
-_BLOCK_FUSED = _os.environ.get("LGS_BLOCK_FUSED", "1") != "0"
+from . import tuning as _tuning
+_BLOCK_FUSED = _tuning.host("BLOCK_FUSED") != 0
 
 
 def _plain(m):
@@ -85,9 +85,17 @@ def _block_fast_path_ok(blk, x):
         if len(blk.downsample) != 2:
             return False
         convs.append(blk.downsample[0]); norms.append(blk.downsample[1])
-    for c in convs:
+    for i, c in enumerate(convs):
         if type(c) is not ME.MinkowskiConvolution or c.bias is not None or c.kernel.dtype != torch.float32 or not _plain(c):
             return False
+        # the fast path hard-codes the kernel maps (key, key, 3) for conv1 / conv2 and (key, key, 1) for the downsample: a block
+        # whose convolutions were configured differently (strided downsample, other kernel sizes, loaded variants) goes op by op
+        want_ks = 3 if i < 2 else 1
+        if (any(k != want_ks for k in c.kernel_size) or any(st != 1 for st in c.stride) or any(d != 1 for d in c.dilation)
+                or c.kernel.dim() != (3 if want_ks == 3 else 2)):
+            return False
+    if convs[0].out_channels != convs[1].in_channels or (len(convs) == 3 and convs[2].out_channels != convs[1].out_channels):
+        return False
     for n in norms:
         b = n.bn
         if type(n) is not ME.MinkowskiBatchNorm or not (b.training and b.affine and b.track_running_stats) or not _plain(n) or not _plain(b):

@@ -1,0 +1,69 @@
+"""ONE table of the host-side (Python) tuning / debugging knobs.  The engine-side knobs live in the C table of
+csrc/lgs_tuning.hip (engine.tuning_table(), engine.tuning_set()); `python -m languagegroundedsemseg_amd.tuning` prints both.
+
+A knob's value is the environment variable LGS_<NAME> when set at import time, else its default.  None of them changes results
+(the A/B ones are bit-identical paths, proven by the tests named in their descriptions)."""
+import os
+
+HOST_KNOBS = {
+    # name: (default, parser, doc)
+    "WGRAD_INLINE_BELOW": (400000, int, "batches below this many input voxels run their weight gradients on the compute stream "
+                                        "(host-bound regime: no fork / join events); larger ones use the side stream"),
+    "BLOCK_FUSED": (1, int, "0 = BasicBlocks run module by module instead of as one autograd node "
+                            "(bit-identical: test_block_fast_path_is_the_op_by_op_path)"),
+    "PACK_CACHE": (1, int, "0 = re-pack the MFMA weight image on every conv call instead of once per optimiser step "
+                           "(bit-identical: test_packed_weight_cache_never_serves_stale_weights)"),
+    "ZERO_COPY_CAT": (1, int, "0 = ME.cat copies instead of both norms writing into the concat buffer "
+                              "(bit-identical: test_zero_copy_cat_equals_the_copying_cat)"),
+    "CONV_BN_STATS": ("", str, "'1' / 'big' = BatchNorm statistics from the conv epilogue (measured slower: 31.5 vs 30.9 ms; off)"),
+    "DBG_WGRAD": ("", str, "'skip' / 'inline': step-time attribution experiments only ('skip' produces no weight gradients)"),
+    "SET_HW_QUEUES": (0, int, "1 = importing the package sets GPU_MAX_HW_QUEUES=8 before the HIP runtime starts (see configure_hw_queues)"),
+}
+
+
+def host(name):
+    default, parse, _ = HOST_KNOBS[name]
+    v = os.environ.get("LGS_" + name)
+    if v is None:
+        return default
+    try:
+        return parse(v)
+    except ValueError:
+        raise ValueError("LGS_%s=%r: expected %s" % (name, v, parse.__name__))
+
+
+def configure_hw_queues(n=8):
+    """The engine drives FOUR HIP streams per device (compute, weight gradients, coordinate / kernel maps, input staging) next to
+    torch's and RCCL's.  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with a fifth
+    stream two of them share a queue and run IN ORDER -- measured: the map stream landed behind the compute stream, so every
+    `SparseTensor(...)` (its insert returns a count to the host) blocked the host until the GPU had finished the previous step
+    (one 145 k-voxel scene per step: 11.5 vs 10.4 ms).  The variable is read when the HIP runtime initialises, so this must run
+    before the process's first device call; an explicit user setting wins.  It is a PROCESS-WIDE setting and therefore the
+    application's call (bench.py and tests/conftest.py make it), not a side effect of importing a library: several processes
+    time-sharing ONE GPU should keep the runtime's default (2 x 8 queues oversubscribe the device: 136 vs 520 ms per step)."""
+    import warnings
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        return int(os.environ["GPU_MAX_HW_QUEUES"])
+    try:
+        import torch
+        if torch.cuda.is_initialized():
+            warnings.warn("configure_hw_queues(): the HIP runtime is already initialised; GPU_MAX_HW_QUEUES has no effect now")
+    except ImportError:
+        pass
+    os.environ["GPU_MAX_HW_QUEUES"] = str(n)
+    return n
+
+
+def describe():
+    rows = [("host", k, str(d), str(host(k)), doc) for k, (d, _, doc) in HOST_KNOBS.items()]
+    try:
+        from . import engine
+        rows += [("engine", n, str(d), str(v), doc) for n, d, v, doc in engine.tuning_table()]
+    except Exception as e:      # library not built
+        rows.append(("engine", "(liblgs_engine.so not built: %s)" % e, "", "", ""))
+    return rows
+
+
+if __name__ == "__main__":
+    for side, name, d, v, doc in describe():
+        print("%-6s LGS_%-20s default %-8s now %-8s %s" % (side, name, d, v, doc))

@@ -26,7 +26,26 @@ def _has_gpu():
         return False
 
 
+# ---- dispatch coverage (tests/test_gpu_dispatch_coverage.py): every GPU test's kernel launch sites are recorded from the engine's
+# dispatch counters; the coverage test runs LAST and compares what the benchmarked steps dispatch against the union
+DISPATCHED = {}          # test node id -> set of launch sites it hit
+
+
+@pytest.fixture(autouse=True)
+def _record_dispatch(request):
+    if "gpu" not in request.keywords or not _has_gpu():
+        yield
+        return
+    from languagegroundedsemseg_amd import engine
+    engine.dispatch_counts(reset=True)
+    yield
+    DISPATCHED[request.node.nodeid] = set(engine.dispatch_counts(reset=True))
+
+
 def pytest_collection_modifyitems(config, items):
+    last = [it for it in items if "test_gpu_dispatch_coverage" in it.nodeid]
+    if last:
+        items[:] = [it for it in items if "test_gpu_dispatch_coverage" not in it.nodeid] + last
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

@@ -9,6 +9,7 @@
 2. contrastive_loss.npz   inputs/outputs of the reference's own ContrastiveLanguageLoss.feat_dist +
                           hinge (lib/losses/ContrastiveLanguageLoss.py:73-95,185-192) on CPU, with the
                           sampled negative indices made explicit (the reference's sampling is thread-racy).
+2d. contrastive_distances.npz  the same for representation_distance_type 'l1' / 'l2' (:79-86).
 2b. feature_sim.npz       the reference's feature_sim (lib/losses/utils.py:80-103, cosine branch) + argmax on the
                           contrastive fixture's features / anchors (2-D anchors and the 3-D attribute layout).
 2c. balancing.npz         the reference's sample_categories_for_balancing (lib/losses/utils.py:13-77) on fixed
@@ -84,6 +85,38 @@ def contrastive():
             out["%s_%s" % (tag, k)] = v.numpy()
     np.savez_compressed(os.path.join(HERE, "contrastive_loss.npz"), **out)
     print("contrastive fixture written")
+
+
+def distance_fixture():
+    """2d. contrastive_distances.npz: the reference's feat_dist + hinge for representation_distance_type 'l1' and 'l2'
+    (lib/losses/ContrastiveLanguageLoss.py:79-86) on the inputs of contrastive_loss.npz.  Note the reference's 'l1' is the
+    SIGNED sum of differences (no abs) -- reproduced as written."""
+    for mod in ("torchmetrics",):
+        if mod not in sys.modules:
+            sys.modules[mod] = types.SimpleNamespace(Metric=object)
+    from lib.losses.ContrastiveLanguageLoss import ContrastiveLanguageLoss
+    fx = np.load(os.path.join(HERE, "contrastive_loss.npz"))
+    out = {}
+    for dist in ("l1", "l2"):
+        cfg = types.SimpleNamespace(ignore_label=-1, num_negative_samples=3, contrast_neg_thresh=0.6, contrast_pos_thresh=0.0,
+                                    contrast_neg_weight=1.0, instance_augmentation_color_aug_prob=0.0, scannet_path="/nonexistent",
+                                    projection_model_path="none", representation_distance_type=dist, clip_uniform_sampling=True)
+        for tag, C in (("c512", 512), ("c96", 96)):
+            loss = ContrastiveLanguageLoss(cfg, 200, feature_dim=C)
+            F, T = torch.from_numpy(fx[tag + "_F"]), torch.from_numpy(fx[tag + "_T"])
+            labels, neg = torch.from_numpy(fx[tag + "_labels"]), torch.from_numpy(fx[tag + "_neg"])
+            N, K = neg.shape
+            pos_samples = T[labels.clamp_min(0)].view(N, 1, C)
+            neg_samples = T[neg.view(-1)].view(N, K, C)
+            d_pos = loss.feat_dist(F, pos_samples, labels)
+            d_neg = loss.feat_dist(F, neg_samples, labels)
+            pos_loss = torch.relu(d_pos - cfg.contrast_pos_thresh)
+            neg_loss = torch.relu(cfg.contrast_neg_thresh - d_neg)
+            total = pos_loss.mean() + neg_loss.mean() * cfg.contrast_neg_weight
+            for k, v in dict(d_pos=d_pos, d_neg=d_neg, pos_loss=pos_loss, neg_loss=neg_loss, total=total.reshape(1)).items():
+                out["%s_%s_%s" % (dist, tag, k)] = v.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "contrastive_distances.npz"), **out)
+    print("distance fixture:", sorted(out)[:4], "...")
 
 
 def _loss_utils():
@@ -215,12 +248,16 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "insseg":
         insseg_fixture()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "distances":
+        distance_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "losses":
         feature_sim_fixture()
         balancing_fixture()
         sys.exit(0)
     manifest()
     contrastive()
+    distance_fixture()
     feature_sim_fixture()
     balancing_fixture()
     forward_fixture("Res16UNet14A", 3, 1500)

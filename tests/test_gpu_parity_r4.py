@@ -1,0 +1,151 @@
+"""Round-4 parity additions (GPU):
+  * k_wgrad_wide per op at the size production selects it (>= 200 k positions): 3^3 256 -> 256 and 512 -> 256 weight gradients
+    vs the oracle, plus the strided-input (column slice of a concat buffer) reader;
+  * train -> eval -> train -> eval BatchNorm: the cached eval-mode statistics must follow the running statistics the engine
+    writes through raw pointers (round-3 advisor finding, high);
+  * the whole-block fast path declines blocks whose convolutions are not the 3^3 / 3^3 / 1x1 stride-1 shape it hard-codes.
+Reference: /root/reference/models/clip_models.py:205-215, models/modules/resnet_block.py:41-57, models/modules/common.py:17-19."""
+import numpy as np
+import pytest
+import torch
+
+import MinkowskiEngine as ME
+from helpers import Cfg, deterministic_init
+from oracle.backend import OracleBackend
+from test_gpu_engine import rel_err, run_both
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _wide_hits(engine):
+    return {k: v for k, v in engine.dispatch_counts().items() if k.split()[0] in ("k_wgrad_wide", "k_ww_count", "k_ww_scan", "k_ww_write",
+                                                                                  "k_wgrad_wide_reduce")}
+
+
+@pytest.mark.parametrize("cin,cout", [(256, 256), (512, 256)])
+def test_wide_weight_gradient_at_production_size_matches_oracle(cin, cout):
+    """two 2 cm scenes = a map of >= 210 k positions: above the WW_MIN_ROWS gate (200 k), i.e. the launch the 8-scene
+    benchmark batch of BASELINE configs[2] takes for every >= 256 x 256-channel 3^3 layer.  bf16 forward / dgrad / wgrad vs
+    the fp32 oracle on bf16-rounded inputs, 2e-2 relative (max-norm) like every per-op bf16 test."""
+    from languagegroundedsemseg_amd import engine
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    coords, _, _ = make_batch([11, 12], voxel=0.02, n_target=112000)
+    assert coords.shape[0] >= 210000, coords.shape
+    assert engine.tuning_get("WW_MIN_ROWS") == 200000
+    feats = torch.from_numpy(np.random.default_rng(5).standard_normal((coords.shape[0], cin)).astype(np.float32)).bfloat16().float().numpy()
+    engine.dispatch_counts(reset=True)
+    (h_out, h_g), (o_out, o_g) = run_both(
+        lambda: [ME.MinkowskiConvolution(cin, cout, kernel_size=3, stride=1, dimension=3)], coords, feats, dtype=torch.bfloat16,
+        oracle_impl="torch")
+    hits = _wide_hits(engine)
+    assert len(hits) == 5 and all(v == 1 for v in hits.values()), hits      # count, scan, write, GEMM, reduce: one launch each
+    assert rel_err(h_out, o_out) < 2e-2
+    for n, a, b in zip(["dgrad", "wgrad"], h_g, o_g):
+        assert rel_err(a, b) < 2e-2, n
+    # and the sharper measure for a reduction over ~3 M pairs per offset: relative L2 over the whole [27, cin, cout] gradient
+    a, b = h_g[1].astype(np.float64), o_g[1].astype(np.float64)
+    assert np.linalg.norm(a - b) / np.linalg.norm(b) < 3e-3
+
+
+def test_wide_weight_gradient_reads_a_column_slice_in_place():
+    """the gathered operand as a column slice of a wider row-major buffer (a zero-copy ME.cat half: 512 of 544 columns):
+    bit-identical to the contiguous copy, on k_wgrad_wide (in_row_stride)"""
+    from languagegroundedsemseg_amd import engine
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    coords, _, _ = make_batch([13, 14], voxel=0.02, n_target=112000)
+    n = coords.shape[0]
+    x = ME.SparseTensor(torch.zeros(n, 3, device=DEV), torch.from_numpy(coords).to(DEV))
+    km = x.coordinate_manager.kernel_map_handle(x.coordinate_map_key, x.coordinate_map_key, 3)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    big = torch.randn(n, 544, device=DEV, generator=g).bfloat16()
+    gout = torch.randn(n, 256, device=DEV, generator=g).bfloat16()
+    sl = big[:, :512]
+    assert not sl.is_contiguous()
+    assert engine.lib().lgs_conv_wgrad_supports_stride(km.h, 0, 512, 256, engine.LGS_BF16, 544) == 1
+    engine.dispatch_counts(reset=True)
+    a = km.conv_wgrad(sl, gout, False)
+    b = km.conv_wgrad(sl.contiguous(), gout, False)
+    torch.cuda.synchronize()
+    hits = _wide_hits(engine)
+    assert hits and all(v == 2 for v in hits.values()), hits
+    assert torch.equal(a, b)
+    # a second, offset slice (columns 32 .. 543) as well
+    sl2 = big[:, 32:544]
+    assert torch.equal(km.conv_wgrad(sl2, gout, False), km.conv_wgrad(sl2.contiguous(), gout, False))
+
+
+# ------------------------------------------------------------------------------------------- BatchNorm eval cache
+def _bn_eval_ref(bn, x):
+    return torch.nn.functional.batch_norm(x.float(), bn.bn.running_mean, bn.bn.running_var, bn.bn.weight, bn.bn.bias, False, 0.0, bn.bn.eps)
+
+
+@pytest.mark.parametrize("sync", [False, True])
+def test_eval_statistics_follow_training_updates(sync):
+    """train -> eval -> train -> eval on one MinkowskiBatchNorm: a Lightning-style sanity validation BEFORE training caches
+    [mean | invstd]; the engine then updates running_mean / running_var through raw pointers (lgs_bn_forward), which torch's
+    version counters did not see, so the second validation silently reused the first one's statistics."""
+    torch.manual_seed(2)
+    n, c = 6001, 64
+    coords = torch.cat([torch.zeros(n, 1, dtype=torch.int32), torch.arange(n, dtype=torch.int32)[:, None].repeat(1, 3)], 1).to(DEV)
+    xs = ME.SparseTensor(torch.randn(n, c, device=DEV) * 3 + 1.5, coords)
+    bn = (ME.MinkowskiSyncBatchNorm if sync else ME.MinkowskiBatchNorm)(c, momentum=0.5).to(DEV)
+    bn.eval()
+    y0 = bn(xs).F                                              # sanity validation: running stats are still (0, 1)
+    assert rel_err(y0.cpu().numpy(), _bn_eval_ref(bn, xs.F).cpu().numpy()) < 1e-5
+    v0 = bn.bn.running_mean._version
+    bn.train()
+    for _ in range(2):
+        bn(xs)                                                 # the engine moves the running statistics
+    assert bn.bn.running_mean._version > v0                    # ... and says so
+    assert float(bn.bn.running_mean.abs().max()) > 0.5
+    bn.eval()
+    y1 = bn(xs).F
+    assert rel_err(y1.cpu().numpy(), _bn_eval_ref(bn, xs.F).cpu().numpy()) < 1e-5
+    assert not torch.allclose(y0, y1)
+    bn.train(); bn(xs); bn.eval()
+    y2 = bn(xs).F
+    assert rel_err(y2.cpu().numpy(), _bn_eval_ref(bn, xs.F).cpu().numpy()) < 1e-5
+
+
+def test_model_validation_after_training_uses_fresh_statistics():
+    """the same through the whole-block fast path (it calls lgs_bn_forward itself): eval logits of Res16UNet14A after two
+    training steps equal those of a copy whose eval caches never existed"""
+    import copy
+    from languagegroundedsemseg_amd import models
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    coords, feats, labels = make_batch([0], voxel=0.05, n_target=20000)
+    m = deterministic_init(models.load_model("Res16UNet14A")(3, 20, Cfg()), 42).to(DEV)
+    x = lambda: ME.SparseTensor(torch.from_numpy(feats).to(DEV), torch.from_numpy(coords).to(DEV))
+    m.eval()
+    with torch.no_grad():
+        before = m(x())[0].F.clone()
+    m.train()
+    for _ in range(2):
+        m(x())[0].F.float().sum().backward()
+    m.eval()
+    with torch.no_grad():
+        after = m(x())[0].F.clone()
+    fresh = models.load_model("Res16UNet14A")(3, 20, Cfg()).to(DEV)
+    fresh.load_state_dict(copy.deepcopy(m.state_dict()))
+    fresh.eval()
+    with torch.no_grad():
+        want = fresh(x())[0].F
+    assert torch.equal(after, want)
+    assert not torch.allclose(after, before)
+
+
+# ------------------------------------------------------------------------------------------- block fast path guard
+def test_block_fast_path_declines_other_conv_shapes():
+    from languagegroundedsemseg_amd import models
+    from languagegroundedsemseg_amd.models import BasicBlock, _block_fast_path_ok
+    coords = torch.cat([torch.zeros(500, 1, dtype=torch.int32), torch.randint(0, 12, (500, 3), dtype=torch.int32)], 1).unique(dim=0).to(DEV)
+    x = ME.SparseTensor(torch.randn(coords.shape[0], 32, device=DEV), coords)
+    blk = BasicBlock(32, 32, D=3).to(DEV).train()
+    assert _block_fast_path_ok(blk, x)
+    odd = BasicBlock(32, 32, D=3)
+    odd.conv2 = ME.MinkowskiConvolution(32, 32, kernel_size=1, stride=1, dimension=3)
+    odd = odd.to(DEV).train()
+    assert not _block_fast_path_ok(odd, x)
+    y = odd(x)                                                  # and the op-by-op path computes it (1x1 second conv)
+    assert y.F.shape == x.F.shape and torch.isfinite(y.F).all()

@@ -61,6 +61,12 @@ def _worker(rank, port, ret):
         assert not db.reduce
         gb, pb, _ = _step(b, db, FlatSGD(db, lr=0.1, momentum=0.9, dampening=0.1, weight_decay=1e-4), coords, feats, dev)
         same = all(torch.equal(ga[k], gb[k]) for k in gb) and all(torch.equal(pa[k], pb[k]) for k in pb) and set(ga) == set(gb)
+        # (1b) the same buckets as reduce-scatter + all-gather IN PLACE on the flat bucket (reduce_scatter_tensor with the output
+        # a slice of the input, all_gather_into_tensor back into it): RCCL's in-place forms, as `--allreduce rs_ag` issues them
+        e = build(False)
+        de = BucketedDDP(e, bucket_mb=1.0, force_collectives=True, allreduce="rs_ag")
+        ge, pe, _ = _step(e, de, FlatSGD(de, lr=0.1, momentum=0.9, dampening=0.1, weight_decay=1e-4), coords, feats, dev)
+        same_rs = all(torch.equal(ge[k], gb[k]) for k in gb) and all(torch.equal(pe[k], pb[k]) for k in pb) and set(ge) == set(gb)
         # (2) + SyncBN records through RCCL all_gather_into_tensor / all_reduce (Chan's combination of ONE record is
         # the same statistics up to the last float bit: compared with a tolerance, not bitwise)
         f32 = feats.float()
@@ -74,7 +80,7 @@ def _worker(rank, port, ret):
         ME.MinkowskiSyncBatchNorm.force_sync = False
         worst = max(float((gc_[k] - gd[k]).norm() / gd[k].norm().clamp_min(1e-12)) for k in gd)
         rm = float((c.bn0.bn.running_mean - d.bn0.bn.running_mean).abs().max())
-        ret["out"] = (same, worst, rm, int(c.bn0.bn.num_batches_tracked))
+        ret["out"] = (same, worst, rm, int(c.bn0.bn.num_batches_tracked), same_rs)
     finally:
         dist.destroy_process_group()
 
@@ -83,7 +89,8 @@ def test_rccl_collective_paths_with_one_rank_reproduce_the_local_step():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(_free_port(), ret), nprocs=1, join=True)
-    same, worst, rm, nbt = ret["out"]
+    same, worst, rm, nbt, same_rs = ret["out"]
     assert same, "RCCL all_reduce of the gradient buckets (world 1) must leave the step bit-identical"
+    assert same_rs, "RCCL in-place reduce_scatter_tensor + all_gather_into_tensor of the buckets (world 1) must leave the step bit-identical"
     print("SyncBN over RCCL (world 1) vs local BatchNorm: worst gradient rel-L2 %.3e, running_mean diff %.3e" % (worst, rm))
     assert worst < 2e-2 and rm < 1e-5 and nbt == 2

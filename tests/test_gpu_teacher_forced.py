@@ -135,10 +135,14 @@ class TeacherForcing:
         return fn
 
 
-def run_teacher_forced(model_name, coords, feats, loss_fn, n_out):
-    """-> (forward errors, backward errors, parameter-gradient errors, forcing object)"""
+_TAPES = {}     # the oracle's taped pass per (model, scene): minutes of CPU time, shared by the tests that replay it
+
+
+def oracle_tape(model_name, coords, feats, loss_fn, n_out, cache_key=None):
+    """the oracle's one bf16-storage pass, taped -> (tape, parameter gradients, loss)"""
+    if cache_key is not None and cache_key in _TAPES:
+        return _TAPES[cache_key]
     dtype = torch.bfloat16
-    # ---- the oracle's one bf16-storage pass, taped
     prev = ME.set_backend(OracleBackend("torch"))
     try:
         mo = deterministic_init(load_model(model_name)(3, n_out, Cfg()), 42).train()
@@ -153,6 +157,16 @@ def run_teacher_forced(model_name, coords, feats, loss_fn, n_out):
     finally:
         ME.set_backend(prev)
     assert all(r["gy"] is not None for n, r in tape.rec.items()), "every taped module output must have received a gradient"
+    out = (tape, go, lo.detach())
+    if cache_key is not None:
+        _TAPES[cache_key] = out
+    return out
+
+
+def run_teacher_forced(model_name, coords, feats, loss_fn, n_out, cache_key=None):
+    """-> (forward errors, backward errors, parameter-gradient errors, forcing object)"""
+    dtype = torch.bfloat16
+    tape, go, lo = oracle_tape(model_name, coords, feats, loss_fn, n_out, cache_key)
     # ---- the HIP network, module by module on oracle inputs
     mh = deterministic_init(load_model(model_name)(3, n_out, Cfg()), 42).to(DEV).train()
     if hasattr(loss_fn, "prepare"):
@@ -234,7 +248,7 @@ def test_res16unet34c_bf16_layerwise_teacher_forced():
     assert abs(lh - lo) < 2e-3, (lh, lo)                   # the loss on the oracle's (teacher-forced) logits
 
 
-def test_res16unet34d_clip_bf16_layerwise_teacher_forced():
+def _clip_case():
     from languagegroundedsemseg_amd.losses import ContrastiveLanguageLoss
     from languagegroundedsemseg_amd.synthetic import make_batch, text_anchors
     coords, feats, _ = make_batch([9], voxel=0.02, n_target=70000)
@@ -243,7 +257,31 @@ def test_res16unet34d_clip_bf16_layerwise_teacher_forced():
     anchors = text_anchors(200, 512)
     neg = ContrastiveLanguageLoss(num_labels=200, num_negative_samples=3).sample_negatives(
         torch.from_numpy(labels), generator=torch.Generator().manual_seed(5))
-    fe, be, ge, tf, lh, lo = run_teacher_forced("Res16UNet34D", coords, feats, _ClipLoss(labels, anchors, neg), 20)
+    return coords, feats, _ClipLoss(labels, anchors, neg)
+
+
+def test_res16unet34d_clip_bf16_layerwise_teacher_forced():
+    coords, feats, loss = _clip_case()
+    fe, be, ge, tf, lh, lo = run_teacher_forced("Res16UNet34D", coords, feats, loss, 20, cache_key="34d")
     n_units = 62 + 62                                      # no classifier in representation_only mode
     check("34D + CLIP loss bf16", fe, be, ge, tf, n_units)
+    assert abs(lh - lo) < 2e-3, (lh, lo)
+
+
+def test_res16unet34d_teacher_forced_through_the_wide_weight_gradient():
+    """k_wgrad_wide is chosen in production for 3^3 layers with >= 256 x 256 channels on maps of >= 200 k positions -- the
+    benchmark's 8-scene batch; this 70 k-voxel scene takes k_wgrad_ps there.  The tuning knob WW_MIN_ROWS = 0 sends every such
+    layer of the SAME teacher-forced replay (level 0: 512 -> 512, 544 -> 512; level 1: 256 -> 256, 288 -> 256 ...) through
+    k_ww_count / k_ww_scan / k_ww_write / k_wgrad_wide / k_wgrad_wide_reduce: same per-tensor bound on every parameter gradient.
+    Reference: /root/reference/models/clip_models.py:205-215 (Res16UNet34D planes), scripts/text_representation_train.sh:7."""
+    from languagegroundedsemseg_amd import engine
+    coords, feats, loss = _clip_case()
+    engine.dispatch_counts(reset=True)
+    with engine.tuning(WW_MIN_ROWS=0):
+        fe, be, ge, tf, lh, lo = run_teacher_forced("Res16UNet34D", coords, feats, loss, 20, cache_key="34d")
+    hits = engine.dispatch_counts()
+    wide = {k: v for k, v in hits.items() if k.startswith("k_wgrad_wide") or k.startswith("k_ww_")}
+    print("wide weight-gradient launches:", wide)
+    assert sum(v for k, v in wide.items() if k.split()[0] == "k_wgrad_wide") >= 8, hits
+    check("34D + CLIP loss bf16, k_wgrad_wide", fe, be, ge, tf, 62 + 62)
     assert abs(lh - lo) < 2e-3, (lh, lo)
