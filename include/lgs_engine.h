@@ -74,6 +74,12 @@ int64_t lgs_debug_dispatch_counts(char *buf, int64_t cap, int reset);
  *   /root/reference/downstream/insseg/lib/pl_Trainer.py:263                                  */
 int lgs_manager_create(int device, lgs_manager **out);
 int lgs_manager_destroy(lgs_manager *mgr);
+/* Options of one manager, set before its maps are requested.  "halo" (0 / 1): 3^3 stride-1 kernel maps of at least
+ * HALO_MIN_ROWS positions also get halo tables -- per 256-position tile the list of distinct input rows and the kernel map as
+ * 16-bit slots into it -- which the bf16 convolutions of <= 128 channels then use (csrc/lgs_conv_halo.hip: every row is staged
+ * once per tile in LDS instead of being gathered once per offset).  The host side sets it for bf16 feature tensors
+ * (the call sites are the same SparseTensor constructions as above).  Unknown option -> error.                    */
+int lgs_manager_set_option(lgs_manager *mgr, const char *name, int64_t value);
 
 /* Insert coords[N,4] as the tensor-stride-1 map.  Dedups (first occurrence wins, surviving
  * rows keep input order).  Writes the map key to *key and the unique-row count to *n_unique

@@ -1007,6 +1007,26 @@ int pack_desc_t(const View &v, int K, int cin_w, int cout_w, int transposed_w, i
   return 0;
 }
 
+// ---- per-tile distinct-row kernel (lgs_conv_halo.hip) for 3^3 maps that carry halo tables: bf16, forward and dgrad
+inline bool halo_takes(const lgs_kmap *km, int transposed, int g_real, int o_real, int dtype, int in_ld) {
+  return km && km->ks == 3 && !transposed && dtype == LGS_BF16 && (in_ld == 0 || (in_ld * 2) % 16 == 0) &&
+         conv_halo_supported(km->halo, g_real, o_real, km->K);
+}
+// op 0 forward / 1 dgrad on the halo view: pack (unless the caller's image is up to date) and launch
+int conv_halo_op(lgs_kmap *km, int op, const void *in, int g_real, const float *weight, int cin_w, int cout_w, int o_real,
+                 const float *bias, void *out, void *workspace, hipStream_t s, int accum, void *packed_ext, int pack_mode, int in_ld) {
+  int ncp = 0, nbp = 0;
+  const int64_t total = conv_halo_pack_layout(g_real, o_real, &ncp, &nbp);
+  LGS_REQUIRE(total > 0, "halo conv: unsupported shape (internal error)");
+  uint4 *wp = reinterpret_cast<uint4 *>(packed_ext ? packed_ext : workspace);
+  if (!packed_ext) pack_mode = 0;
+  if (pack_mode != 2)
+    LGS_KLAUNCH((k_pack_weights<bf16_t>), (unsigned)((total + 255) / 256), 256, 0, s, weight, km->K, cin_w, cout_w, op, op, g_real, o_real,
+                ncp, nbp, wp);
+  LGS_HIP(hipGetLastError());
+  return launch_conv_halo(km->halo, op, in, g_real, in_ld, wp, ncp, nbp, out, o_real, bias, accum, s);
+}
+
 }  // namespace lgs
 
 using namespace lgs;
@@ -1029,6 +1049,7 @@ int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtyp
 
 int lgs_conv_bn_partial_rows(const lgs_kmap *km, int transposed, int cout, int dtype) {
   if (!km) return 0;
+  if (km->ks == 3 && km->halo.ok && dtype == LGS_BF16) return 0;    // the halo kernel has no statistics epilogue (any input width)
   const View &v = transposed ? km->bwd : km->fwd;
   if (dtype == LGS_F32) return bn_partial_rows_t<float>(v, km->K, cout);
   if (dtype == LGS_BF16) return bn_partial_rows_t<bf16_t>(v, km->K, cout);
@@ -1040,6 +1061,14 @@ int lgs_conv_pack_desc(const lgs_kmap *km, int op, int transposed, int cin, int 
   const View &v = op == 0 ? (transposed ? km->bwd : km->fwd) : (transposed ? km->fwd : km->bwd);
   const int mirror = (op == 1 && km->ks == 3) ? 1 : 0;
   const int g = op == 0 ? cin : cout, o = op == 0 ? cout : cin;
+  if (halo_takes(km, transposed, g, o, dtype, 0)) {
+    memset(out, 0, sizeof(*out));
+    out->total = conv_halo_pack_layout(g, o, &out->ncp, &out->nbp);
+    out->bytes = out->total * 16;
+    out->K = km->K; out->cin_w = cin; out->cout_w = cout; out->transposed = op; out->mirror = mirror;
+    out->g_real = g; out->o_real = o; out->dtype = dtype;
+    return 0;
+  }
   if (dtype == LGS_F32) return pack_desc_t<float>(v, km->K, cin, cout, op, mirror, g, o, dtype, out);
   if (dtype == LGS_BF16) return pack_desc_t<bf16_t>(v, km->K, cin, cout, op, mirror, g, o, dtype, out);
   LGS_REQUIRE(false, "lgs_conv_pack_desc: unknown dtype");
@@ -1066,6 +1095,8 @@ int lgs_conv_forward(lgs_kmap *km, int transposed, const void *in, int cin, cons
   bn.partial = bn_partial; bn.pivot = bn_pivot;
   LGS_REQUIRE(!bn_partial || lgs_conv_bn_partial_rows(km, transposed, cout, dtype) > 0,
               "lgs_conv_forward: this launch shape produces no BatchNorm statistics (see lgs_conv_bn_partial_rows)");
+  if (halo_takes(km, transposed, cin, cout, dtype, in_row_stride))
+    return conv_halo_op(km, 0, in, cin, weight, cin, cout, cout, bias, out, workspace, s, 0, packed, pack_mode, in_row_stride);
   if (dtype == LGS_F32) return conv_gather_op<float>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr, packed, pack_mode, in_row_stride);
   if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr, packed, pack_mode, in_row_stride);
   LGS_REQUIRE(false, "lgs_conv_forward: unknown dtype");
@@ -1079,6 +1110,8 @@ int lgs_conv_dgrad(lgs_kmap *km, int transposed, const void *grad_out, int cout,
   View vv = v; vv.mirror = (km->ks == 3) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   if (kmap_wait(km, s)) return 1;
+  if (halo_takes(km, transposed, cout, cin, dtype, 0))
+    return conv_halo_op(km, 1, grad_out, cout, weight, cin, cout, cin, nullptr, grad_in, workspace, s, 0, packed, pack_mode, 0);
   if (dtype == LGS_F32) return conv_gather_op<float>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, nullptr, packed, pack_mode);
   if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, nullptr, packed, pack_mode);
   LGS_REQUIRE(false, "lgs_conv_dgrad: unknown dtype");
@@ -1090,7 +1123,7 @@ int lgs_conv_dgrad_can_accumulate(const lgs_kmap *km, int transposed, int cin, i
   if (!km || (transposed && km->ks == 3) || cin % 4 != 0 || (dtype != LGS_F32 && dtype != LGS_BF16)) return 0;
   const View &v = transposed ? km->fwd : km->bwd;
   if (v.n_pad == 0) return 0;
-  (void)cout;
+  if (halo_takes(km, transposed, cout, cin, dtype, 0)) return 1;
   const int nb_total = pad32(cin) / 32;
   const int id = dtype == LGS_F32 ? gather_cfg<float>(v, nb_total).id : gather_cfg<bf16_t>(v, nb_total).id;
   return id == 17 ? 0 : 1;
@@ -1106,6 +1139,8 @@ int lgs_conv_dgrad_accumulate(lgs_kmap *km, int transposed, const void *grad_out
   View vv = v; vv.mirror = (km->ks == 3) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   if (kmap_wait(km, s)) return 1;
+  if (halo_takes(km, transposed, cout, cin, dtype, 0))
+    return conv_halo_op(km, 1, grad_out, cout, weight, cin, cout, cin, nullptr, grad_in, workspace, s, 1, packed, pack_mode, 0);
   BnEpi acc; acc.accum = 1;
   if (dtype == LGS_F32) return conv_gather_op<float>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, &acc, packed, pack_mode);
   return conv_gather_op<bf16_t>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, &acc, packed, pack_mode);

@@ -386,6 +386,11 @@ class HipManager:
         except Exception:
             pass
 
+    def hint_feature_dtype(self, dtype):
+        """bf16 features: the 3^3 maps of the big levels also get HALO tables (per-tile distinct-row lists + 16-bit slot maps,
+        csrc/lgs_conv_halo.hip), built with the map on the map stream; fp32 (the parity path) runs k_conv_gather and skips them"""
+        engine.check(engine.lib().lgs_manager_set_option(self.h, b"halo", 1 if dtype == torch.bfloat16 else 0))
+
     def insert(self, coords):
         _require_dev(coords, "coordinates")
         L = engine.lib()

@@ -72,11 +72,14 @@ class CoordinateManager:
         self.device = torch.device(device) if device is not None else None
         self._m = None
         self._keys = {}
+        self.feature_dtype = None
 
     def _ensure(self, device):
         if self._m is None:
             self.device = torch.device(device)
             self._m = self.backend.new_manager(self.device)
+            if self.feature_dtype is not None and hasattr(self._m, "hint_feature_dtype"):
+                self._m.hint_feature_dtype(self.feature_dtype)
         return self._m
 
     def _key(self, kid):
@@ -142,6 +145,7 @@ class SparseTensor:
             D = coordinates.shape[1] - 1
             if coordinate_manager is None:
                 coordinate_manager = CoordinateManager(D=D, device=features.device)
+                coordinate_manager.feature_dtype = features.dtype     # a hint for the backend's map builder (bf16: halo tables)
             key, (unique_index, inverse) = coordinate_manager.insert_and_map(coordinates, tensor_stride)
             self.unique_index, self.inverse_mapping = unique_index, inverse
             if unique_index.shape[0] != features.shape[0]:

@@ -15,6 +15,7 @@ from .kernel import KernelGenerator, RegionType, convert_to_int_list
 
 
 from .. import tuning as _tuning
+_WIDE_WGRAD_INLINE = _tuning.host("WIDE_WGRAD_INLINE") != 0
 _DBG_WGRAD = _tuning.host("DBG_WGRAD")   # "", "skip", "inline": step-time attribution experiments only
 
 
@@ -69,8 +70,13 @@ def conv_weight_grad(kmap, feats, gout, transposed, kparam, kshape, kdtype):
         return kmap.conv_wgrad(feats, gout, transposed).reshape(kshape).to(kdtype)
     if _DBG_WGRAD == "skip":
         return view                                      # profiling knob: no weight gradient at all
-    if _DBG_WGRAD == "inline" or getattr(kmap.mgr, "inline_wgrad", False):
-        # small (host-bound) batches, or the profiling knob: weight gradient on the compute stream
+    # >= 256 x 256-channel layers: both the weight gradient (k_wgrad_wide / wide k_wgrad_ps) and the dgrad running beside it on the
+    # compute stream (k_conv_wide) are MFMA-bound kernels that own their CUs -- concurrently they halve each other (round 3, CLIP
+    # step: dgrad 17.5 ms in-step vs 9.2 alone, weight gradient 15.9 vs 7.7, and the 1x1 512 -> 544 dgrad next to them 11.6 vs
+    # 1.3 ms), so there is nothing to overlap: they run back to back on the compute stream
+    wide = _WIDE_WGRAD_INLINE and feats.shape[1] >= 256 and gout.shape[1] >= 256
+    if _DBG_WGRAD == "inline" or wide or getattr(kmap.mgr, "inline_wgrad", False):
+        # small (host-bound) batches, wide layers, or the profiling knob: weight gradient on the compute stream
         kmap.conv_wgrad(feats, gout, transposed, out=view.view(kmap.K, -1, kshape[-1]))
         return view
     dev = gout.device

@@ -15,6 +15,8 @@ HOST_KNOBS = {
                            "(bit-identical: test_packed_weight_cache_never_serves_stale_weights)"),
     "ZERO_COPY_CAT": (1, int, "0 = ME.cat copies instead of both norms writing into the concat buffer "
                               "(bit-identical: test_zero_copy_cat_equals_the_copying_cat)"),
+    "WIDE_WGRAD_INLINE": (1, int, "0 = weight gradients of >= 256 x 256-channel layers go to the side stream like the narrow ones "
+                                  "(A/B: the MFMA-bound wide kernels halve each other when they run concurrently)"),
     "CONV_BN_STATS": ("", str, "'1' / 'big' = BatchNorm statistics from the conv epilogue (measured slower: 31.5 vs 30.9 ms; off)"),
     "DBG_WGRAD": ("", str, "'skip' / 'inline': step-time attribution experiments only ('skip' produces no weight gradients)"),
     "SET_HW_QUEUES": (0, int, "1 = importing the package sets GPU_MAX_HW_QUEUES=8 before the HIP runtime starts (see configure_hw_queues)"),

@@ -75,8 +75,30 @@ def test_wide_weight_gradient_reads_a_column_slice_in_place():
     assert torch.equal(km.conv_wgrad(sl2, gout, False), km.conv_wgrad(sl2.contiguous(), gout, False))
 
 
+@pytest.mark.parametrize("cin,cout,bias,dtype,tol", [(96, 200, True, torch.float32, 2e-5), (96, 200, True, torch.bfloat16, 2e-2),
+                                                      (512, 256, False, torch.bfloat16, 2e-2), (256, 512, False, torch.bfloat16, 2e-2)])
+def test_pointwise_conv_tiles_of_the_big_maps(cin, cout, bias, dtype, tol):
+    """1x1 convolutions on maps of >= 65536 positions take tile configurations no small-map test reaches (found by
+    tests/test_gpu_dispatch_coverage.py): the 7-block classifier tile (`final`, 96 -> 200 + bias, res16unet.py:193) in fp32 and
+    bf16, and the 8-wave 256-channel tile of the representation model's 1x1 downsample branches (clip_models.py:205-215) in both
+    directions (forward 512 -> 256 is its dgrad's 256 -> 512 shape and vice versa)"""
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    coords, _, _ = make_batch([4], voxel=0.02, n_target=80000)
+    assert coords.shape[0] >= 66000
+    feats = np.random.default_rng(5).standard_normal((coords.shape[0], cin)).astype(np.float32)
+    if dtype == torch.bfloat16:
+        feats = torch.from_numpy(feats).bfloat16().float().numpy()
+    (h_out, h_g), (o_out, o_g) = run_both(
+        lambda: [ME.MinkowskiConvolution(cin, cout, kernel_size=1, stride=1, bias=bias, dimension=3)], coords, feats, dtype=dtype,
+        oracle_impl="torch")
+    assert rel_err(h_out, o_out) < tol
+    for n, a, b in zip(["dgrad", "wgrad", "bgrad"], h_g, o_g):
+        assert rel_err(a, b) < tol * (5 if dtype == torch.float32 else 1), n
+
+
 # ------------------------------------------------------------------------------------------- BatchNorm eval cache
 def _bn_eval_ref(bn, x):
+    x = x.detach()
     return torch.nn.functional.batch_norm(x.float(), bn.bn.running_mean, bn.bn.running_var, bn.bn.weight, bn.bn.bias, False, 0.0, bn.bn.eps)
 
 
@@ -91,7 +113,7 @@ def test_eval_statistics_follow_training_updates(sync):
     xs = ME.SparseTensor(torch.randn(n, c, device=DEV) * 3 + 1.5, coords)
     bn = (ME.MinkowskiSyncBatchNorm if sync else ME.MinkowskiBatchNorm)(c, momentum=0.5).to(DEV)
     bn.eval()
-    y0 = bn(xs).F                                              # sanity validation: running stats are still (0, 1)
+    y0 = bn(xs).F.detach()                                     # sanity validation: running stats are still (0, 1)
     assert rel_err(y0.cpu().numpy(), _bn_eval_ref(bn, xs.F).cpu().numpy()) < 1e-5
     v0 = bn.bn.running_mean._version
     bn.train()
@@ -100,11 +122,11 @@ def test_eval_statistics_follow_training_updates(sync):
     assert bn.bn.running_mean._version > v0                    # ... and says so
     assert float(bn.bn.running_mean.abs().max()) > 0.5
     bn.eval()
-    y1 = bn(xs).F
+    y1 = bn(xs).F.detach()
     assert rel_err(y1.cpu().numpy(), _bn_eval_ref(bn, xs.F).cpu().numpy()) < 1e-5
     assert not torch.allclose(y0, y1)
     bn.train(); bn(xs); bn.eval()
-    y2 = bn(xs).F
+    y2 = bn(xs).F.detach()
     assert rel_err(y2.cpu().numpy(), _bn_eval_ref(bn, xs.F).cpu().numpy()) < 1e-5
 
 
