@@ -59,10 +59,14 @@ struct HaloCfg {
   static_assert(CAP >= kHaloT, "a tile's own rows must fit one segment");
 };
 
-template <int NC, int NB>
+// TRACE (tuning knob HALO_TRACE, debug instance): shader-clock sums of wave 0 of one tile in the middle of the grid:
+// [0] prologue (table + row staging + first slab, to the first barrier)  [1] weight prefetch issue  [2] multiply  [3] slab end
+// (weight store + barrier)  [4] epilogue  [5] slabs  [6] active (block, offset) pairs of the wave  [7] distinct rows
+template <int NC, int NB, bool TRACE>
 __global__ __launch_bounds__(256, 1) void k_conv_halo(HaloView hv, const bf16_t *__restrict__ in, int g_real, int in_ld, int npass,
                                                        const u32x4 *__restrict__ wp, int ncp, bf16_t *__restrict__ out, int o_real,
-                                                       const float *__restrict__ bias, int accum, unsigned in_bytes, unsigned w_bytes) {
+                                                       const float *__restrict__ bias, int accum, unsigned in_bytes, unsigned w_bytes,
+                                                       unsigned long long *trace) {
   using C = HaloCfg<NC, NB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -82,6 +86,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_halo(HaloView hv, const bf16_t 
   for (int g = 0; g < kHaloT / 64; ++g) smask |= v.mask64[pos0 / 64 + g];
   smask = __builtin_amdgcn_readfirstlane(smask);
   const int U = __builtin_amdgcn_readfirstlane(hv.ucount[tile]);
+  const bool tr = TRACE && trace != nullptr && blockIdx.x == (gridDim.x / 2 / 8) * 8 && wave == 0;
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tt0 = 0, tt1 = 0;
+  if (tr) { tt0 = __builtin_amdgcn_s_memtime(); tacc[7] = (unsigned long long)(U < 0 ? 0 : U); }
   const bool listed = U >= 0;                                   // false: per-offset staging
   const int nseg = listed ? (U + C::CAP - 1) / C::CAP : 27;
 
@@ -185,12 +192,14 @@ __global__ __launch_bounds__(256, 1) void k_conv_halo(HaloView hv, const bf16_t 
       wstore(0);
       LGS_HALO_VMCNT0();                                            // this wave's row pieces have landed
       __syncthreads();                                              // rows, table, klist, slab 0 visible
+      if (tr) { tt1 = __builtin_amdgcn_s_memtime(); tacc[0] += tt1 - tt0; tt0 = tt1; }
 
       const int nslab = (nk + C::G - 1) / C::G;
       int buf = 0;
       for (int slab = 0; slab < nslab; ++slab) {
         const bool more = slab + 1 < nslab;
         if (more) wload();                                          // in flight under this slab's multiply
+        if (tr) { tt1 = __builtin_amdgcn_s_memtime(); tacc[1] += tt1 - tt0; tt0 = tt1; tacc[5] += 1; }
         const int kcount = min(C::G, nk - slab * C::G);
         for (int oi = 0; oi < kcount; ++oi) {
           const int k = __builtin_ctz(crem);
@@ -200,27 +209,51 @@ __global__ __launch_bounds__(256, 1) void k_conv_halo(HaloView hv, const bf16_t 
           const bool ok0 = q0 < (unsigned)cnt, ok1 = q1 < (unsigned)cnt;
           const bool act0 = __ballot(ok0) != 0ull, act1 = __ballot(ok1) != 0ull;
           if (!act0 && !act1) continue;
+          if (tr) tacc[6] += (act0 ? 1 : 0) + (act1 ? 1 : 0);
           const char *a0 = l_rows + (ok0 ? q0 : (unsigned)C::CAP) * C::PITCH + h * 32;
           const char *a1 = l_rows + (ok1 ? q1 : (unsigned)C::CAP) * C::PITCH + h * 32;
           const char *wb = smem + C::O_W + buf * C::WSLAB + oi * C::WK + lane * 16;
           auto body = [&](auto A0, auto A1) __attribute__((always_inline)) {
             constexpr bool B0 = decltype(A0)::value, B1 = decltype(A1)::value;
+            // software pipeline over the 2 NC k-steps (16 channels each): the LDS reads of step s + 1 are issued in front of the
+            // MFMAs of step s (one wave per SIMD: nobody else covers the LDS latency), interleaved one read per MFMA; the
+            // sched_group_barriers pin that order (left alone, hipcc issued read -> lgkmcnt(0) -> 1-3 MFMAs, every latency exposed)
+            constexpr int NS = 2 * NC, NR = NB + (B0 ? 1 : 0) + (B1 ? 1 : 0), NM = NB * ((B0 ? 1 : 0) + (B1 ? 1 : 0));
+            u32x4 wf[2][NB], f0[2], f1[2];
+            auto rd = [&](int st, int b) __attribute__((always_inline)) {
+              const int c = st >> 1, t = st & 1;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
+              for (int nb = 0; nb < NB; ++nb) wf[b][nb] = *reinterpret_cast<const u32x4 *>(wb + ((c * NB + nb) * 2 + t) * 1024);
+              if constexpr (B0) f0[b] = *reinterpret_cast<const u32x4 *>(a0 + 64 * c + 16 * t);
+              if constexpr (B1) f1[b] = *reinterpret_cast<const u32x4 *>(a1 + 64 * c + 16 * t);
+            };
+            rd(0, 0);
 #pragma unroll
-              for (int t = 0; t < 2; ++t) {
-                u32x4 wf[NB], f0, f1;
+            for (int st = 0; st < NS; ++st) {
+              const int b = st & 1;
+              if (st + 1 < NS) rd(st + 1, b ^ 1);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) wf[nb] = *reinterpret_cast<const u32x4 *>(wb + ((c * NB + nb) * 2 + t) * 1024);
-                if constexpr (B0) f0 = *reinterpret_cast<const u32x4 *>(a0 + 64 * c + 16 * t);
-                if constexpr (B1) f1 = *reinterpret_cast<const u32x4 *>(a1 + 64 * c + 16 * t);
+              for (int nb = 0; nb < NB; ++nb) {
+                if constexpr (B0)
+                  acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[b][nb]), __builtin_bit_cast(bf16x8, f0[b]), acc[0][nb], 0, 0, 0);
+                if constexpr (B1)
+                  acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[b][nb]), __builtin_bit_cast(bf16x8, f1[b]), acc[1][nb], 0, 0, 0);
+              }
+            }
+            // schedule: [reads of step 0] then per step: MFMA / read alternating, the remaining MFMAs at the end
+            __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                  if constexpr (B0)
-                    acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[nb]), __builtin_bit_cast(bf16x8, f0), acc[0][nb], 0, 0, 0);
-                  if constexpr (B1)
-                    acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[nb]), __builtin_bit_cast(bf16x8, f1), acc[1][nb], 0, 0, 0);
+            for (int st = 0; st < NS; ++st) {
+              if (st + 1 < NS) {
+#pragma unroll
+                for (int i = 0; i < (NR < NM ? NR : NM); ++i) {
+                  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
+                if (NM > NR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+                if (NR > NM) __builtin_amdgcn_sched_group_barrier(0x100, NR - NM, 0);
+              } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
               }
             }
           };
@@ -228,11 +261,13 @@ __global__ __launch_bounds__(256, 1) void k_conv_halo(HaloView hv, const bf16_t 
           else if (act0) body(std::true_type{}, std::false_type{});
           else body(std::false_type{}, std::true_type{});
         }
+        if (tr) { tt1 = __builtin_amdgcn_s_memtime(); tacc[2] += tt1 - tt0; tt0 = tt1; }
         if (more) {
           wstore(buf ^ 1);                                          // last read before the previous slab's barrier
           __syncthreads();
           buf ^= 1;
         }
+        if (tr) { tt1 = __builtin_amdgcn_s_memtime(); tacc[3] += tt1 - tt0; tt0 = tt1; }
       }
     }
   }
@@ -265,6 +300,11 @@ __global__ __launch_bounds__(256, 1) void k_conv_halo(HaloView hv, const bf16_t 
         *reinterpret_cast<uint2 *>(dst + c0) = pk;
       }
     }
+  }
+  if (tr) {
+    tt1 = __builtin_amdgcn_s_memtime(); tacc[4] += tt1 - tt0;
+    if (lane == 0)
+      for (int i = 0; i < 8; ++i) trace[i] = tacc[i];
   }
 }
 
@@ -305,12 +345,28 @@ static int launch_halo_t(const HaloView &hv, const void *in, int g_real, int in_
   using C = HaloCfg<NC, NB>;
   static bool attr_set = false;
   if (!attr_set) {
-    LGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_halo<NC, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+    LGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_halo<NC, NB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+    LGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_halo<NC, NB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
     attr_set = true;
   }
   const unsigned nt = (unsigned)(hv.v.n_pad / kHaloT);
-  LGS_KLAUNCH((k_conv_halo<NC, NB>), dim3(nt), dim3(256), C::LDS, s, hv, reinterpret_cast<const bf16_t *>(in), g_real, in_ld, npass,
-              reinterpret_cast<const u32x4 *>(wp), ncp, reinterpret_cast<bf16_t *>(out), o_real, bias, accum, in_bytes, w_bytes);
+  if (tune(T_HALO_TRACE) != 0) {
+    static unsigned long long *trace = nullptr;
+    if (!trace) LGS_HIP(hipMalloc(&trace, 8 * sizeof(unsigned long long)));
+    LGS_HIP(hipMemsetAsync(trace, 0, 8 * sizeof(unsigned long long), s));
+    LGS_KLAUNCH((k_conv_halo<NC, NB, true>), dim3(nt), dim3(256), C::LDS, s, hv, reinterpret_cast<const bf16_t *>(in), g_real, in_ld, npass,
+                reinterpret_cast<const u32x4 *>(wp), ncp, reinterpret_cast<bf16_t *>(out), o_real, bias, accum, in_bytes, w_bytes, trace);
+    unsigned long long h[8];
+    LGS_HIP(hipStreamSynchronize(s));
+    LGS_HIP(hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[k_conv_halo trace] %d->%d NC %d NB %d: tile of %llu distinct rows, %llu slabs, %llu active (block, offset) pairs in wave 0; cycles: "
+            "prologue %llu  weight issue %llu  multiply %llu  slab end (store + barrier) %llu  epilogue %llu\n", g_real, o_real, NC, NB, h[7], h[5], h[6],
+            h[0], h[1], h[2], h[3], h[4]);
+    return 0;
+  }
+  LGS_KLAUNCH((k_conv_halo<NC, NB, false>), dim3(nt), dim3(256), C::LDS, s, hv, reinterpret_cast<const bf16_t *>(in), g_real, in_ld, npass,
+              reinterpret_cast<const u32x4 *>(wp), ncp, reinterpret_cast<bf16_t *>(out), o_real, bias, accum, in_bytes, w_bytes,
+              (unsigned long long *)nullptr);
   LGS_HIP(hipGetLastError());
   return 0;
 }

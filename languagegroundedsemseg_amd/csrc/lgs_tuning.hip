@@ -42,6 +42,7 @@ const Knob kKnobs[T_COUNT] = {
     {"CONV_WIDE", 1, "0 = >= 256-output-channel layers stay on k_conv_gather's 8-wave tile (id 16) instead of k_conv_wide (A/B)"},
     {"HALO", 1, "0 = 3^3 bf16 convolutions at <= 128 channels stay on k_conv_gather instead of the per-tile distinct-row kernel k_conv_halo (A/B)"},
     {"HALO_MIN_ROWS", 65536, "k_conv_halo is used on maps of at least this many positions"},
+    {"HALO_TRACE", 0, "k_conv_halo: print per-phase shader-clock sums of one workgroup's wave 0 (debug instance, synchronises)"},
 };
 std::atomic<int64_t> g_val[T_COUNT];
 std::once_flag g_once;

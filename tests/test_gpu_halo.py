@@ -63,8 +63,10 @@ def test_halo_conv_matches_gather_path_and_oracle_on_a_surface_scene(cin, cout):
     coords, _, _ = make_batch([3], voxel=0.02, n_target=80000)
     assert coords.shape[0] >= 66000
     (ho, hd, hits), (go, gd, nohits) = _conv_both_paths(coords, cin, cout)
-    supported = cout <= 128                                      # wider outputs stay on k_conv_gather (standard view)
-    assert (sum(hits.values()) == 2) == supported, hits         # forward + dgrad on the halo kernel
+    # forward + dgrad on the halo kernel; outputs wider than 128 channels stay on k_conv_gather (standard view): 96 -> 160 not at
+    # all, 192 -> 128 in the forward direction only (its dgrad writes 192 channels)
+    want = 0 if cout > 128 else (1 if cin > 128 else 2)
+    assert sum(hits.values()) == want, hits
     assert not nohits
     assert rel_l2(ho, go) < 2e-3 and rel_l2(hd, gd) < 2e-3, (rel_l2(ho, go), rel_l2(hd, gd))
     if (cin, cout) in ((96, 96), (128, 96), (32, 32)):           # and against the oracle (the other shapes: via the gather path above)

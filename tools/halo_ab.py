@@ -57,7 +57,11 @@ def main():
                 balg = M * cin * 2 + rows * cout * 2 + 8 * M + 27 * cin * cout * 2
                 line += " | %s(%s) fwd %.3f ms (%.2f TB/s alg) dgrad %.3f" % (name, ",".join(sorted(set(used))), tf, balg / tf / 1e9, td)
             d = float((outs[0] - outs[1]).norm() / outs[1].norm())
-            print(line + " | rel diff %.2e" % d)
+            print(line + " | rel diff %.2e" % d, flush=True)
+            if os.environ.get("HALO_AB_TRACE"):
+                with engine.tuning(HALO=1, HALO_TRACE=1):
+                    mh[lvl][2].conv_forward(f, w, None, False)
+                    torch.cuda.synchronize()
 
 
 if __name__ == "__main__":
