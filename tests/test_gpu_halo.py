@@ -1,5 +1,6 @@
 """k_conv_halo (csrc/lgs_conv_halo.hip): the per-tile distinct-row 3^3 convolution that bf16 layers of <= 128 channels take on
-maps that carry halo tables.  Held (a) to the fp32 oracle on bf16-rounded inputs like every bf16 per-op test (2e-2 max-norm),
+maps that carry halo tables -- with the tuning knob HALO = 1 (default 0: measured slower than k_conv_gather at the benchmark's
+shapes; the kernel stays parity-tested so that the measurement can be repeated).  Held (a) to the fp32 oracle on bf16-rounded inputs like every bf16 per-op test (2e-2 max-norm),
 (b) to the k_conv_gather path on the same inputs (same bf16 products, another summation order: <= 2e-3 rel-L2, i.e. bf16
 rounding flips only), on every instantiated (gathered-chunk, output-block) shape, forward and dgrad, on
   * a 2 cm surface scene of >= 65 k voxels (production gate HALO_MIN_ROWS),
@@ -19,6 +20,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 SHAPES = [(96, 96), (128, 96), (96, 128), (32, 32), (64, 64), (32, 64), (64, 32), (128, 128), (192, 128), (64, 96), (64, 128), (40, 24), (96, 160)]
+
+
+def _halo_shape_ok(g, o):
+    """mirror of halo_shape() in csrc/lgs_conv_halo.hip: gathered channels g -> (chunks per pass NC), outputs o -> blocks per pass"""
+    if g % 8 or o % 4 or g < 32 or o < 8 or o > 128:
+        return False
+    gc, nb = (g + 31) // 32, (o + 31) // 32
+    nc = gc if gc <= 3 else (2 if gc == 4 else (3 if gc == 6 else 0))
+    nbp = 2 if nb == 4 else nb
+    return (nc == 1 and nbp in (1, 2)) or (nc == 2 and 1 <= nbp <= 3) or (nc == 3 and nbp in (2, 3))
 
 
 def rel_l2(a, b):
@@ -65,16 +76,18 @@ def test_halo_conv_matches_gather_path_and_oracle_on_a_surface_scene(cin, cout):
     (ho, hd, hits), (go, gd, nohits) = _conv_both_paths(coords, cin, cout)
     # forward + dgrad on the halo kernel; outputs wider than 128 channels stay on k_conv_gather (standard view): 96 -> 160 not at
     # all, 192 -> 128 in the forward direction only (its dgrad writes 192 channels)
-    want = 0 if cout > 128 else (1 if cin > 128 else 2)
+    from languagegroundedsemseg_amd.me.backend_hip import _ptr  # noqa: F401
+    want = (1 if _halo_shape_ok(cin, cout) else 0) + (1 if _halo_shape_ok(cout, cin) else 0)
     assert sum(hits.values()) == want, hits
     assert not nohits
     assert rel_l2(ho, go) < 2e-3 and rel_l2(hd, gd) < 2e-3, (rel_l2(ho, go), rel_l2(hd, gd))
     if (cin, cout) in ((96, 96), (128, 96), (32, 32)):           # and against the oracle (the other shapes: via the gather path above)
         feats = torch.from_numpy(np.random.default_rng(5).standard_normal((coords.shape[0], cin)).astype(np.float32)).bfloat16().float().numpy()
         engine.dispatch_counts(reset=True)
-        (h_out, h_g), (o_out, o_g) = run_both(
-            lambda: [ME.MinkowskiConvolution(cin, cout, kernel_size=3, stride=1, dimension=3)], coords, feats, dtype=torch.bfloat16,
-            oracle_impl="torch")
+        with engine.tuning(HALO=1):
+            (h_out, h_g), (o_out, o_g) = run_both(
+                lambda: [ME.MinkowskiConvolution(cin, cout, kernel_size=3, stride=1, dimension=3)], coords, feats, dtype=torch.bfloat16,
+                oracle_impl="torch")
         assert sum(halo_hits(engine).values()) == 2
         assert rel_err(h_out, o_out) < 2e-2
         for n, a, b in zip(["dgrad", "wgrad"], h_g, o_g):
@@ -106,7 +119,8 @@ def test_halo_conv_on_dense_and_sparse_random_volumes(density, cin, cout):
 
 @pytest.mark.parametrize("n", [1, 37, 255, 256, 257, 1500])
 def test_halo_conv_on_tiny_and_ragged_maps(n):
-    coords = small_scene(n, n=max(n, 4), extent=10, batches=1)[:n]
+    coords = small_scene(n, n=6 * n + 16, extent=24, batches=1)[:n]
+    assert coords.shape[0] == n
     (ho, hd, hits), (go, gd, _) = _conv_both_paths(coords, 32, 32, min_rows=0)
     assert sum(hits.values()) == 2, hits
     assert ho.shape == go.shape == (n, 32)
@@ -118,6 +132,7 @@ def test_halo_conv_reads_a_strided_input_and_accumulates_in_the_epilogue():
     from languagegroundedsemseg_amd.synthetic import make_batch
     coords, _, _ = make_batch([5], voxel=0.02, n_target=80000)
     n = coords.shape[0]
+    engine.tuning_set("HALO", 1)
     x = ME.SparseTensor(torch.zeros(n, 3, device=DEV).bfloat16(), torch.from_numpy(coords).to(DEV))
     km = x.coordinate_manager.kernel_map_handle(x.coordinate_map_key, x.coordinate_map_key, 3)
     g = torch.Generator(device=DEV).manual_seed(1)
@@ -135,16 +150,26 @@ def test_halo_conv_reads_a_strided_input_and_accumulates_in_the_epilogue():
     assert engine.lib().lgs_conv_dgrad_can_accumulate(km.h, 0, 96, 96, engine.LGS_BF16) == 1
     want = km.conv_dgrad(gout, w, False) + t
     got = km.conv_dgrad(gout, w, False, accumulate_into=t.clone())
+    engine.tuning_set("HALO", 0)
     assert torch.equal(got, want)
 
 
-def test_fp32_tensors_get_no_halo_tables():
-    """the halo option follows the feature dtype: the fp32 parity path stays on k_conv_gather"""
+def test_halo_tables_follow_the_knob_and_the_feature_dtype():
+    """HALO = 1: the halo option follows the feature dtype (the fp32 parity path stays on k_conv_gather); default: nobody builds them"""
     from languagegroundedsemseg_amd import engine
     from languagegroundedsemseg_amd.synthetic import make_batch
     coords, _, _ = make_batch([5], voxel=0.02, n_target=80000)
     conv = ME.MinkowskiConvolution(32, 32, kernel_size=3, stride=1, dimension=3).to(DEV)
+    with engine.tuning(HALO=1):
+        engine.dispatch_counts(reset=True)
+        conv(ME.SparseTensor(torch.randn(coords.shape[0], 32, device=DEV), torch.from_numpy(coords).to(DEV)))
+        d = engine.dispatch_counts()
+        assert not any(k.startswith("k_conv_halo") or k.startswith("k_build_halo") for k in d), d
+        conv(ME.SparseTensor(torch.randn(coords.shape[0], 32, device=DEV).bfloat16(), torch.from_numpy(coords).to(DEV)))
+        d = engine.dispatch_counts()
+        assert any(k.startswith("k_conv_halo") for k in d) and any(k.startswith("k_build_halo") for k in d), d
+    # and with the knob at its default (off) a bf16 tensor stays on k_conv_gather too
+    assert engine.tuning_get("HALO") == 0
     engine.dispatch_counts(reset=True)
-    conv(ME.SparseTensor(torch.randn(coords.shape[0], 32, device=DEV), torch.from_numpy(coords).to(DEV)))
-    d = engine.dispatch_counts()
-    assert not any(k.startswith("k_conv_halo") or k.startswith("k_build_halo") for k in d), d
+    conv(ME.SparseTensor(torch.randn(coords.shape[0], 32, device=DEV).bfloat16(), torch.from_numpy(coords).to(DEV)))
+    assert not any(k.startswith("k_conv_halo") or k.startswith("k_build_halo") for k in engine.dispatch_counts())
