@@ -553,6 +553,59 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     return;
   }
   // ---- epilogue: lane (voxel vx, half h) owns channels nb*32 + 8q + 4h + {0..3}
+  // bf16 rows on the 8-channel grid: SIXTEEN-byte stores.  The accumulator layout gives a lane four 4-channel pieces (8 bytes of
+  // bf16 each) 16 bytes apart; the two half-wave lanes of a voxel hold interleaved pieces.  v_permlane32_swap trades piece
+  // q = 2p+1 of the h = 0 lane for piece q = 2p of the h = 1 lane, so that lane h owns the 8 contiguous channels
+  // nb*32 + 16p + 8h .. + 7: half as many store instructions (the kernel sits on the CU's vector-memory instruction rate, and
+  // the classifier's 200-channel rows are mostly stores).  Same values, same rounding -- only who writes them changes.
+  if constexpr (EPL == 8 && EPI == 0) {
+    if (!out_f32 && (cout_real & 7) == 0) {      // kernel-uniform
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        int64_t p = pos_wg + row_of(rb);
+        int32_t orow = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
+        T *dst = out + (int64_t)(orow < 0 ? 0 : orow) * cout_real;
+#pragma unroll
+        for (int nb = 0; nb < NCB; ++nb) {
+          if (nb_w + nb >= nb_total) continue;
+#pragma unroll
+          for (int pq = 0; pq < 2; ++pq) {
+            uint32_t pk[2][2];                   // [piece q = 2pq, 2pq+1][dword]
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int q = 2 * pq + e, c0 = (nb_w + nb) * 32 + 8 * q + 4 * h;
+              float o0 = acc[rb][nb][4 * q + 0], o1 = acc[rb][nb][4 * q + 1], o2 = acc[rb][nb][4 * q + 2], o3 = acc[rb][nb][4 * q + 3];
+              if (bias && c0 < cout_real) { o0 += bias[c0]; o1 += bias[c0 + 1]; o2 += bias[c0 + 2]; o3 += bias[c0 + 3]; }
+              pk[e][0] = (uint32_t)f32_to_bf16(o0) | ((uint32_t)f32_to_bf16(o1) << 16);
+              pk[e][1] = (uint32_t)f32_to_bf16(o2) | ((uint32_t)f32_to_bf16(o3) << 16);
+            }
+            // after the swaps: lane h holds [pk0 | pk1] = channels nb*32 + 16 pq + 8h + {0..3 | 4..7}
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+            const int c8 = (nb_w + nb) * 32 + 16 * pq + 8 * h;
+            if (orow >= 0 && c8 < cout_real) {
+              u32x4 val = {s0[0], s1[0], s0[1], s1[1]};
+              if (be.accum) {     // kernel-uniform: rounded exactly like "store the result, then add the two tensors"
+                const u32x4 prev = *reinterpret_cast<const u32x4 *>(dst + c8);
+                const uint32_t a[4] = {val.x, val.y, val.z, val.w}, b[4] = {prev.x, prev.y, prev.z, prev.w};
+                uint32_t r[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const float lo = __uint_as_float(a[i] << 16) + __uint_as_float(b[i] << 16);
+                  const float hi = __uint_as_float(a[i] & 0xffff0000u) + __uint_as_float(b[i] & 0xffff0000u);
+                  r[i] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+                }
+                val = u32x4{r[0], r[1], r[2], r[3]};
+              }
+              *reinterpret_cast<u32x4 *>(dst + c8) = val;
+            }
+          }
+        }
+      }
+      goto stats;
+    }
+  }
+  // ---- epilogue: lane (voxel vx, half h) owns channels nb*32 + 8q + 4h + {0..3}
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     int64_t p = pos_wg + row_of(rb);
@@ -591,6 +644,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
       }
     }
   }
+stats:
   if constexpr (EPI == 0) {
     if (be.partial != nullptr) {   // kernel-uniform
       // ---- BatchNorm statistics of this workgroup's rows.  Lane (vx, h) holds, per row block, the 16 NCB channels
@@ -698,6 +752,8 @@ GatherCfg gather_cfg(const View &v, int nb_total) {
   if (!kF32 && small_override == 9) return {9, 4, 4, 64};
   if (!kF32 && small_override == 10) return {10, 4, 2, 64};
   if (!kF32 && small_override == 11) return {11, 4, 4, 64};
+  if (!kF32 && small_override == 12) return {12, 8, 2, 128};
+  if (!kF32 && small_override == 13) return {13, 8, 4, 128};
   if (!kF32) return {8, 4, 2, 128};   // measured best on the L3/L4 shapes (tools/microbench.py coarse): 128 positions x 64 channels
   return {5, 2, 2, 64};
 }
@@ -793,6 +849,8 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
     case 9: LGS_LAUNCH(1, 2, 2, 2, 4, 6); break;
     case 10: LGS_LAUNCH(1, 2, 2, 1, 4, 6); break;
     case 11: LGS_LAUNCH(1, 4, 2, 1, 4, 6); break;
+    case 12: if constexpr (!kF32) LGS_LAUNCH(1, 2, 4, 1, 8, 6); break;     // as 8 with 8-chunk (256-channel) weight slabs: half the slab barriers
+    case 13: if constexpr (!kF32) LGS_LAUNCH(1, 4, 4, 1, 8, 4); break;     // 128 positions x 128 channels, 8-chunk slabs
     default: LGS_LAUNCH(1, 1, 2, 2, (kF32 ? 2 : 4), (kF32 ? 4 : 8)); break;
   }
 #undef LGS_LAUNCH

@@ -74,7 +74,8 @@ def conv_weight_grad(kmap, feats, gout, transposed, kparam, kshape, kdtype):
     # compute stream (k_conv_wide) are MFMA-bound kernels that own their CUs -- concurrently they halve each other (round 3, CLIP
     # step: dgrad 17.5 ms in-step vs 9.2 alone, weight gradient 15.9 vs 7.7, and the 1x1 512 -> 544 dgrad next to them 11.6 vs
     # 1.3 ms), so there is nothing to overlap: they run back to back on the compute stream
-    wide = _WIDE_WGRAD_INLINE and feats.shape[1] >= 256 and gout.shape[1] >= 256
+    # (big maps only: the 256-channel layers of the coarse levels are latency-bound launches that DO overlap)
+    wide = _WIDE_WGRAD_INLINE and feats.shape[1] >= 256 and gout.shape[1] >= 256 and gout.shape[0] >= 65536
     if _DBG_WGRAD == "inline" or wide or getattr(kmap.mgr, "inline_wgrad", False):
         # small (host-bound) batches, wide layers, or the profiling knob: weight gradient on the compute stream
         kmap.conv_wgrad(feats, gout, transposed, out=view.view(kmap.K, -1, kshape[-1]))

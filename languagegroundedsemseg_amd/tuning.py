@@ -15,8 +15,9 @@ HOST_KNOBS = {
                            "(bit-identical: test_packed_weight_cache_never_serves_stale_weights)"),
     "ZERO_COPY_CAT": (1, int, "0 = ME.cat copies instead of both norms writing into the concat buffer "
                               "(bit-identical: test_zero_copy_cat_equals_the_copying_cat)"),
-    "WIDE_WGRAD_INLINE": (1, int, "0 = weight gradients of >= 256 x 256-channel layers go to the side stream like the narrow ones "
-                                  "(A/B: the MFMA-bound wide kernels halve each other when they run concurrently)"),
+    "WIDE_WGRAD_INLINE": (0, int, "1 = weight gradients of >= 256 x 256-channel layers on big maps run on the compute stream instead of the side "
+                                  "stream (A/B, round 4: CLIP step 166.8 vs 164.0 ms -- every wide kernel then runs at its stand-alone time, "
+                                  "e.g. the 1x1 512->544 dgrad 1.37 instead of 11.6 ms, but the step is the sum of its kernels either way)"),
     "CONV_BN_STATS": ("", str, "'1' / 'big' = BatchNorm statistics from the conv epilogue (measured slower: 31.5 vs 30.9 ms; off)"),
     "DBG_WGRAD": ("", str, "'skip' / 'inline': step-time attribution experiments only ('skip' produces no weight gradients)"),
     "SET_HW_QUEUES": (0, int, "1 = importing the package sets GPU_MAX_HW_QUEUES=8 before the HIP runtime starts (see configure_hw_queues)"),
