@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LGS_ABI_VERSION 8
+#define LGS_ABI_VERSION 9
 
 enum lgs_dtype { LGS_F32 = 0, LGS_BF16 = 1 };
 
@@ -234,6 +234,53 @@ int lgs_bn_backward_reduce(const void *x, const void *y, const void *dy, int64_t
 int lgs_bn_backward_apply(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
                           const float *beta, const float *stats, const float *sums, float inv_n_total,
                           const float *inv_n_device, int relu, void *dx, void *dresidual, int dtype, void *stream);
+
+/* ---- one call per residual block and direction (csrc/lgs_block.hip) -----------------------------
+ * replaces the call sequence of BasicBlock.forward and of its autograd backward
+ *   /root/reference/models/modules/resnet_block.py:41-57   (conv1 - norm1 - relu - conv2 - norm2 - (+ residual) - relu)
+ *   /root/reference/models/resnet.py:93-103                 (downsample = 1x1 conv + norm on the residual branch)
+ * for batches small enough that the training step is bound by the HOST enqueueing ~250 engine calls (one ~150 k-voxel
+ * scene per step).  Exactly the launches of the call-by-call path, in the same order, on the caller's stream: results are
+ * bit-identical.  Every pointer is a device pointer owned by the caller; packed weight images / modes as in lgs_conv_forward
+ * (forward images for lgs_block_forward, dgrad images for lgs_block_backward).  Training mode only (batch statistics).     */
+typedef struct lgs_bn_params {
+  const float *gamma, *beta;
+  float *running_mean, *running_var;     /* may be NULL together */
+  int64_t *num_batches_tracked;          /* may be NULL */
+  float eps, momentum;
+} lgs_bn_params;
+typedef struct lgs_block_fwd {
+  lgs_kmap *km3, *km1;                   /* 3^3 map of the level; 1x1 map (NULL = no downsample branch) */
+  int dtype, relu_final, cin, planes;
+  int64_t n;                             /* rows of the level */
+  const void *x;                         /* [n, cin] */
+  const float *w1, *w2, *wd;             /* fp32 [27, cin, planes], [27, planes, planes], [cin, planes] or NULL */
+  void *pk1, *pk2, *pkd;                 /* packed images (lgs_conv_pack_desc, op 0) or NULL */
+  int pm1, pm2, pmd;                     /* pack modes as for lgs_conv_forward */
+  lgs_bn_params n1, n2, nd;
+  void *o1, *y1, *o2, *od, *res, *y2;    /* [n, planes] outputs: conv1, norm1+relu, conv2, downsample conv, its norm, block output */
+  float *st1, *st2, *std_;               /* [2 planes] mean | invstd of the three norms (saved for backward) */
+  void *conv_ws, *bn_ws;                 /* lgs_block_workspace_bytes / lgs_bn_workspace_bytes(n, planes) */
+} lgs_block_fwd;
+typedef struct lgs_block_bwd {
+  lgs_kmap *km3, *km1;
+  int dtype, relu_final, cin, planes, want_gin, x_row_stride;   /* x_row_stride: elements, 0 = cin (zero-copy cat slices) */
+  int64_t n, dy_row_stride;              /* dy_row_stride: elements, 0 = planes */
+  const void *dy;                        /* [n, planes] upstream gradient */
+  const void *x, *o1, *y1, *o2, *y2, *od;               /* saved by the forward (y2 only when relu_final; od with km1) */
+  const float *st1, *st2, *std_;
+  const float *w1, *w2, *wd;
+  void *pk1, *pk2, *pkd;                 /* packed DGRAD images (lgs_conv_pack_desc, op 1) or NULL */
+  int pm1, pm2, pmd;
+  const float *gamma1, *beta1, *gamma2, *beta2, *gammad, *betad;
+  void *dx2, *dres, *dy1, *dx1, *dxd, *gind;            /* [n, planes] x5 scratch / results, gind [n, cin] (km1 only) */
+  float *gw1, *gw2, *gwd;                /* weight gradients, fp32, parameter shapes (e.g. views of gradient-bucket slots) */
+  float *dgamma1, *dbeta1, *dgamma2, *dbeta2, *dgammad, *dbetad;
+  void *conv_ws, *bn_ws;
+} lgs_block_bwd;                         /* grad_in: dres (no downsample) or gind (with), accumulated in place */
+int64_t lgs_block_workspace_bytes(const lgs_kmap *km3, const lgs_kmap *km1, int cin, int planes, int dtype);
+int lgs_block_forward(const lgs_block_fwd *args, void *stream);
+int lgs_block_backward(const lgs_block_bwd *args, void *stream);
 
 /* ---- CLIP text-anchor contraction (MFMA) ----------------------------------------------------
  * replaces ContrastiveLanguageLoss.feat_dist (cos) + feature_sim

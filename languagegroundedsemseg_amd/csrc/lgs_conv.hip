@@ -273,7 +273,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
 
   // ---- gather indices of every visited slot are parked in LDS once (coalesced), so that the per-offset index
   // fetch is a ds_read (lgkmcnt) and never sits in the VMEM queue in front of the gather ring
-  __shared__ int32_t l_idx[27 * TM];
+  __shared__ __attribute__((aligned(16))) int32_t l_idx[27 * TM];
   // ---- feature-side iterator: flat sequence of (slot, chunk)
   // Order of the reduction: channel GROUPS of gc chunks outermost, then the offsets, then the chunks of the group.
   // gc = nc (one group) is the plain "offset by offset" order.  With wide rows (512 channels = 1 KB) the plain order
@@ -407,7 +407,28 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   // workgroup -- a quarter of its lifetime -- and the first weight fetch only started behind it).
   const bool whave = wadvance();
   if (whave) wissue(wreg);
-  if (v.nbr) {
+  // kernel-map rows of the tile: SIXTEEN-byte loads, four consecutive positions of one offset per lane (the table is
+  // offset-major and position tiles are 16-byte aligned): 27 x TM / 4 / 64 wave-instructions per tile instead of one 4-byte
+  // load per (offset, wave) -- 27 instead of 108 per 256-position tile of the ~900 vector-memory instructions the kernel is
+  // bound by.  Offsets the tile does not visit get an out-of-range address (zeros, never read).
+  const uint64_t idx_bytes = (uint64_t)v.KS * (uint64_t)v.n_pad * 4ull;
+  if (v.nbr && idx_bytes < 0xfffff000ull) {     // kernel-uniform
+    constexpr int Q = TM / 4, NU = (27 * Q + NT - 1) / NT;
+    const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(v.nbr), 0, (int)idx_bytes, 0x00020000);
+    u32x4 t4[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int e = tid + i * NT, sl = e / Q, q = e - sl * Q;
+      const bool ok = sl < v.KS && ((smask >> sl) & 1u);
+      const unsigned off = ok ? (unsigned)(((int64_t)sl * v.n_pad + pos_wg + 4 * q) * 4) : 0xfffff000u;
+      t4[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, off, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int e = tid + i * NT, sl = e / Q, q = e - sl * Q;
+      if (sl < 27) *reinterpret_cast<u32x4 *>(&l_idx[sl * TM + 4 * q]) = t4[i];
+    }
+  } else if (v.nbr) {
     constexpr int IT = (TM + NT - 1) / NT;
     int32_t tmp[27][IT];
 #pragma unroll

@@ -10,7 +10,7 @@ import os
 from . import build as _build
 
 LGS_F32, LGS_BF16 = 0, 1
-ABI_VERSION = 8     # LGS_ABI_VERSION of include/lgs_engine.h
+ABI_VERSION = 9     # LGS_ABI_VERSION of include/lgs_engine.h
 
 
 class PackDesc(ctypes.Structure):
@@ -19,6 +19,49 @@ class PackDesc(ctypes.Structure):
                 ("K", ctypes.c_int), ("cin_w", ctypes.c_int), ("cout_w", ctypes.c_int), ("transposed", ctypes.c_int),
                 ("mirror", ctypes.c_int), ("g_real", ctypes.c_int), ("o_real", ctypes.c_int), ("ncp", ctypes.c_int),
                 ("nbp", ctypes.c_int), ("dtype", ctypes.c_int)]
+
+class BnParams(ctypes.Structure):
+    """lgs_bn_params"""
+    _fields_ = [("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p),
+                ("num_batches_tracked", ctypes.c_void_p), ("eps", ctypes.c_float), ("momentum", ctypes.c_float)]
+
+
+class BlockFwd(ctypes.Structure):
+    """lgs_block_fwd (include/lgs_engine.h)"""
+    _fields_ = [("km3", ctypes.c_void_p), ("km1", ctypes.c_void_p),
+                ("dtype", ctypes.c_int), ("relu_final", ctypes.c_int), ("cin", ctypes.c_int), ("planes", ctypes.c_int),
+                ("n", ctypes.c_int64), ("x", ctypes.c_void_p),
+                ("w1", ctypes.c_void_p), ("w2", ctypes.c_void_p), ("wd", ctypes.c_void_p),
+                ("pk1", ctypes.c_void_p), ("pk2", ctypes.c_void_p), ("pkd", ctypes.c_void_p),
+                ("pm1", ctypes.c_int), ("pm2", ctypes.c_int), ("pmd", ctypes.c_int),
+                ("n1", BnParams), ("n2", BnParams), ("nd", BnParams),
+                ("o1", ctypes.c_void_p), ("y1", ctypes.c_void_p), ("o2", ctypes.c_void_p), ("od", ctypes.c_void_p),
+                ("res", ctypes.c_void_p), ("y2", ctypes.c_void_p),
+                ("st1", ctypes.c_void_p), ("st2", ctypes.c_void_p), ("std_", ctypes.c_void_p),
+                ("conv_ws", ctypes.c_void_p), ("bn_ws", ctypes.c_void_p)]
+
+
+class BlockBwd(ctypes.Structure):
+    """lgs_block_bwd (include/lgs_engine.h)"""
+    _fields_ = [("km3", ctypes.c_void_p), ("km1", ctypes.c_void_p),
+                ("dtype", ctypes.c_int), ("relu_final", ctypes.c_int), ("cin", ctypes.c_int), ("planes", ctypes.c_int),
+                ("want_gin", ctypes.c_int), ("x_row_stride", ctypes.c_int),
+                ("n", ctypes.c_int64), ("dy_row_stride", ctypes.c_int64), ("dy", ctypes.c_void_p),
+                ("x", ctypes.c_void_p), ("o1", ctypes.c_void_p), ("y1", ctypes.c_void_p), ("o2", ctypes.c_void_p),
+                ("y2", ctypes.c_void_p), ("od", ctypes.c_void_p),
+                ("st1", ctypes.c_void_p), ("st2", ctypes.c_void_p), ("std_", ctypes.c_void_p),
+                ("w1", ctypes.c_void_p), ("w2", ctypes.c_void_p), ("wd", ctypes.c_void_p),
+                ("pk1", ctypes.c_void_p), ("pk2", ctypes.c_void_p), ("pkd", ctypes.c_void_p),
+                ("pm1", ctypes.c_int), ("pm2", ctypes.c_int), ("pmd", ctypes.c_int),
+                ("gamma1", ctypes.c_void_p), ("beta1", ctypes.c_void_p), ("gamma2", ctypes.c_void_p), ("beta2", ctypes.c_void_p),
+                ("gammad", ctypes.c_void_p), ("betad", ctypes.c_void_p),
+                ("dx2", ctypes.c_void_p), ("dres", ctypes.c_void_p), ("dy1", ctypes.c_void_p), ("dx1", ctypes.c_void_p),
+                ("dxd", ctypes.c_void_p), ("gind", ctypes.c_void_p),
+                ("gw1", ctypes.c_void_p), ("gw2", ctypes.c_void_p), ("gwd", ctypes.c_void_p),
+                ("dgamma1", ctypes.c_void_p), ("dbeta1", ctypes.c_void_p), ("dgamma2", ctypes.c_void_p), ("dbeta2", ctypes.c_void_p),
+                ("dgammad", ctypes.c_void_p), ("dbetad", ctypes.c_void_p),
+                ("conv_ws", ctypes.c_void_p), ("bn_ws", ctypes.c_void_p)]
+
 
 _lib = None
 
@@ -33,6 +76,7 @@ EXPORTS = [
     "lgs_conv_wgrad_supports_stride", "lgs_conv_dgrad_can_accumulate", "lgs_conv_dgrad_accumulate",
     "lgs_conv_pack_desc", "lgs_pack_weights_batch",
     "lgs_bn_workspace_bytes", "lgs_bn_forward", "lgs_bn_backward",
+    "lgs_block_workspace_bytes", "lgs_block_forward", "lgs_block_backward",
     "lgs_bn_stats", "lgs_bn_sync_combine", "lgs_bn_apply", "lgs_bn_backward_reduce", "lgs_bn_backward_apply",
     "lgs_clip_similarity", "lgs_clip_workspace_bytes",
     "lgs_clip_loss_workspace_bytes", "lgs_clip_loss_forward", "lgs_clip_loss_backward",
@@ -65,6 +109,8 @@ def lib():
     L.lgs_last_error.restype = ctypes.c_char_p
     L.lgs_last_error.argtypes = []
     sig = {
+        "lgs_block_forward": [ctypes.POINTER(BlockFwd), vp],
+        "lgs_block_backward": [ctypes.POINTER(BlockBwd), vp],
         "lgs_tuning_set": [ctypes.c_char_p, i64],
         "lgs_tuning_get": [ctypes.c_char_p, pi64],
         "lgs_manager_create": [ci, pvp],
@@ -111,6 +157,8 @@ def lib():
     L.lgs_tuning_describe.argtypes = [ctypes.c_char_p, i64]
     L.lgs_debug_dispatch_counts.restype = i64
     L.lgs_debug_dispatch_counts.argtypes = [ctypes.c_char_p, i64, ci]
+    L.lgs_block_workspace_bytes.restype = i64
+    L.lgs_block_workspace_bytes.argtypes = [vp, vp, ci, ci, ci]
     L.lgs_cluster_workspace_bytes.restype = i64
     L.lgs_cluster_workspace_bytes.argtypes = [i64]
     L.lgs_conv_workspace_bytes.restype = i64

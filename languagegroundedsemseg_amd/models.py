@@ -140,12 +140,47 @@ def _bn_bwd(be, x, y, dy, g, b, gp, bp, stats, relu_mode, want_res, need):
     return dx, dres, (dg.to(g.dtype) if need else None), (db.to(g.dtype) if need else None)
 
 
+_BLOCK_C = _tuning.host("BLOCK_C") != 0
+
+
+def _c_block_ok(x, kmap3, kmap1, cin, planes, be):
+    """the one-call-per-direction entry points (csrc/lgs_block.hip) serve small batches (their weight gradients stay on the
+    compute stream) whose block input is a plain contiguous tensor and whose dgrad shape has the accumulating epilogue"""
+    if not (_BLOCK_C and getattr(kmap3.mgr, "inline_wgrad", False) and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32)):
+        return False
+    if getattr(be, "conv_bn_stats", False) or not hasattr(be, "block_forward"):
+        return False
+    key = ("cblk", cin, planes, x.dtype)
+    ok = kmap3._wsb.get(key)
+    if ok is None:
+        from . import engine
+        dt = engine.LGS_BF16 if x.dtype == torch.bfloat16 else engine.LGS_F32
+        ok = kmap3._wsb[key] = bool(engine.lib().lgs_conv_dgrad_can_accumulate(kmap3.h, 0, cin, planes, dt))
+    return ok
+
+
 class _BasicBlockFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, blk, kmap3, kmap1, w1, g1, b1, w2, g2, b2, wd=None, gd=None, bd=None):
         be = ME.get_backend()
         n1, n2 = blk.norm1.bn, blk.norm2.bn
         pc1, pc2 = blk.conv1._cache_for(x), blk.conv2._cache_for(x)
+        ctx.c_path = g1.dtype == torch.float32 and _c_block_ok(x, kmap3, kmap1, w1.shape[1], w1.shape[2], be)
+        if ctx.c_path:
+            # ONE engine call for the whole block (same launches, same order: bit-identical to the sequence below)
+            ctx.has_ds = wd is not None
+            nd = blk.downsample[1].bn if ctx.has_ds else None
+            pcd = blk.downsample[0]._cache_for(x) if ctx.has_ds else None
+            relu = bool(blk.final_relu)
+            o1, st1, y1, o2, st2, y2, od, std = be.block_forward(x, kmap3, kmap1, (w1, w2, wd), (pc1, pc2, pcd), (n1, n2, nd),
+                                                                 ((g1, b1), (g2, b2), (gd, bd)), relu)
+            ctx.kmap3, ctx.kmap1, ctx.relu, ctx.pc = kmap3, kmap1, relu, (pc1, pc2, pcd)
+            ctx.params = tuple(t if isinstance(t, nn.Parameter) else None for t in (w1, g1, b1, w2, g2, b2, wd, gd, bd))
+            if ctx.has_ds:
+                ctx.save_for_backward(x, w1, g1, b1, w2, g2, b2, o1, st1, y1, o2, st2, y2, wd, gd, bd, od, std)
+            else:
+                ctx.save_for_backward(x, w1, g1, b1, w2, g2, b2, o1, st1, y1, o2, st2, y2)
+            return y2
         # the conv epilogue also emits the next norm's statistics (off by default)
         want = bool(getattr(be, "conv_bn_stats", False)) and be.want_conv_bn_stats(x.shape[0], w1.shape[-1], x.element_size())
         o1, s1 = kmap3.conv_forward(x, w1, None, False, bn_pivot=n1.running_mean, want_bn_stats=True, pack_cache=pc1) if want else \
@@ -182,6 +217,9 @@ class _BasicBlockFunction(torch.autograd.Function):
         kmap3, (pc1, pc2, pcd) = ctx.kmap3, ctx.pc
         pw1, pg1, pb1, pw2, pg2, pb2, pwd, pgd, pbd = ctx.params
         # inputs: 0 x | 1 blk 2 kmap3 3 kmap1 | 4 w1 5 g1 6 b1 | 7 w2 8 g2 9 b2 | 10 wd 11 gd 12 bd
+        if ctx.c_path and all(need[i] for i in (4, 5, 6, 7, 8, 9)) and (not ctx.has_ds or all(need[i] for i in (10, 11, 12))):
+            extra = sv[13:] if ctx.has_ds else (None, None, None, None, None)
+            return be.block_backward(dy, sv[:13], extra, kmap3, ctx.kmap1, ctx.pc, ctx.params, ctx.relu, bool(need[0]))
         # norm2 (+ residual) (+ ReLU): mask from the saved output when there is a ReLU (a residual was added)
         dx2, dres, dg2, db2 = _bn_bwd(be, o2, y2 if ctx.relu else None, dy, g2, b2, pg2, pb2, st2, 1 if ctx.relu else 0, True,
                                       need[8] or need[9])

@@ -11,6 +11,8 @@ HOST_KNOBS = {
                                         "(host-bound regime: no fork / join events); larger ones use the side stream"),
     "BLOCK_FUSED": (1, int, "0 = BasicBlocks run module by module instead of as one autograd node "
                             "(bit-identical: test_block_fast_path_is_the_op_by_op_path)"),
+    "BLOCK_C": (1, int, "0 = small batches enqueue a BasicBlock call by call instead of through lgs_block_forward / lgs_block_backward "
+                        "(bit-identical: test_c_side_block_equals_the_call_by_call_block)"),
     "PACK_CACHE": (1, int, "0 = re-pack the MFMA weight image on every conv call instead of once per optimiser step "
                            "(bit-identical: test_packed_weight_cache_never_serves_stale_weights)"),
     "ZERO_COPY_CAT": (1, int, "0 = ME.cat copies instead of both norms writing into the concat buffer "

@@ -98,8 +98,8 @@ def test_pointwise_conv_tiles_of_the_big_maps(cin, cout, bias, dtype, tol):
 
 # ------------------------------------------------------------------------------------------- BatchNorm eval cache
 def _bn_eval_ref(bn, x):
-    x = x.detach()
-    return torch.nn.functional.batch_norm(x.float(), bn.bn.running_mean, bn.bn.running_var, bn.bn.weight, bn.bn.bias, False, 0.0, bn.bn.eps)
+    with torch.no_grad():
+        return torch.nn.functional.batch_norm(x.detach().float(), bn.bn.running_mean, bn.bn.running_var, bn.bn.weight, bn.bn.bias, False, 0.0, bn.bn.eps)
 
 
 @pytest.mark.parametrize("sync", [False, True])
@@ -171,3 +171,63 @@ def test_block_fast_path_declines_other_conv_shapes():
     assert not _block_fast_path_ok(odd, x)
     y = odd(x)                                                  # and the op-by-op path computes it (1x1 second conv)
     assert y.F.shape == x.F.shape and torch.isfinite(y.F).all()
+
+
+# ------------------------------------------------------------------------------------------- C-side block entry points
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("with_ddp", [True, False])
+def test_c_side_block_equals_the_call_by_call_block(monkeypatch, dtype, with_ddp):
+    """lgs_block_forward / lgs_block_backward (one engine call per BasicBlock and direction, the small-batch regime) issue the
+    launches of the call-by-call path in the same order: logits, every gradient (through the gradient-bucket slots and without
+    them) and the running statistics are bit-identical; Res16UNet34C has blocks with and without the 1x1 downsample branch and
+    without a final ReLU is covered by 34D's last block.  Reference: /root/reference/models/modules/resnet_block.py:41-57."""
+    from languagegroundedsemseg_amd import engine, models
+    from languagegroundedsemseg_amd.ddp import BucketedDDP
+    from languagegroundedsemseg_amd.losses import fused_cross_entropy
+    from languagegroundedsemseg_amd.me import backend_hip
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    coords, feats, labels = make_batch([8], voxel=0.05, n_target=9000)
+    c, f = torch.from_numpy(coords).to(DEV), torch.from_numpy(feats).to(DEV).to(dtype)
+    l = torch.from_numpy(labels % 20).to(DEV)
+    monkeypatch.setattr(backend_hip, "_WGRAD_INLINE_BELOW", 1 << 30)
+
+    def run(c_path, name):
+        monkeypatch.setattr(models, "_BLOCK_C", c_path)
+        be = ME.get_backend()
+        calls0 = getattr(be, "block_calls", 0)
+        m = deterministic_init(models.load_model(name)(3, 20, Cfg()), 11).to(DEV).train()
+        if name == "Res16UNet34D":
+            m.representation_only(True)
+        ddp = BucketedDDP(m, bucket_mb=1.0) if with_ddp else None
+        outs = []
+        for step in range(2):                                   # second step: running statistics of the first feed nothing, but must match
+            if ddp is not None:
+                ddp.zero_grad()
+            else:
+                m.zero_grad(set_to_none=True)
+            x = ME.SparseTensor(f, c)
+            assert x.coordinate_manager._m.inline_wgrad
+            engine.dispatch_counts(reset=True)
+            y = m(x)
+            out = y[0].F if isinstance(y, tuple) else y.F
+            loss = fused_cross_entropy(out[:, :20].contiguous(), l, ignore_index=-1) if out.shape[1] >= 20 else out.float().square().mean()
+            loss.backward()
+            if ddp is not None:
+                ddp.finalize()
+            torch.cuda.synchronize()
+            outs.append((out.detach().float().cpu().clone(),
+                         {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters() if p.grad is not None},
+                         {k: b.detach().float().cpu().clone() for k, b in m.named_buffers()}))
+        n_blocks = sum(1 for mod in m.modules() if isinstance(mod, models.BasicBlock) and not mod.cat_up)
+        assert getattr(be, "block_calls", 0) - calls0 == (2 * 2 * n_blocks if c_path else 0)     # fwd + bwd, two steps
+        return outs
+
+    for name in ("Res16UNet34C", "Res16UNet34D") if dtype == torch.bfloat16 else ("Res16UNet14A",):
+        a, b = run(True, name), run(False, name)
+        for (oa, ga, ba), (ob, gb, bb) in zip(a, b):
+            assert torch.equal(oa, ob), name
+            assert set(ga) == set(gb) and len(ga) > 50
+            for k in ga:
+                assert torch.equal(ga[k], gb[k]), (name, k)
+            for k in ba:
+                assert torch.equal(ba[k], bb[k]), (name, k)
