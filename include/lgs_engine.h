@@ -15,9 +15,10 @@
  *     (a hipStream_t cast to void*; NULL = default stream) and never synchronise.
  *   - coordinate-manager entry points build their maps on the manager's OWN stream; `stream` is the
  *     caller's stream, used only for ordering (inputs produced on it are waited for, outputs written
- *     to caller memory are published to it).  lgs_manager_insert / lgs_manager_stride2 /
- *     lgs_kmap_export synchronise the manager's stream once to return a row count to the host; they
- *     never wait for the caller's compute backlog.  Every compute call that takes an lgs_kmap
+ *     to caller memory are published to it).  lgs_manager_insert and lgs_kmap_export synchronise the
+ *     manager's stream once to return a row count to the host (never the caller's compute backlog);
+ *     the insert also counts the rows of the eight coarser levels, so lgs_manager_stride2 returns its
+ *     count WITHOUT a synchronisation (one host sync per input batch instead of five).  Every compute call that takes an lgs_kmap
  *     orders itself after the manager's map work with a stream-side event wait (no host sync).
  *   - return value: 0 = OK, non-zero = error; lgs_last_error() returns the message of the
  *     last failing call on this thread.  The Python side raises RuntimeError with it.

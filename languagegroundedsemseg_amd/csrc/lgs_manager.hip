@@ -151,6 +151,25 @@ __global__ void k_hash_insert(const uint64_t *skeys, const int32_t *order, int64
   }
 }
 
+// Row counts of ALL coarser levels from the sorted stride-1 keys: coarsening by 2^L drops the 3 L low Morton bits and keeps the
+// order, so the level-L map has one row per run of equal masked keys.  Counting the run heads of every level in the pass that
+// already exists for the insert lets lgs_manager_insert return them with ITS host synchronisation: the four
+// lgs_manager_stride2 calls of the U-Net then need none (5 host syncs per training step -> 1; duplicates of the input do not
+// matter: equal keys stay equal under any mask).
+constexpr int kPreLevels = 8;
+__global__ void k_count_levels(const uint64_t *__restrict__ skeys, int64_t n, int32_t *__restrict__ counts) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = p < n;
+  const uint64_t k = live ? skeys[p] : 0ull, q = (live && p > 0) ? skeys[p - 1] : ~0ull;
+#pragma unroll
+  for (int L = 1; L <= kPreLevels; ++L) {
+    const uint64_t mask = ~((1ull << (3 * L)) - 1ull);
+    const bool head = live && (p == 0 || (k & mask) != (q & mask));
+    const uint64_t b = __ballot(head);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&counts[L - 1], __popcll(b));
+  }
+}
+
 // 3x3x3 stride-1 map: one thread per sorted position, 27 probes; nbr is offset-major [27][n_pad]
 __global__ void k_build_map3(const uint64_t *skeys, int64_t n, int64_t n_pad, int ts, const uint64_t *hkeys,
                              const int32_t *hvals, uint64_t capm1, int32_t *nbr, uint32_t *pmask) {
@@ -426,6 +445,7 @@ struct lgs_manager {
   std::vector<Blk> blks;           // live arena blocks in allocation order (a stack: freed blocks on top are popped)
   size_t pool_live = 0, pool_peak = 0;
   int opt_halo = 0;                // lgs_manager_set_option("halo"): 3^3 maps also get halo tables (lgs_common.h HaloView)
+  int64_t precount[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // rows of the maps at tensor stride 2^(i+1), counted by the insert (-1: unknown)
 };
 
 namespace {
@@ -721,10 +741,16 @@ int lgs_manager_insert(lgs_manager *m, const int32_t *coords, int64_t n, int64_t
     LGS_HIP(hipMemsetAsync(urow, 0, sizeof(int32_t), s));
     if (scan_incl(m, is_first, urow + 1, n, s)) return 1;
   }
-  int32_t h_nu = 0; int h_err = 0;
+  int32_t *lvl_counts;
+  if (dalloc(m, &lvl_counts, kPreLevels, s)) return 1;
+  LGS_HIP(hipMemsetAsync(lvl_counts, 0, sizeof(int32_t) * kPreLevels, s));
+  LGS_KLAUNCH(k_count_levels, nblk(n), 256, 0, s, skeys, n, lvl_counts);
+  int32_t h_nu = 0; int h_err = 0; int32_t h_lvl[kPreLevels];
   LGS_HIP(hipMemcpyAsync(&h_nu, urow + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   LGS_HIP(hipMemcpyAsync(&h_err, m->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+  LGS_HIP(hipMemcpyAsync(h_lvl, lvl_counts, sizeof(int32_t) * kPreLevels, hipMemcpyDeviceToHost, s));
   LGS_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < kPreLevels; ++i) m->precount[i] = h_lvl[i];
   LGS_REQUIRE(h_err == 0,
               "lgs_manager_insert: coordinate out of range (batch must be in [0,1024), |x|,|y|,|z| < 131008)");
   int64_t nu = h_nu;
@@ -735,7 +761,7 @@ int lgs_manager_insert(lgs_manager *m, const int32_t *coords, int64_t n, int64_t
   if (inverse) LGS_KLAUNCH(k_emit_inverse, nblk(n), 256, 0, s, svals, runid, cm.order, n, inverse);
   LGS_HIP(hipGetLastError());
   if (dfree_now(m, keys, s) || dfree_now(m, skeys, s) || dfree_now(m, vals, s) || dfree_now(m, svals, s) ||
-      dfree_now(m, head, s) || dfree_now(m, runid, s) || dfree_now(m, is_first, s) || dfree_now(m, urow, s))
+      dfree_now(m, head, s) || dfree_now(m, runid, s) || dfree_now(m, is_first, s) || dfree_now(m, urow, s) || dfree_now(m, lvl_counts, s))
     return 1;
   m->maps.push_back(cm);
   *key = 0; *n_unique = nu;
@@ -768,10 +794,15 @@ int lgs_manager_stride2(lgs_manager *m, int in_key, void *stream, int *out_key, 
   if (dalloc(m, &head, n, s) || dalloc(m, &cincl, n, s)) return 1;
   LGS_KLAUNCH(k_heads, nblk(n), 256, 0, s, f.skeys, n, keep, head);
   if (scan_incl(m, head, cincl, n, s)) return 1;
-  int32_t h_nc = 0;
-  LGS_HIP(hipMemcpyAsync(&h_nc, cincl + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  LGS_HIP(hipStreamSynchronize(s));
-  int64_t nc = h_nc;
+  int64_t nc;
+  if (c.log2ts >= 1 && c.log2ts <= kPreLevels && m->precount[c.log2ts - 1] >= 0) {
+    nc = m->precount[c.log2ts - 1];                 // counted by lgs_manager_insert: no host synchronisation here
+  } else {
+    int32_t h_nc = 0;
+    LGS_HIP(hipMemcpyAsync(&h_nc, cincl + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    LGS_HIP(hipStreamSynchronize(s));
+    nc = h_nc;
+  }
   c.n = nc; c.n_pad = pad_rows(nc);
   if (dalloc(m, &c.coords, nc * 4, s) || dalloc(m, &c.skeys, nc, s) || dalloc(m, &c.cstart, nc + 1, s) ||
       dalloc(m, &c.fine_cidx, n, s))

@@ -63,6 +63,15 @@ class BlockBwd(ctypes.Structure):
                 ("conv_ws", ctypes.c_void_p), ("bn_ws", ctypes.c_void_p)]
 
 
+# struct-module formats of lgs_block_fwd / lgs_block_bwd (native alignment); checked against the ctypes layouts at import
+BLOCK_FWD_FMT = "@PPiiiiqP" + "PPP" + "PPP" + "iii" + "PPPPPff" * 3 + "PPPPPP" + "PPP" + "PP"
+BLOCK_BWD_FMT = "@PPiiiiiiqqP" + "PPPPPP" + "PPP" + "PPP" + "PPP" + "iii" + "PPPPPP" + "PPPPPP" + "PPP" + "PPPPPP" + "PP"
+import struct as _struct
+assert _struct.calcsize(BLOCK_FWD_FMT) == ctypes.sizeof(BlockFwd), (_struct.calcsize(BLOCK_FWD_FMT), ctypes.sizeof(BlockFwd))
+assert _struct.calcsize(BLOCK_BWD_FMT) == ctypes.sizeof(BlockBwd), (_struct.calcsize(BLOCK_BWD_FMT), ctypes.sizeof(BlockBwd))
+BLOCK_FWD_PACK = _struct.Struct(BLOCK_FWD_FMT)
+BLOCK_BWD_PACK = _struct.Struct(BLOCK_BWD_FMT)
+
 _lib = None
 
 # every symbol include/lgs_engine.h declares; tests check the built library exports all of them
@@ -109,8 +118,8 @@ def lib():
     L.lgs_last_error.restype = ctypes.c_char_p
     L.lgs_last_error.argtypes = []
     sig = {
-        "lgs_block_forward": [ctypes.POINTER(BlockFwd), vp],
-        "lgs_block_backward": [ctypes.POINTER(BlockBwd), vp],
+        "lgs_block_forward": [vp, vp],        # (const lgs_block_fwd *, stream): the host packs the struct with struct.pack_into
+        "lgs_block_backward": [vp, vp],
         "lgs_tuning_set": [ctypes.c_char_p, i64],
         "lgs_tuning_get": [ctypes.c_char_p, pi64],
         "lgs_manager_create": [ci, pvp],

@@ -570,6 +570,13 @@ class HipBackend:
         return dx, dres, dgamma, dbeta
 
     # ---- a whole BasicBlock per call (csrc/lgs_block.hip): small batches, everything on the compute stream
+    # host staging of lgs_block_fwd / lgs_block_bwd: one buffer per direction (forward runs on the caller's thread, backward on
+    # autograd's; the engine is single-threaded per process otherwise, include/lgs_engine.h)
+    _blk_args = ctypes.create_string_buffer(512)
+    _blk_addr = ctypes.addressof(_blk_args)
+    _blk_args_b = ctypes.create_string_buffer(512)
+    _blk_addr_b = ctypes.addressof(_blk_args_b)
+
     def _block_ws(self, L, kmap3, kmap1, cin, planes, dt, n, device):
         key = ("cblk_ws", cin, planes, dt)
         b = kmap3._wsb.get(key)
@@ -580,7 +587,8 @@ class HipBackend:
         return _ws(max(b, _bn_ws_bytes(L, n, planes)), device)
 
     def block_forward(self, x, kmap3, kmap1, ws3, pcs, norms, affines, relu_final):
-        """BasicBlock forward through lgs_block_forward -> (o1, st1, y1, o2, st2, y2, od, std)"""
+        """BasicBlock forward through lgs_block_forward -> (o1, st1, y1, o2, st2, y2, od, std).  The argument struct is packed
+        with ONE struct.pack_into call (setting ~50 ctypes fields one by one cost 60 us per block, more than the calls it saves)"""
         L = engine.lib()
         self.block_calls = getattr(self, "block_calls", 0) + 1
         w1, w2, wd = ws3
@@ -588,42 +596,38 @@ class HipBackend:
         planes = w1.shape[2]
         dt = _dtype_code(x)
         dev = x.device
-        a = engine.BlockFwd()
-        a.km3, a.km1 = kmap3.h.value, (kmap1.h.value if kmap1 is not None else None)
-        a.dtype, a.relu_final, a.cin, a.planes, a.n = dt, int(relu_final), cin, planes, n
-        a.x = x.data_ptr()
-        a.w1, a.w2 = w1.data_ptr(), w2.data_ptr()
+        ds = wd is not None
         pk = get_packed()
         with _dev(dev):
-            buf = torch.empty((6 if wd is not None else 4, n, planes), dtype=x.dtype, device=dev)
-            st = torch.empty((3 if wd is not None else 2, 2 * planes), dtype=torch.float32, device=dev)
-            p1, a.pm1 = pk.lookup(pcs[0], kmap3, 0, False, w1, w1, cin, planes, dt)
-            p2, a.pm2 = pk.lookup(pcs[1], kmap3, 0, False, w2, w2, planes, planes, dt)
-            a.pk1, a.pk2 = _ptr(p1), _ptr(p2)
-            o1, y1, o2, y2 = buf[0], buf[1], buf[2], buf[3]
-            od = res = std = None
-            if wd is not None:
-                a.wd = wd.data_ptr()
-                pd, a.pmd = pk.lookup(pcs[2], kmap1, 0, False, wd, wd, cin, planes, dt)
-                a.pkd = _ptr(pd)
-                od, res, std = buf[4], buf[5], st[2]
-                a.od, a.res, a.std_ = od.data_ptr(), res.data_ptr(), std.data_ptr()
-            a.o1, a.y1, a.o2, a.y2 = o1.data_ptr(), y1.data_ptr(), o2.data_ptr(), y2.data_ptr()
-            a.st1, a.st2 = st[0].data_ptr(), st[1].data_ptr()
+            buf = torch.empty((6 if ds else 4, n, planes), dtype=x.dtype, device=dev)
+            st = torch.empty((3 if ds else 2, 2 * planes), dtype=torch.float32, device=dev)
+            p1, pm1 = pk.lookup(pcs[0], kmap3, 0, False, w1, w1, cin, planes, dt)
+            p2, pm2 = pk.lookup(pcs[1], kmap3, 0, False, w2, w2, planes, planes, dt)
+            pd, pmd = pk.lookup(pcs[2], kmap1, 0, False, wd, wd, cin, planes, dt) if ds else (None, 0)
+            b0 = buf.data_ptr()
+            row = n * planes * x.element_size()
+            s0 = st.data_ptr()
+            srow = 2 * planes * 4
+            bn = []
             touched = []
-            for dst, bn, (g, b) in zip((a.n1, a.n2, a.nd), norms, affines):
-                if bn is None:
+            for m, (g, b) in zip(norms, affines):
+                if m is None:
+                    bn += [0, 0, 0, 0, 0, 0.0, 0.0]
                     continue
-                dst.gamma, dst.beta = g.data_ptr(), b.data_ptr()
-                dst.running_mean, dst.running_var = _ptr(bn.running_mean), _ptr(bn.running_var)
-                dst.num_batches_tracked = _ptr(bn.num_batches_tracked)
-                dst.eps, dst.momentum = float(bn.eps), float(bn.momentum)
-                touched += [bn.running_mean, bn.running_var, bn.num_batches_tracked]
-            cws = self._block_ws(L, kmap3, kmap1, cin, planes, dt, n, dev)
-            a.conv_ws, a.bn_ws = cws.data_ptr(), cws.data_ptr()
-            engine.check(L.lgs_block_forward(ctypes.byref(a), _stream()))
+                bn += [g.data_ptr(), b.data_ptr(), _ptr(m.running_mean) or 0, _ptr(m.running_var) or 0, _ptr(m.num_batches_tracked) or 0,
+                       float(m.eps), float(m.momentum)]
+                touched += [m.running_mean, m.running_var, m.num_batches_tracked]
+            cws = self._block_ws(L, kmap3, kmap1, cin, planes, dt, n, dev).data_ptr()
+            args = self._blk_args
+            engine.BLOCK_FWD_PACK.pack_into(
+                args, 0, kmap3.h.value, kmap1.h.value if ds else 0, dt, int(relu_final), cin, planes, n, x.data_ptr(),
+                w1.data_ptr(), w2.data_ptr(), wd.data_ptr() if ds else 0,
+                _ptr(p1) or 0, _ptr(p2) or 0, _ptr(pd) or 0, int(pm1), int(pm2), int(pmd), *bn,
+                b0, b0 + row, b0 + 2 * row, (b0 + 4 * row) if ds else 0, (b0 + 5 * row) if ds else 0, b0 + 3 * row,
+                s0, s0 + srow, (s0 + 2 * srow) if ds else 0, cws, cws)
+            engine.check(L.lgs_block_forward(self._blk_addr, _stream()))
         _written_by_engine(*touched)
-        return o1, st[0], y1, o2, st[1], y2, od, std
+        return buf[0], st[0], buf[1], buf[2], st[1], buf[3], (buf[4] if ds else None), (st[2] if ds else None)
 
     def block_backward(self, dy, saved, extra, kmap3, kmap1, pcs, params, relu_final, want_gin):
         """BasicBlock backward through lgs_block_backward -> the gradient tuple of models._BasicBlockFunction"""
@@ -637,29 +641,21 @@ class HipBackend:
         planes = w1.shape[2]
         dt = _dtype_code(x)
         dev = x.device
+        ds = wd is not None
         esz = dy.element_size()
         if (dy.dim() == 2 and dy.stride(1) == 1 and dy.stride(0) >= planes and (dy.stride(0) * esz) % 16 == 0
                 and dy.data_ptr() % 16 == 0 and dy.dtype == x.dtype):
             dy_ld = dy.stride(0)
         else:
             dy, dy_ld = dy.contiguous(), planes
-        a = engine.BlockBwd()
-        a.km3, a.km1 = kmap3.h.value, (kmap1.h.value if kmap1 is not None else None)
-        a.dtype, a.relu_final, a.cin, a.planes, a.want_gin, a.x_row_stride = dt, int(relu_final), cin, planes, int(want_gin), 0
-        a.n, a.dy_row_stride, a.dy = n, (0 if dy_ld == planes else dy_ld), dy.data_ptr()
-        a.x, a.o1, a.y1, a.o2 = x.data_ptr(), o1.data_ptr(), y1.data_ptr(), o2.data_ptr()
-        a.y2 = y2.data_ptr() if relu_final else None
-        a.st1, a.st2 = st1.data_ptr(), st2.data_ptr()
-        a.w1, a.w2 = w1.data_ptr(), w2.data_ptr()
-        a.gamma1, a.beta1, a.gamma2, a.beta2 = g1.data_ptr(), b1.data_ptr(), g2.data_ptr(), b2.data_ptr()
         pk = get_packed()
         with _dev(dev):
-            p1, a.pm1 = pk.lookup(pcs[0], kmap3, 1, False, w1, w1, cin, planes, dt)
-            p2, a.pm2 = pk.lookup(pcs[1], kmap3, 1, False, w2, w2, planes, planes, dt)
-            a.pk1, a.pk2 = _ptr(p1), _ptr(p2)
-            buf = torch.empty((5 if wd is not None else 4, n, planes), dtype=x.dtype, device=dev)
-            dx2, dres, dy1, dx1 = buf[0], buf[1], buf[2], buf[3]
-            a.dx2, a.dres, a.dy1, a.dx1 = dx2.data_ptr(), dres.data_ptr(), dy1.data_ptr(), dx1.data_ptr()
+            p1, pm1 = pk.lookup(pcs[0], kmap3, 1, False, w1, w1, cin, planes, dt)
+            p2, pm2 = pk.lookup(pcs[1], kmap3, 1, False, w2, w2, planes, planes, dt)
+            pd, pmd = pk.lookup(pcs[2], kmap1, 1, False, wd, wd, cin, planes, dt) if ds else (None, 0)
+            buf = torch.empty((5 if ds else 4, n, planes), dtype=x.dtype, device=dev)
+            b0 = buf.data_ptr()
+            row = n * planes * x.element_size()
 
             def wgrad_out(param, ref):
                 v = grad_slot_view(param) if param is not None else None
@@ -673,28 +669,31 @@ class HipBackend:
                     return t[0], t[1]
                 return gv, bv
             gw1, gw2 = wgrad_out(pw1, w1), wgrad_out(pw2, w2)
-            a.gw1, a.gw2 = gw1.data_ptr(), gw2.data_ptr()
             dg1, db1 = affine_out(pg1, pb1, planes)
             dg2, db2 = affine_out(pg2, pb2, planes)
-            a.dgamma1, a.dbeta1, a.dgamma2, a.dbeta2 = dg1.data_ptr(), db1.data_ptr(), dg2.data_ptr(), db2.data_ptr()
             gwd = dgd = dbd = gind = None
-            if wd is not None:
-                a.wd, a.od, a.std_ = wd.data_ptr(), od.data_ptr(), std.data_ptr()
-                a.gammad, a.betad = gd.data_ptr(), bd.data_ptr()
-                pd, a.pmd = pk.lookup(pcs[2], kmap1, 1, False, wd, wd, cin, planes, dt)
-                a.pkd = _ptr(pd)
+            if ds:
                 gwd = wgrad_out(pwd, wd)
                 dgd, dbd = affine_out(pgd, pbd, planes)
                 gind = torch.empty((n, cin), dtype=x.dtype, device=dev)
-                a.dxd, a.gind, a.gwd = buf[4].data_ptr(), gind.data_ptr(), gwd.data_ptr()
-                a.dgammad, a.dbetad = dgd.data_ptr(), dbd.data_ptr()
-            cws = self._block_ws(L, kmap3, kmap1, cin, planes, dt, n, dev)
-            a.conv_ws, a.bn_ws = cws.data_ptr(), cws.data_ptr()
-            engine.check(L.lgs_block_backward(ctypes.byref(a), _stream()))
-        gin = (gind if wd is not None else dres) if want_gin else None
+            cws = self._block_ws(L, kmap3, kmap1, cin, planes, dt, n, dev).data_ptr()
+            engine.BLOCK_BWD_PACK.pack_into(
+                self._blk_args_b, 0, kmap3.h.value, kmap1.h.value if ds else 0, dt, int(relu_final), cin, planes, int(want_gin), 0,
+                n, 0 if dy_ld == planes else dy_ld, dy.data_ptr(),
+                x.data_ptr(), o1.data_ptr(), y1.data_ptr(), o2.data_ptr(), y2.data_ptr() if relu_final else 0, od.data_ptr() if ds else 0,
+                st1.data_ptr(), st2.data_ptr(), std.data_ptr() if ds else 0,
+                w1.data_ptr(), w2.data_ptr(), wd.data_ptr() if ds else 0,
+                _ptr(p1) or 0, _ptr(p2) or 0, _ptr(pd) or 0, int(pm1), int(pm2), int(pmd),
+                g1.data_ptr(), b1.data_ptr(), g2.data_ptr(), b2.data_ptr(), gd.data_ptr() if ds else 0, bd.data_ptr() if ds else 0,
+                b0, b0 + row, b0 + 2 * row, b0 + 3 * row, (b0 + 4 * row) if ds else 0, gind.data_ptr() if ds else 0,
+                gw1.data_ptr(), gw2.data_ptr(), gwd.data_ptr() if ds else 0,
+                dg1.data_ptr(), db1.data_ptr(), dg2.data_ptr(), db2.data_ptr(), dgd.data_ptr() if ds else 0, dbd.data_ptr() if ds else 0,
+                cws, cws)
+            engine.check(L.lgs_block_backward(self._blk_addr_b, _stream()))
+        gin = (gind if ds else buf[1]) if want_gin else None
         # (all parameters of the fast path are fp32: the engine's fp32 gradients need no cast)
         out = (gin, None, None, None, gw1, dg1, db1, gw2, dg2, db2)
-        if wd is not None:
+        if ds:
             out = out + (gwd, dgd, dbd)
         return out
 
