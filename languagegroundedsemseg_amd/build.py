@@ -32,7 +32,8 @@ def build(force=False, verbose=False):
     procs = []
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("LGS_EXTRA_CFLAGS", "").split() + \
+              ["-c", os.path.join(CSRC, src), "-o", obj]      # LGS_EXTRA_CFLAGS: experiment builds only (e.g. -DLGS_CONV_DBG)
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

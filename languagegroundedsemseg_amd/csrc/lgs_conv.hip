@@ -161,6 +161,10 @@ struct BnEpi {
   float *partial = nullptr;     // [gridDim.x][2][cout_real]
   const float *pivot = nullptr; // [cout_real] or NULL
   int accum = 0;                // 1: out += result (lgs_conv_dgrad_accumulate: the residual branch's gradient is already in `out`)
+#ifdef LGS_CONV_DBG
+  int dbg = 0;                  // knock-out bits of an EXPERIMENT build (-DLGS_CONV_DBG, results wrong): 1 no MFMA, 2 no gathers, 4 no weight loads
+  unsigned long long *trace = nullptr;   // [4]: shader clocks of workgroup 0 / wave 0: start -> first barrier -> end of the main loop -> end
+#endif
 };
 // four adjacent stored elements -> fp32 (one 8- or 16-byte access)
 __device__ inline void load4(const float *p, float (&v)[4]) { const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
@@ -317,8 +321,12 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     act = 0;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
+#ifdef LGS_CONV_DBG
+      const bool ok = idx_i[rb] >= 0 && !(be.dbg & 2);
+#else
       const bool ok = idx_i[rb] >= 0;
-      if (__ballot(ok)) act |= 1u << rb;
+#endif
+      if (__ballot(idx_i[rb] >= 0)) act |= 1u << rb;
       const unsigned base = ok ? (unsigned)idx_i[rb] * row_bytes + (unsigned)(ichunk * 32 + h * 16) * (unsigned)sizeof(T) : kOOB;
 #pragma unroll
       for (int t = 0; t < LD; ++t) {
@@ -358,6 +366,9 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   auto wissue = [&](u32x4 (&wreg)[WR]) __attribute__((always_inline)) {
     const int kw = v.KS > 1 ? wslot : kw_single;  // 3^3 dgrad mirroring (K-1-k) is folded into the weight packing
     const unsigned sbase = (unsigned)((((int64_t)kw * ncp + wslab * SC) * nbp + nb_wg) * (LD * 64) * 16);
+#ifdef LGS_CONV_DBG
+    if (be.dbg & 4) return;
+#endif
 #pragma unroll
     for (int i = 0; i < WR; ++i) wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[i], sbase, 0);
   };
@@ -371,6 +382,9 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   float sumsq = 0.f;   // EPI = 1: |f|^2 of this lane's channel half of row vx
   auto compute = [&](int buf, int cc, const u32x4 (&F)[RB][LD], uint32_t act) __attribute__((always_inline)) {
     if (act == 0) return;
+#ifdef LGS_CONV_DBG
+    if (be.dbg & 1) return;
+#endif
     if constexpr (EPI == 1) {
 #pragma unroll
       for (int t = 0; t < LD; ++t) sumsq = sq16<T>(F[0][t], sumsq);
@@ -405,6 +419,11 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   // Prologue: the first weight slab and ALL index loads of the tile are in flight together, one barrier publishes
   // both (a slot-by-slot index copy loop was a chain of ~16 dependent global-load latencies at the head of every
   // workgroup -- a quarter of its lifetime -- and the first weight fetch only started behind it).
+#ifdef LGS_CONV_DBG
+  const bool trw = be.trace != nullptr && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && wave == 0;
+  unsigned long long tq0 = 0, tq1 = 0, tq2 = 0;
+  if (trw) tq0 = __builtin_amdgcn_s_memtime();
+#endif
   const bool whave = wadvance();
   if (whave) wissue(wreg);
   // kernel-map rows of the tile: SIXTEEN-byte loads, four consecutive positions of one offset per lane (the table is
@@ -459,6 +478,9 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     if (wnext) { pslab = wslab; wissue(wreg); }
   }
   __syncthreads();   // indices and the first weight slab are visible
+#ifdef LGS_CONV_DBG
+  if (trw) tq1 = __builtin_amdgcn_s_memtime();
+#endif
   const int total = __builtin_popcount(fmask) * nc;  // chunks of this wave
 #pragma unroll
   for (int d = 0; d < D - 1; ++d) {
@@ -504,6 +526,9 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     }
   }
 
+#ifdef LGS_CONV_DBG
+  if (trw) tq2 = __builtin_amdgcn_s_memtime();
+#endif
   if constexpr (EPI == 1) {
     // ---- CLIP-loss epilogue.  The weight LDS is idle now: every wave parks one 32 x 32 block of its similarity tile
     // there at a time (row stride 36 floats) so that a lane can pick the entries of ITS row's label / negatives with
@@ -666,6 +691,11 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     }
   }
 stats:
+#ifdef LGS_CONV_DBG
+  if (trw && lane == 0) {
+    be.trace[0] = tq1 - tq0; be.trace[1] = tq2 - tq1; be.trace[2] = __builtin_amdgcn_s_memtime() - tq2; be.trace[3] = (unsigned long long)total;
+  }
+#endif
   if constexpr (EPI == 0) {
     if (be.partial != nullptr) {   // kernel-uniform
       // ---- BatchNorm statistics of this workgroup's rows.  Lane (vx, h) holds, per row block, the 16 NCB channels
@@ -773,6 +803,8 @@ GatherCfg gather_cfg(const View &v, int nb_total) {
   if (!kF32 && small_override == 9) return {9, 4, 4, 64};
   if (!kF32 && small_override == 10) return {10, 4, 2, 64};
   if (!kF32 && small_override == 11) return {11, 4, 4, 64};
+  if (!kF32 && small_override == 3 && nb_total % 4 == 0) return {3, 2, 4, 256};     // 256 positions x 128 channels (64 x 128 per wave)
+  if (!kF32 && small_override == 7 && nb_total % 4 == 0) return {7, 2, 4, 128};     // 128 positions x 128 channels (32 x 128 per wave)
   if (!kF32 && small_override == 12) return {12, 8, 2, 128};
   if (!kF32 && small_override == 13) return {13, 8, 4, 128};
   if (!kF32) return {8, 4, 2, 128};   // measured best on the L3/L4 shapes (tools/microbench.py coarse): 128 positions x 64 channels
@@ -815,7 +847,18 @@ inline int64_t split_partial_bytes(int K, int64_t n_out, int o_real) {
 
 // epilogue options of one launch: a slot-split launch writes fp32 partial images (statistics / accumulation happen in
 // k_sum_partials or not at all)
-inline BnEpi bn_epi(const BnEpi *bn, bool did_split) { return (bn && !did_split) ? *bn : BnEpi(); }
+inline BnEpi bn_epi(const BnEpi *bn, bool did_split) {
+  BnEpi e = (bn && !did_split) ? *bn : BnEpi();
+#ifdef LGS_CONV_DBG
+  e.dbg = getenv("LGS_CONV_DBG") ? atoi(getenv("LGS_CONV_DBG")) : 0;
+  if (getenv("LGS_CONV_TRACE")) {
+    static unsigned long long *tr = nullptr;
+    if (!tr) (void)hipMalloc(&tr, 4 * sizeof(unsigned long long));
+    e.trace = tr;
+  }
+#endif
+  return e;
+}
 
 template <typename T>
 int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real, int nc, const uint4 *wp,
@@ -875,6 +918,16 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
     default: LGS_LAUNCH(1, 1, 2, 2, (kF32 ? 2 : 4), (kF32 ? 4 : 8)); break;
   }
 #undef LGS_LAUNCH
+#ifdef LGS_CONV_DBG
+  if (getenv("LGS_CONV_TRACE")) {
+    BnEpi e = bn_epi(bn, did_split);
+    unsigned long long h[4];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, e.trace, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[k_conv_gather trace] cfg %d rows %lld %d->%d z=%d: prologue %llu  main loop %llu (%llu chunk iterations = %llu cycles each)  epilogue %llu\n",
+            cfg.id, (long long)v.n_out, cin_real, cout_real, did_split ? 3 : 1, h[0], h[1], h[3], h[3] ? h[1] / h[3] : 0ull, h[2]);
+  }
+#endif
   if (did_split) {
     const int64_t n4 = zstride / 4;
     if (n4 > 0) LGS_KLAUNCH((k_sum_partials<T>), (unsigned)((n4 + 255) / 256), 256, 0, s, zpartial, n4, zstride, bias, cout_real, out,

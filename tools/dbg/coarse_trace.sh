@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT
+for d in 0 7; do echo "== CONV_DBG=$d"; LGS_CONV_TRACE=1 LGS_CONV_DBG=$d python tools/microbench.py coarse 2>&1 | grep -E "trace" | awk 'NR%13==1' | head -12; done
