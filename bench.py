@@ -286,13 +286,15 @@ def pmc_traffic(dom_key, args):
     (profiles/rNN_pmc_traffic.json, newest round first: FETCH_SIZE / WRITE_SIZE collected with rocprofv3 --pmc in separate passes, read side
     doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for the default workload they were collected on, null
     otherwise.  It is not measured inside this run (PMC collection needs the profiler)."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    wide = "K=27 512->512" in dom_key                 # the CLIP workload's dominant shape (k_conv_wide)
+    names = ("r04_pmc_traffic_wide.json",) if wide else ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+    for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
     else:
         return None, None
-    if not (args.scenes == 8 and args.voxels == 150000 and args.dtype == "bf16" and "K=27 96->96" in dom_key):
+    if not (args.scenes == 8 and args.voxels == 150000 and args.dtype == "bf16" and ("K=27 96->96" in dom_key or wide)):
         return None, None
     try:
         return json.load(open(path))["traffic_bytes"], "static: profiles/%s (rocprofv3 --pmc passes of this workload)" % name
@@ -470,7 +472,8 @@ def roofline_report(clog, disc, dtype_name, workload, steps, ms_per_step, n_vox,
     mfma_peak = 2.5e15 if dtype_name == "bf16" else 157.3e12
     return {
         "bound": "hbm",
-        "kernel": "k_conv_gather (sparse-conv forward/dgrad implicit GEMM), dominant launch shape: " + dom_key,
+        "kernel": ("k_conv_wide (2-D blocked wide-channel sparse conv forward/dgrad)" if "512->" in dom_key or "->512" in dom_key
+                   else "k_conv_gather (sparse-conv forward/dgrad implicit GEMM)") + ", dominant launch shape: " + dom_key,
         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
         "traffic": traffic, "traffic_source": traffic_src,
         # launches of this shape in ONE step (forward + dgrad launches; the 3^3 96->96 shape of Res16UNet34C: 4 forward + 5
@@ -511,8 +514,9 @@ def secondary_block(workload, model_name, dtype, coords, feats, labels, device, 
            "note": note, "dtype": dname, "steps": steps, "warmup": warmup, "voxels_per_step": n_vox, "ms_per_step": ms,
            "value": n_vox * steps / res["dt"], "unit": "voxels/s", "final_loss": float(res["loss"].item()), "phases": res["phases"]}
     if clog is not None and res["disc"] is not None:
+        tp = pmc_traffic(res["disc"]["top"][0][0], args) if (workload == "clip" and dtype == torch.bfloat16) else (None, None)
         out["roofline"] = roofline_report(clog, res["disc"], dname, "clip" if workload == "clip" else ("ce" if workload == "ce" else "insseg"),
-                                          steps, ms, n_vox, (None, None))
+                                          steps, ms, n_vox, tp)
         if workload == "clip":
             out["roofline"]["mfma"] = clip_mfma_report(out_dim=model.PLANES[7], n=n_vox, dtype=dtype, device=device)
     del model, ddp, opt, res

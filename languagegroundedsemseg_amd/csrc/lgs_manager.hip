@@ -205,10 +205,33 @@ __global__ void k_build_map3(const uint64_t *skeys, int64_t n, int64_t n_pad, in
 // 27-bit presence mask, so a 32-row MFMA block meets far fewer distinct (block, offset) combinations
 // (measured on the synthetic rooms: zero-padded MFMA work 1.83x -> 1.31x of the real pairs).
 constexpr int kMaskWindow = 16384;
-__global__ void k_mask_sort_keys(const uint32_t *pmask, int64_t n, int64_t n_pad, int window, uint64_t *keys, int32_t *vals) {
+// Sort key of a neighbourhood mask inside its window (tuning knob MASK_ORDER; the row order is free, only speed depends on it):
+//   0  the mask itself (offset 26 most significant);
+//   1  offsets by CLASS, corners most significant, then edges, faces, centre -- the rare offsets split the window first, so a
+//      tile's rows agree on them and fewer (32-row block, offset) pairs are gathered for nothing;
+//   2  the reverse (faces most significant);  3  popcount-major, then the mask.
+__device__ inline uint32_t mask_sort_code(uint32_t m, int order) {
+  if (order == 0) return m;
+  if (order == 3) return ((uint32_t)__popc(m) << 27) | m;
+  // offset k = (dx+1) + 3 (dy+1) + 9 (dz+1): class = number of non-zero components
+  uint32_t corner = 0, edge = 0, face = 0, centre = (m >> 13) & 1u;
+  int nc = 0, ne = 0, nf = 0;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
+    const int cls = (dx != 0) + (dy != 0) + (dz != 0);
+    const uint32_t b = (m >> k) & 1u;
+    if (cls == 3) corner |= b << nc++;
+    else if (cls == 2) edge |= b << ne++;
+    else if (cls == 1) face |= b << nf++;
+  }
+  if (order == 1) return (corner << 19) | (edge << 7) | (face << 1) | centre;
+  return (face << 21) | (edge << 9) | (corner << 1) | centre;
+}
+__global__ void k_mask_sort_keys(const uint32_t *pmask, int64_t n, int64_t n_pad, int window, int order, uint64_t *keys, int32_t *vals) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pad) return;
-  keys[p] = p < n ? (((uint64_t)(p / window)) << 32) | pmask[p] : ~0ull;
+  keys[p] = p < n ? (((uint64_t)(p / window)) << 32) | mask_sort_code(pmask[p], order) : ~0ull;
   vals[p] = (int32_t)p;
 }
 __global__ void k_permute_map3(const int32_t *nbr_tmp, const uint32_t *pmask, const int32_t *perm, const int32_t *order,
@@ -874,7 +897,7 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
       LGS_KLAUNCH(k_build_map3, (unsigned)(ci.n_pad / 256), 256, 0, s, ci.skeys, ci.n, ci.n_pad, ci.ts, ci.hkeys,
                          ci.hvals, (uint64_t)(ci.hcap - 1), nbr_tmp, pmask);
       const int window = (int)tune(T_MASK_WINDOW);   // tuning knob (default kMaskWindow)
-      LGS_KLAUNCH(k_mask_sort_keys, (unsigned)(ci.n_pad / 256), 256, 0, s, pmask, ci.n, ci.n_pad, window, keys, vals);
+      LGS_KLAUNCH(k_mask_sort_keys, (unsigned)(ci.n_pad / 256), 256, 0, s, pmask, ci.n, ci.n_pad, window, (int)tune(T_MASK_ORDER), keys, vals);
       {
         size_t tb = 0;
         LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, 64, s));
@@ -897,7 +920,7 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
         if (dalloc(m, &hnbr, 27 * ci.n_pad, s) || dalloc(m, &hmask, ci.n_pad / kGroup, s) || dalloc(m, &horow, ci.n_pad, s) ||
             dalloc(m, &lnbr, 27 * ci.n_pad, s) || dalloc(m, &urows, nt * kHaloS, s) || dalloc(m, &ucount, nt, s))
           return 1;
-        LGS_KLAUNCH(k_mask_sort_keys, (unsigned)(ci.n_pad / 256), 256, 0, s, pmask, ci.n, ci.n_pad, kHaloT, keys, vals);
+        LGS_KLAUNCH(k_mask_sort_keys, (unsigned)(ci.n_pad / 256), 256, 0, s, pmask, ci.n, ci.n_pad, kHaloT, (int)tune(T_MASK_ORDER), keys, vals);
         {
           size_t tb = 0;
           LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, 64, s));

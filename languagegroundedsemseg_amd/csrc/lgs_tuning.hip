@@ -45,6 +45,7 @@ const Knob kKnobs[T_COUNT] = {
                 "(L0 96->96 0.78 vs 0.58 ms; wins only at 32 / 64 channels by 2-9 %, less than the 1.2 ms per step the tables cost)"},
     {"HALO_MIN_ROWS", 65536, "k_conv_halo is used on maps of at least this many positions"},
     {"HALO_TRACE", 0, "k_conv_halo: print per-phase shader-clock sums of one workgroup's wave 0 (debug instance, synchronises)"},
+    {"MASK_ORDER", 0, "3^3 maps: sort code of the neighbourhood mask inside a window: 0 the mask, 1 corners > edges > faces, 2 faces > edges > corners, 3 popcount-major"},
 };
 std::atomic<int64_t> g_val[T_COUNT];
 std::once_flag g_once;

@@ -36,6 +36,7 @@ python tools/pmc_traffic.py gpurun_out/$TAG/pmc $O/pmc_traffic.json > /dev/null 
 rm -rf gpurun_out/$TAG/pmc/*/
 bash tools/run_pmc_wide.sh $TAG/pmcw > $O/pmc_wide.log 2>&1
 python tools/pmc_summary.py gpurun_out/$TAG/pmcw > $O/pmc_wide.txt 2>&1
+python tools/pmc_traffic.py gpurun_out/$TAG/pmcw $O/pmc_traffic_wide.json k_conv_wide > /dev/null 2>&1
 rm -rf gpurun_out/$TAG/pmcw/*/
 ( python tools/microbench.py 8; python tools/microbench.py wgrad; python tools/microbench.py clip; python tools/microbench.py wide ) 2>&1 | grep -v amdgpu.ids > $O/microbench.txt
 head -12 $O/queue_timeline.txt
