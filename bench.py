@@ -167,7 +167,7 @@ def _mark(tag):
     _PHASES.append((tag, e, time.perf_counter()))
 
 
-def phase_summary(steps):
+def phase_summary(steps, origin=None):
     """per-step milliseconds between the marks of the last `steps` steps: on the compute stream (HIP events) and on the
     host (enqueue time).  `finalize` = joining the weight-gradient stream + (N > 1) the exposed part of the bucket
     all-reduces; call after torch.cuda.synchronize()."""
@@ -178,8 +178,19 @@ def phase_summary(steps):
         for a, b in zip(blk[:-1], blk[1:]):
             acc[b[0]] = acc.get(b[0], 0.0) + a[1].elapsed_time(b[1])
             host[b[0]] = host.get(b[0], 0.0) + (b[2] - a[2]) * 1e3
+    out = {"stream_ms": {k: v / steps for k, v in acc.items()}, "host_enqueue_ms": {k: v / steps for k, v in host.items()}}
+    if origin is not None:
+        # how far the HOST runs ahead of the compute stream at each mark: (time the stream reached the mark) - (time the host
+        # enqueued it), both from the synchronised start of the timed region.  ~0 at `start` = the host is not ahead at the
+        # head of a step (the stream waits for the host); growing over the steps = nothing throttles the host
+        ev0, t0 = origin
+        lead = {}
+        for j in range(steps):
+            for tag, e, t in ev[5 * j:5 * j + 5]:
+                lead.setdefault(tag, []).append(ev0.elapsed_time(e) - (t - t0) * 1e3)
+        out["host_lead_ms"] = {k: {"avg": sum(v) / len(v), "first_step": v[0], "last_step": v[-1]} for k, v in lead.items()}
     del _PHASES[:]
-    return {"stream_ms": {k: v / steps for k, v in acc.items()}, "host_enqueue_ms": {k: v / steps for k, v in host.items()}}
+    return out
 
 
 def train_step(model, ddp, opt, coords, feats, labels, dtype, step_idx, shift=True, ctx=None):
@@ -444,7 +455,7 @@ def measure(model, ddp, opt, coords, feats, labels, dtype, steps, warmup, ctx, c
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"dt": dt, "loss": loss, "disc": disc, "phases": phase_summary(steps),
+    return {"dt": dt, "loss": loss, "disc": disc, "phases": phase_summary(steps, origin=(marks[0], t0)),
             "step_ms": [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]}
 
 

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LGS_ABI_VERSION 9
+#define LGS_ABI_VERSION 10
 
 enum lgs_dtype { LGS_F32 = 0, LGS_BF16 = 1 };
 
@@ -369,6 +369,10 @@ int lgs_cluster(const float *xyz, const int32_t *batch_idx, const int32_t *seman
  * wrapper asks for the loss in the forward pass and for the gradient in the backward pass. */
 int lgs_ce_forward_backward(const void *logits, int64_t n, int c, const int64_t *labels, int64_t ignore_index,
                             const float *scale, float *loss_rows, void *dlogits, int dtype, void *stream);
+/* number of rows the loss above counts (label != ignore_index and inside [0, c)) -> *count (DEVICE int32, overwritten): the
+ * denominator of the mean reduction (pl_BaselineTrainer.py:350, nn.CrossEntropyLoss(ignore_index) 'mean') without a host
+ * sync and without a chain of elementwise / reduction launches over the label tensor. */
+int lgs_ce_count_valid(const int64_t *labels, int64_t n, int c, int64_t ignore_index, int32_t *count, void *stream);
 
 #ifdef __cplusplus
 }

@@ -110,6 +110,29 @@ __global__ __launch_bounds__(256) void k_ce_fwd_bwd(const T *__restrict__ logits
   }
 }
 
+// rows the mean cross-entropy counts: integer atomics, one per workgroup -> deterministic
+__global__ __launch_bounds__(256) void k_ce_count_valid(const int64_t *__restrict__ labels, int64_t n, int c, int64_t ignore_index,
+                                                         int32_t *__restrict__ count) {
+  __shared__ int32_t l_cnt;
+  if (threadIdx.x == 0) l_cnt = 0;
+  __syncthreads();
+  int32_t mine = 0;
+  const int64_t base = (int64_t)blockIdx.x * 256 * 8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t r = base + (int64_t)i * 256 + threadIdx.x;
+    if (r < n) {
+      const int64_t lab = labels[r];
+      mine += (lab != ignore_index && lab >= 0 && lab < c) ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&l_cnt, mine);
+  __syncthreads();
+  if (threadIdx.x == 0 && l_cnt) atomicAdd(count, l_cnt);
+}
+
 }  // namespace lgs
 
 using namespace lgs;
@@ -130,6 +153,16 @@ extern "C" int lgs_ce_forward_backward(const void *logits, int64_t n, int c, con
                        (bf16_t *)dlogits);
   else
     LGS_REQUIRE(false, "lgs_ce_forward_backward: unknown dtype");
+  LGS_HIP(hipGetLastError());
+  return 0;
+}
+
+int lgs_ce_count_valid(const int64_t *labels, int64_t n, int c, int64_t ignore_index, int32_t *count, void *stream) {
+  LGS_REQUIRE(count && (labels || n == 0) && n >= 0 && c >= 1, "lgs_ce_count_valid: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  LGS_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+  if (n == 0) return 0;
+  LGS_KLAUNCH(k_ce_count_valid, (unsigned)((n + 2047) / 2048), 256, 0, s, labels, n, c, ignore_index, count);
   LGS_HIP(hipGetLastError());
   return 0;
 }

@@ -157,17 +157,34 @@ __global__ void k_hash_insert(const uint64_t *skeys, const int32_t *order, int64
 // lgs_manager_stride2 calls of the U-Net then need none (5 host syncs per training step -> 1; duplicates of the input do not
 // matter: equal keys stay equal under any mask).
 constexpr int kPreLevels = 8;
-__global__ void k_count_levels(const uint64_t *__restrict__ skeys, int64_t n, int32_t *__restrict__ counts) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = p < n;
-  const uint64_t k = live ? skeys[p] : 0ull, q = (live && p > 0) ? skeys[p - 1] : ~0ull;
+constexpr int kCountPerThread = 16;
+__global__ __launch_bounds__(256) void k_count_levels(const uint64_t *__restrict__ skeys, int64_t n, int32_t *__restrict__ counts) {
+  // a workgroup walks 256 x kCountPerThread consecutive keys and adds ONE number per level to the global counters (one
+  // atomic per wave and level on eight shared addresses cost 0.67 ms at 1.2 M keys: the atomics serialise at the L2)
+  __shared__ int32_t l_cnt[kPreLevels];
+  if (threadIdx.x < kPreLevels) l_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  int32_t c[kPreLevels];
 #pragma unroll
-  for (int L = 1; L <= kPreLevels; ++L) {
-    const uint64_t mask = ~((1ull << (3 * L)) - 1ull);
-    const bool head = live && (p == 0 || (k & mask) != (q & mask));
-    const uint64_t b = __ballot(head);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&counts[L - 1], __popcll(b));
+  for (int L = 0; L < kPreLevels; ++L) c[L] = 0;
+  const int64_t base = (int64_t)blockIdx.x * 256 * kCountPerThread;
+#pragma unroll 4
+  for (int i = 0; i < kCountPerThread; ++i) {
+    const int64_t p = base + (int64_t)i * 256 + threadIdx.x;
+    if (p >= n) break;
+    const uint64_t k = skeys[p], q = p > 0 ? skeys[p - 1] : ~0ull, d = k ^ q;
+#pragma unroll
+    for (int L = 1; L <= kPreLevels; ++L) c[L - 1] += (p == 0 || (d >> (3 * L)) != 0) ? 1 : 0;
   }
+#pragma unroll
+  for (int L = 0; L < kPreLevels; ++L) {
+    int32_t v = c[L];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&l_cnt[L], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < kPreLevels && l_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], l_cnt[threadIdx.x]);
 }
 
 // 3x3x3 stride-1 map: one thread per sorted position, 27 probes; nbr is offset-major [27][n_pad]
@@ -767,7 +784,7 @@ int lgs_manager_insert(lgs_manager *m, const int32_t *coords, int64_t n, int64_t
   int32_t *lvl_counts;
   if (dalloc(m, &lvl_counts, kPreLevels, s)) return 1;
   LGS_HIP(hipMemsetAsync(lvl_counts, 0, sizeof(int32_t) * kPreLevels, s));
-  LGS_KLAUNCH(k_count_levels, nblk(n), 256, 0, s, skeys, n, lvl_counts);
+  LGS_KLAUNCH(k_count_levels, (unsigned)((n + 256 * kCountPerThread - 1) / (256 * kCountPerThread)), 256, 0, s, skeys, n, lvl_counts);
   int32_t h_nu = 0; int h_err = 0; int32_t h_lvl[kPreLevels];
   LGS_HIP(hipMemcpyAsync(&h_nu, urow + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   LGS_HIP(hipMemcpyAsync(&h_err, m->d_err, sizeof(int), hipMemcpyDeviceToHost, s));

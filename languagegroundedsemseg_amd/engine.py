@@ -10,7 +10,7 @@ import os
 from . import build as _build
 
 LGS_F32, LGS_BF16 = 0, 1
-ABI_VERSION = 9     # LGS_ABI_VERSION of include/lgs_engine.h
+ABI_VERSION = 10     # LGS_ABI_VERSION of include/lgs_engine.h
 
 
 class PackDesc(ctypes.Structure):
@@ -91,6 +91,7 @@ EXPORTS = [
     "lgs_clip_loss_workspace_bytes", "lgs_clip_loss_forward", "lgs_clip_loss_backward",
     "lgs_clip_anchor_grad_workspace_bytes", "lgs_clip_loss_backward_anchors",
     "lgs_ce_forward_backward",
+    "lgs_ce_count_valid",
     "lgs_voxelize", "lgs_label_vote", "lgs_cluster_workspace_bytes", "lgs_cluster", "lgs_sgd_step",
 ]
 
@@ -154,6 +155,7 @@ def lib():
         "lgs_bn_backward_apply": [vp, vp, vp, i64, ci, vp, vp, vp, vp, cf, vp, ci, vp, vp, ci, vp],
         "lgs_clip_similarity": [vp, i64, ci, vp, ci, vp, vp, ci, vp, vp],
         "lgs_ce_forward_backward": [vp, i64, ci, vp, i64, vp, vp, vp, ci, vp],
+        "lgs_ce_count_valid": [vp, i64, ci, i64, vp, vp],
         "lgs_clip_loss_forward": [vp, i64, ci, vp, ci, vp, vp, ci, i64, vp, vp, vp, vp, vp, vp, ci, vp, vp],
         "lgs_clip_loss_backward": [vp, i64, ci, vp, ci, vp, vp, ci, i64, vp, vp, vp, vp, vp, vp, ci, vp],
         "lgs_clip_loss_backward_anchors": [vp, i64, ci, ci, vp, vp, ci, i64, vp, vp, vp, vp, ci, vp, vp],

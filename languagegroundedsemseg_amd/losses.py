@@ -20,15 +20,15 @@ class _FusedCE(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, labels, ignore_index):
-        loss, _ = get_backend().cross_entropy(logits, labels, ignore_index, want_grad=False)
-        ctx.save_for_backward(logits, labels)
+        loss, _, inv_valid = get_backend().cross_entropy(logits, labels, ignore_index, want_grad=False)
+        ctx.save_for_backward(logits, labels, inv_valid)
         ctx.ignore_index = ignore_index
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        logits, labels = ctx.saved_tensors
-        _, dlogits = get_backend().cross_entropy(logits, labels, ctx.ignore_index, grad_scale=g)
+        logits, labels, inv_valid = ctx.saved_tensors
+        _, dlogits, _ = get_backend().cross_entropy(logits, labels, ctx.ignore_index, grad_scale=g, inv_valid=inv_valid)
         return dlogits, None, None
 
 

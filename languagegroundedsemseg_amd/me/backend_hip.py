@@ -835,9 +835,11 @@ class HipBackend:
         return gt[:, :na].t()
 
     # ---- fused softmax cross-entropy: lgs_ce_forward_backward
-    def cross_entropy(self, logits, labels, ignore_index, want_grad=True, grad_scale=None):
+    def cross_entropy(self, logits, labels, ignore_index, want_grad=True, grad_scale=None, inv_valid=None):
         """mean CE over the non-ignored rows.  want_grad=False: loss only; grad_scale (device scalar): gradient only,
-        already multiplied by it (the two halves of one kernel, so the upstream gradient never needs its own pass)."""
+        already multiplied by it (the two halves of one kernel, so the upstream gradient never needs its own pass).
+        inv_valid: 1 / #counted rows from an earlier call on the same labels (the forward's, reused by the backward).
+        -> (loss, dlogits, inv_valid)"""
         _require_dev(logits, "logits")
         L = engine.lib()
         logits = logits.contiguous()
@@ -845,14 +847,17 @@ class HipBackend:
         n, c = logits.shape
         dt = _dtype_code(logits)
         with _dev(logits.device):
-            # the same predicate the kernel uses: a label outside [0, C) is an ignored row, not a counted one
-            valid = ((labels != ignore_index) & (labels >= 0) & (labels < c)).sum().to(torch.float32).clamp_min(1.0)
-            scale = valid.reciprocal()
+            if inv_valid is None:
+                # the same predicate the kernel uses: a label outside [0, C) is an ignored row, not a counted one
+                cnt = torch.empty(1, dtype=torch.int32, device=logits.device)
+                engine.check(L.lgs_ce_count_valid(_ptr(labels), n, c, int(ignore_index), _ptr(cnt), _stream()))
+                inv_valid = cnt.to(torch.float32).clamp_min_(1.0).reciprocal_().reshape(())
+            scale = inv_valid
             if grad_scale is not None:
                 scale = scale * grad_scale.to(torch.float32).reshape(())
             loss_rows = torch.empty(max(n, 1), dtype=torch.float32, device=logits.device) if grad_scale is None else None
             dlogits = torch.empty_like(logits) if (want_grad or grad_scale is not None) else None
             engine.check(L.lgs_ce_forward_backward(_ptr(logits), n, c, _ptr(labels), int(ignore_index), _ptr(scale),
                                                    _ptr(loss_rows), _ptr(dlogits), dt, _stream()))
-        loss = loss_rows[:n].sum() * scale if loss_rows is not None else None
-        return loss, dlogits
+        loss = loss_rows[:n].sum() * inv_valid if loss_rows is not None else None
+        return loss, dlogits, inv_valid

@@ -231,3 +231,34 @@ def test_c_side_block_equals_the_call_by_call_block(monkeypatch, dtype, with_ddp
                 assert torch.equal(ga[k], gb[k]), (name, k)
             for k in ba:
                 assert torch.equal(ba[k], bb[k]), (name, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,c,ignore", [(100003, 200, -1), (4097, 20, 255), (1, 13, -1), (70001, 200, 7)])
+def test_cross_entropy_denominator_is_counted_on_the_device(n, c, ignore):
+    """lgs_ce_count_valid = the rows nn.CrossEntropyLoss(ignore_index) 'mean' divides by (pl_BaselineTrainer.py:350): labels equal to
+    ignore_index or outside [0, C) do not count -- including an ignore_index that collides with a real class -- and the fused loss
+    (one count launch, no elementwise chain over the labels) equals torch's on the same rows, forward and backward."""
+    from languagegroundedsemseg_amd import engine
+    from languagegroundedsemseg_amd.losses import fused_cross_entropy
+    from languagegroundedsemseg_amd.me.backend_hip import _ptr, _stream
+    g = torch.Generator().manual_seed(n)
+    labels = torch.randint(0, c, (n,), generator=g)
+    labels[torch.rand(n, generator=g) < 0.15] = ignore
+    labels[torch.rand(n, generator=g) < 0.02] = c + 5          # outside the head: ignored rows, not errors
+    labels[torch.rand(n, generator=g) < 0.02] = -7
+    want = int(((labels != ignore) & (labels >= 0) & (labels < c)).sum())
+    lab = labels.cuda()
+    cnt = torch.full((1,), 123, dtype=torch.int32, device="cuda")
+    with torch.cuda.device(0):
+        engine.check(engine.lib().lgs_ce_count_valid(_ptr(lab), n, c, ignore, _ptr(cnt), _stream()))
+    assert int(cnt.item()) == want
+    logits = torch.randn(n, c, generator=g).cuda().requires_grad_(True)
+    loss = fused_cross_entropy(logits, lab, ignore_index=ignore)
+    (loss * 3.0).backward()
+    ref_in = logits.detach().clone().requires_grad_(True)
+    safe = torch.where((lab >= 0) & (lab < c) & (lab != ignore), lab, torch.full_like(lab, -100))
+    ref = torch.nn.functional.cross_entropy(ref_in, safe, ignore_index=-100) if want else ref_in.sum() * 0
+    (ref * 3.0).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert float((logits.grad - ref_in.grad).abs().max()) <= 1e-6
