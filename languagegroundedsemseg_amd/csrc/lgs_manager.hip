@@ -251,6 +251,14 @@ __global__ void k_mask_sort_keys(const uint32_t *pmask, int64_t n, int64_t n_pad
   keys[p] = p < n ? (((uint64_t)(p / window)) << 32) | mask_sort_code(pmask[p], order) : ~0ull;
   vals[p] = (int32_t)p;
 }
+// key bits the window sort has to look at: 32 bits of mask code + the window index.  A padding key is all ones; its low
+// bits beat every real key as long as the largest real window index is not all ones too -- one more bit than it needs.
+inline unsigned mask_sort_bits(int64_t n_pad, int window) {
+  const uint64_t nw = (uint64_t)((n_pad + window - 1) / window);
+  unsigned wb = 1;
+  while ((1ull << wb) - 1 < nw) ++wb;
+  return 32u + wb > 64u ? 64u : 32u + wb;
+}
 __global__ void k_permute_map3(const int32_t *nbr_tmp, const uint32_t *pmask, const int32_t *perm, const int32_t *order,
                                int64_t n, int64_t n_pad, int32_t *nbr, int32_t *out_row, uint32_t *mask64) {
   int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // grid covers n_pad exactly
@@ -917,10 +925,11 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
       LGS_KLAUNCH(k_mask_sort_keys, (unsigned)(ci.n_pad / 256), 256, 0, s, pmask, ci.n, ci.n_pad, window, (int)tune(T_MASK_ORDER), keys, vals);
       {
         size_t tb = 0;
-        LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, 64, s));
+        const unsigned eb = mask_sort_bits(ci.n_pad, window);
+        LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, eb, s));
         void *tmp = nullptr;
         if (raw_alloc(m, &tmp, tb ? tb : 16, s)) return 1;
-        LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, 64, s));
+        LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, eb, s));
         if (dfree_now(m, tmp, s)) return 1;
       }
       LGS_KLAUNCH(k_permute_map3, (unsigned)(ci.n_pad / 256), 256, 0, s, nbr_tmp, pmask, perm, ci.order, ci.n, ci.n_pad,
@@ -940,10 +949,11 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
         LGS_KLAUNCH(k_mask_sort_keys, (unsigned)(ci.n_pad / 256), 256, 0, s, pmask, ci.n, ci.n_pad, kHaloT, (int)tune(T_MASK_ORDER), keys, vals);
         {
           size_t tb = 0;
-          LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, 64, s));
+          const unsigned eb = mask_sort_bits(ci.n_pad, kHaloT);
+          LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, eb, s));
           void *tmp = nullptr;
           if (raw_alloc(m, &tmp, tb ? tb : 16, s)) return 1;
-          LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, 64, s));
+          LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, eb, s));
           if (dfree_now(m, tmp, s)) return 1;
         }
         LGS_KLAUNCH(k_permute_map3, (unsigned)(ci.n_pad / 256), 256, 0, s, nbr_tmp, pmask, perm, ci.order, ci.n, ci.n_pad,
