@@ -137,3 +137,69 @@ def test_fullsize_linearity_and_bf16_vs_fp32(batch):
         ya_r = conv(ME.SparseTensor(xa.bfloat16().float(), **mk)).F      # same rounded inputs, fp32 path
         err = (y16 - ya_r).norm().item() / ya_r.norm().item()
         assert err < 6e-3, err                                            # bf16 weights + bf16 output rounding
+
+
+def _neighbour_rows(C, k_sel):
+    """numpy hash lookup: (hit mask, source row) of the neighbour at offset k_sel of every voxel (first spatial axis fastest)"""
+    off = np.array([k_sel % 3 - 1, (k_sel // 3) % 3 - 1, k_sel // 9 - 1], np.int64)
+    keys = _key(C)
+    order = np.argsort(keys)
+    nb = C.copy()
+    nb[:, 1:] += off
+    q = _key(nb)
+    pos = np.clip(np.searchsorted(keys[order], q), 0, len(keys) - 1)
+    return keys[order][pos] == q, order[pos]
+
+
+def _dispatched(before, after, name):
+    return sum(v - before.get(k, 0) for k, v in after.items() if name in k)
+
+
+@pytest.mark.parametrize("k_sel", [2, 13, 21])
+def test_fullsize_wide_one_hot_conv_copies_the_neighbour_row(batch, k_sel):
+    """configs[2] width at configs[1] size: the 2-D blocked wide kernel (>= 256 output channels, bf16) with a one-hot weight is an
+    exact row copy -- every gathered row, every 64-channel stage and every output column tile lands where numpy says"""
+    from languagegroundedsemseg_amd import engine
+    coords = batch
+    n, c = coords.shape[0], 512
+    g = torch.Generator(device=DEV).manual_seed(k_sel)
+    f = torch.randn(n, c, device=DEV, generator=g).to(torch.bfloat16)
+    x = ME.SparseTensor(f, torch.from_numpy(coords).to(DEV))
+    conv = ME.MinkowskiConvolution(c, c, kernel_size=3, dimension=3).to(DEV)
+    with torch.no_grad():
+        conv.kernel.zero_()
+        conv.kernel[k_sel] = torch.eye(c, device=DEV)
+    before = engine.dispatch_counts()
+    with torch.no_grad():
+        y = conv(x).F
+    assert _dispatched(before, engine.dispatch_counts(), "k_conv_wide") >= 1, "the wide kernel was not the one that ran"
+    hit, src = _neighbour_rows(x.C.cpu().numpy().astype(np.int64), k_sel)
+    want = torch.zeros_like(f)
+    hit_t = torch.from_numpy(hit).to(DEV)
+    want[hit_t] = f[torch.from_numpy(src[hit]).to(DEV)]
+    assert torch.equal(y, want)
+
+
+def test_fullsize_wide_adjoint_identity_ties_forward_dgrad_wgrad(batch):
+    """<conv(x), g> = <x, dgrad(g)> = <W, wgrad(x, g)> at 1.2 M voxels x 512 -> 512 channels (bf16): k_conv_wide forward, k_conv_wide
+    on the mirrored weights and k_wgrad_wide (compacted pair lists) describe the same bilinear form"""
+    from languagegroundedsemseg_amd import engine
+    coords = batch
+    n, cin, cout = coords.shape[0], 512, 512
+    g = torch.Generator(device=DEV).manual_seed(5)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=3, dimension=3).to(DEV)
+    xf = torch.randn(n, cin, device=DEV, generator=g).to(torch.bfloat16).requires_grad_(True)
+    gy = torch.randn(n, cout, device=DEV, generator=g).to(torch.bfloat16)
+    x = ME.SparseTensor(xf, torch.from_numpy(coords).to(DEV))
+    before = engine.dispatch_counts()
+    y = conv(x).F
+    y.backward(gy)
+    torch.cuda.synchronize()
+    after = engine.dispatch_counts()
+    assert _dispatched(before, after, "k_conv_wide") >= 2 and _dispatched(before, after, "k_wgrad_wide") >= 1
+    a = (y.double() * gy.double()).sum().item()
+    b = (xf.detach().double() * xf.grad.double()).sum().item()
+    c = (conv.kernel.detach().double() * conv.kernel.grad.double()).sum().item()
+    scale = (y.double().norm() * gy.double().norm()).item()
+    assert abs(a - b) / scale < 6e-3, (a, b)
+    assert abs(a - c) / scale < 6e-3, (a, c)
