@@ -712,11 +712,12 @@ inline unsigned *fused_counter() {
   }
   return ring[dev] + (next[dev].fetch_add(1) % kCtrSlots);
 }
-inline bool bn_fused_on(int64_t tensor_bytes) {
+inline bool bn_fused_on(int64_t tensor_bytes, bool forward = false) {
   const bool on = tune(T_BN_FUSED) != 0;   // A/B knob: 0 = three launches
   // above ~24 MB a direction is bandwidth-bound and the three-launch path's 4096-workgroup apply streams faster than 512
   // resident workgroups can (1.2 M rows x 96 ch bf16 forward: 0.135 ms vs 0.181 ms fused); below, launches dominate
-  const int64_t max_mb = tune(T_BN_FUSED_MAX_MB);
+  int64_t max_mb = tune(T_BN_FUSED_MAX_MB);
+  if (forward && tune(T_BN_FUSED_FWD_MAX_MB) < max_mb) max_mb = tune(T_BN_FUSED_FWD_MAX_MB);
   return on && tensor_bytes <= (max_mb << 20);
 }
 // Workgroups a grid-barrier kernel may be launched with: every one of them must be RESIDENT at the same time, or the resident
@@ -786,7 +787,7 @@ int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const flo
   float *scratch = reinterpret_cast<float *>(workspace);  // caller-owned: no allocator call (and no implicit sync) here
   const T *x = reinterpret_cast<const T *>(xv);
   const int pm = (partials && partial_rows > 0) ? 1 : 0;
-  const int fcap = bn_fused_on(n * (int64_t)c * (int64_t)sizeof(T)) ? fused_cap(reinterpret_cast<const void *>(&k_bn_fwd_fused<T>)) : 0;
+  const int fcap = bn_fused_on(n * (int64_t)c * (int64_t)sizeof(T), true) ? fused_cap(reinterpret_cast<const void *>(&k_bn_fwd_fused<T>)) : 0;
   if (fcap > 0) {
     unsigned *ctr = fused_counter();
     LGS_REQUIRE(ctr != nullptr, "lgs_bn_forward: could not allocate the grid-barrier counters");

@@ -28,6 +28,9 @@ const Knob kKnobs[T_COUNT] = {
     {"BN_FUSED", 1, "0 = BatchNorm always as three launches (column sums, fold, apply) instead of the persistent grid-barrier kernels; "
                     "required when several processes time-share one GPU"},
     {"BN_FUSED_MAX_MB", 24, "layers above this size use the three-launch BatchNorm (they are bandwidth-bound; the 4096-workgroup apply streams faster)"},
+    {"BN_FUSED_FWD_MAX_MB", 0, "the same bound for the FORWARD direction alone; 0 = the forward is always three launches.  Round 4: with the host "
+                               "no longer the bound the one-launch forward loses at every size (8-scene step 27.93 vs 28.15 ms, one scene 10.17 vs "
+                               "10.30; stand-alone 20 MB: 22.8 vs 33.0 us), the one-launch BACKWARD still wins (16.4 vs 16.8 ms of backward)"},
     {"BN_FUSED_BLOCKS", 0, "workgroups of the fused BatchNorm kernels; 0 = min(256, co-resident workgroups of the device)"},
     {"PS_CUS", 20, "CUs per XCD that k_wgrad_ps fills (of 32): the compute stream keeps CUs of its own next to the CU-owning weight gradient"},
     {"PS_WIDE3", 1, "k_wgrad_ps: three-block stationary slices for >= 256-channel layers (0 = two-block)"},

@@ -196,7 +196,17 @@ def test_single_voxel_and_ragged_batches():
 # ------------------------------------------------------------------------------------------- norm
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
-def test_fused_bn_matches_torch(dtype, tol, relu, res):
+@pytest.mark.parametrize("launches", ["default", "one", "three"])
+def test_fused_bn_matches_torch(dtype, tol, relu, res, launches):
+    """launches: the default policy (forward = column sums / fold / apply, backward = one grid-barrier launch for layers <= 24 MB),
+    the one-launch kernels in BOTH directions, three launches in both"""
+    from languagegroundedsemseg_amd import engine
+    knobs = {"default": {}, "one": dict(BN_FUSED=1, BN_FUSED_FWD_MAX_MB=24), "three": dict(BN_FUSED=0)}[launches]
+    with engine.tuning(**knobs):
+        _bn_matches_torch(dtype, tol, relu, res)
+
+
+def _bn_matches_torch(dtype, tol, relu, res):
     torch.manual_seed(0)
     n, c = 5000, 96
     xf = torch.randn(n, c) * 2 + 0.5
