@@ -278,6 +278,12 @@ typedef struct lgs_block_bwd {
   float *gw1, *gw2, *gwd;                /* weight gradients, fp32, parameter shapes (e.g. views of gradient-bucket slots) */
   float *dgamma1, *dbeta1, *dgamma2, *dbeta2, *dgammad, *dbetad;
   void *conv_ws, *bn_ws;
+  /* weight gradients beside the dgrad / BatchNorm chain (me/modules.py conv_weight_grad does the same call by call): when
+   * wgrad_stream is set, every lgs_conv_wgrad of the block is enqueued THERE, ordered after its operands by fork_event
+   * (hipEvent_t, re-recorded on `stream` per weight gradient), uses wgrad_ws (its own lgs_conv_workspace_bytes(op 2) scratch)
+   * and is followed by a record of ev_w1 / ev_w2 / ev_wd (hipEvent_t, may be NULL) on wgrad_stream -- what the consumer of
+   * the gradient (bucketed all-reduce, optimizer) waits for.  NULL: the weight gradients run on `stream`. */
+  void *wgrad_stream, *wgrad_ws, *fork_event, *ev_w1, *ev_w2, *ev_wd;
 } lgs_block_bwd;                         /* grad_in: dres (no downsample) or gind (with), accumulated in place */
 int64_t lgs_block_workspace_bytes(const lgs_kmap *km3, const lgs_kmap *km1, int cin, int planes, int dtype);
 int lgs_block_forward(const lgs_block_fwd *args, void *stream);

@@ -7,7 +7,7 @@
 // Python + ctypes: host 10.2 ms against 9.0 ms of GPU work), not by the GPU.  These two entry points
 // issue exactly the same launches, in the same order, with the same arguments as the call-by-call path (bit-identical results:
 // tests/test_gpu_parity_r4.py::test_c_side_block_equals_the_call_by_call_block) from ONE host call each.  Everything runs on
-// the caller's stream (the regime of small batches, whose weight gradients are not moved to a side stream anyway).
+// the caller's stream, except the weight gradients when the caller names a side stream for them (lgs_block_bwd.wgrad_stream).
 #include "lgs_common.h"
 
 extern "C" {
@@ -55,21 +55,32 @@ int lgs_block_backward(const lgs_block_bwd *a, void *stream) {
   LGS_REQUIRE(!a->relu_final || a->y2, "lgs_block_backward: the ReLU mask of the block output needs y2");
   const int dt = a->dtype, c = a->planes;
   int rc;
+  // one weight gradient: on the caller's stream, or on the side stream behind a fork event (its operands are complete on `stream`)
+  auto wgrad = [&](lgs_kmap *km, const void *in, int cin, const void *gout, float *gw, int in_ld, void *ev) -> int {
+    if (!a->wgrad_stream) return lgs_conv_wgrad(km, 0, in, cin, gout, c, gw, dt, a->conv_ws, in_ld, stream);
+    LGS_REQUIRE(a->fork_event && a->wgrad_ws, "lgs_block_backward: a side stream needs fork_event and wgrad_ws");
+    LGS_HIP(hipEventRecord((hipEvent_t)a->fork_event, (hipStream_t)stream));
+    LGS_HIP(hipStreamWaitEvent((hipStream_t)a->wgrad_stream, (hipEvent_t)a->fork_event, 0));
+    const int r = lgs_conv_wgrad(km, 0, in, cin, gout, c, gw, dt, a->wgrad_ws, in_ld, a->wgrad_stream);
+    if (r) return r;
+    if (ev) LGS_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)a->wgrad_stream));
+    return 0;
+  };
   // norm2 (+ residual) (+ ReLU): mask from the saved output when there is a ReLU (a residual was added)
   if ((rc = lgs_bn_backward(a->o2, a->relu_final ? a->y2 : nullptr, a->dy, a->dy_row_stride, a->n, c, a->gamma2, a->beta2, a->st2,
                             a->relu_final ? 1 : 0, a->dx2, a->dres, a->dgamma2, a->dbeta2, dt, a->bn_ws, 0, stream))) return rc;
-  if ((rc = lgs_conv_wgrad(a->km3, 0, a->y1, c, a->dx2, c, a->gw2, dt, a->conv_ws, 0, stream))) return rc;
+  if ((rc = wgrad(a->km3, a->y1, c, a->dx2, a->gw2, 0, a->ev_w2))) return rc;
   if ((rc = lgs_conv_dgrad(a->km3, 0, a->dx2, c, a->w2, c, a->dy1, dt, a->conv_ws, a->pk2, a->pm2, stream))) return rc;
   // norm1 + ReLU: mask recomputed from its input
   if ((rc = lgs_bn_backward(a->o1, nullptr, a->dy1, 0, a->n, c, a->gamma1, a->beta1, a->st1, 2, a->dx1, nullptr, a->dgamma1, a->dbeta1, dt,
                             a->bn_ws, 0, stream))) return rc;
-  if ((rc = lgs_conv_wgrad(a->km3, 0, a->x, a->cin, a->dx1, c, a->gw1, dt, a->conv_ws, a->x_row_stride, stream))) return rc;
+  if ((rc = wgrad(a->km3, a->x, a->cin, a->dx1, a->gw1, a->x_row_stride, a->ev_w1))) return rc;
   void *acc = a->dres;       // the residual branch's gradient w.r.t. x
   if (a->km1) {
     LGS_REQUIRE(a->od && a->std_ && a->wd && a->dxd && a->gwd && a->gind, "lgs_block_backward: downsample branch tensors missing");
     if ((rc = lgs_bn_backward(a->od, nullptr, a->dres, 0, a->n, c, a->gammad, a->betad, a->std_, 0, a->dxd, nullptr, a->dgammad, a->dbetad, dt,
                               a->bn_ws, 0, stream))) return rc;
-    if ((rc = lgs_conv_wgrad(a->km1, 0, a->x, a->cin, a->dxd, c, a->gwd, dt, a->conv_ws, a->x_row_stride, stream))) return rc;
+    if ((rc = wgrad(a->km1, a->x, a->cin, a->dxd, a->gwd, a->x_row_stride, a->ev_wd))) return rc;
     if (a->want_gin) {
       if ((rc = lgs_conv_dgrad(a->km1, 0, a->dxd, c, a->wd, a->cin, a->gind, dt, a->conv_ws, a->pkd, a->pmd, stream))) return rc;
       acc = a->gind;

@@ -60,12 +60,14 @@ class BlockBwd(ctypes.Structure):
                 ("gw1", ctypes.c_void_p), ("gw2", ctypes.c_void_p), ("gwd", ctypes.c_void_p),
                 ("dgamma1", ctypes.c_void_p), ("dbeta1", ctypes.c_void_p), ("dgamma2", ctypes.c_void_p), ("dbeta2", ctypes.c_void_p),
                 ("dgammad", ctypes.c_void_p), ("dbetad", ctypes.c_void_p),
-                ("conv_ws", ctypes.c_void_p), ("bn_ws", ctypes.c_void_p)]
+                ("conv_ws", ctypes.c_void_p), ("bn_ws", ctypes.c_void_p),
+                ("wgrad_stream", ctypes.c_void_p), ("wgrad_ws", ctypes.c_void_p), ("fork_event", ctypes.c_void_p),
+                ("ev_w1", ctypes.c_void_p), ("ev_w2", ctypes.c_void_p), ("ev_wd", ctypes.c_void_p)]
 
 
 # struct-module formats of lgs_block_fwd / lgs_block_bwd (native alignment); checked against the ctypes layouts at import
 BLOCK_FWD_FMT = "@PPiiiiqP" + "PPP" + "PPP" + "iii" + "PPPPPff" * 3 + "PPPPPP" + "PPP" + "PP"
-BLOCK_BWD_FMT = "@PPiiiiiiqqP" + "PPPPPP" + "PPP" + "PPP" + "PPP" + "iii" + "PPPPPP" + "PPPPPP" + "PPP" + "PPPPPP" + "PP"
+BLOCK_BWD_FMT = "@PPiiiiiiqqP" + "PPPPPP" + "PPP" + "PPP" + "PPP" + "iii" + "PPPPPP" + "PPPPPP" + "PPP" + "PPPPPP" + "PP" + "PPPPPP"
 import struct as _struct
 assert _struct.calcsize(BLOCK_FWD_FMT) == ctypes.sizeof(BlockFwd), (_struct.calcsize(BLOCK_FWD_FMT), ctypes.sizeof(BlockFwd))
 assert _struct.calcsize(BLOCK_BWD_FMT) == ctypes.sizeof(BlockBwd), (_struct.calcsize(BLOCK_BWD_FMT), ctypes.sizeof(BlockBwd))

@@ -121,6 +121,23 @@ def _ws(nbytes, device, stream=None):
     return t
 
 
+def _param_event(param):
+    """the reusable event of a kernel parameter's weight gradient (me/modules.py conv_weight_grad; BucketedDDP waits on it)"""
+    ev = getattr(param, "_lgs_wgrad_event", None)
+    if ev is None:
+        ev = param._lgs_wgrad_event = torch.cuda.Event()
+    return ev
+
+
+def _raw_event(ev, stream):
+    """hipEvent_t of a torch event for the engine to record; torch creates the handle at the first record"""
+    h = ev.cuda_event
+    if not h:
+        ev.record(stream)
+        h = ev.cuda_event
+    return int(h.value if hasattr(h, "value") else h)
+
+
 _DESC_FIELDS = [f for f, _ in engine.PackDesc._fields_]
 
 
@@ -631,6 +648,7 @@ class HipBackend:
 
     def block_backward(self, dy, saved, extra, kmap3, kmap1, pcs, params, relu_final, want_gin):
         """BasicBlock backward through lgs_block_backward -> the gradient tuple of models._BasicBlockFunction"""
+        from . import modules as _modules
         from .modules import grad_slot_view
         L = engine.lib()
         self.block_calls = getattr(self, "block_calls", 0) + 1
@@ -657,9 +675,14 @@ class HipBackend:
             b0 = buf.data_ptr()
             row = n * planes * x.element_size()
 
+            slots = [True]
+
             def wgrad_out(param, ref):
                 v = grad_slot_view(param) if param is not None else None
-                return v if v is not None else torch.empty(ref.shape, dtype=torch.float32, device=dev)
+                if v is None:
+                    slots[0] = False
+                    return torch.empty(ref.shape, dtype=torch.float32, device=dev)
+                return v
 
             def affine_out(pg, pb, c):
                 gv = grad_slot_view(pg) if pg is not None else None
@@ -677,6 +700,19 @@ class HipBackend:
                 dgd, dbd = affine_out(pgd, pbd, planes)
                 gind = torch.empty((n, cin), dtype=x.dtype, device=dev)
             cws = self._block_ws(L, kmap3, kmap1, cin, planes, dt, n, dev).data_ptr()
+            # weight gradients beside the dgrad / BatchNorm chain (what modules.conv_weight_grad does call by call): every kernel
+            # parameter owns a gradient-bucket slot and the batch is not one of the small ones that keep them on the compute stream
+            side = None
+            s_raw = s_ws = s_fork = e1 = e2 = ed = 0
+            if not getattr(kmap3.mgr, "inline_wgrad", False) and slots[0] and _modules._DBG_WGRAD == "":
+                side = self.side_stream(dev)
+                s_raw = side.cuda_stream
+                need = max(kmap3._ws_bytes(L, cin, planes, dt, 2), kmap3._ws_bytes(L, planes, planes, dt, 2),
+                           kmap1._ws_bytes(L, cin, planes, dt, 2) if ds else 0)
+                s_ws = _ws(need, dev, side).data_ptr()
+                s_fork = _raw_event(self.fork_event(dev), side)
+                e1, e2 = _raw_event(_param_event(pw1), side), _raw_event(_param_event(pw2), side)
+                ed = _raw_event(_param_event(pwd), side) if ds else 0
             engine.BLOCK_BWD_PACK.pack_into(
                 self._blk_args_b, 0, kmap3.h.value, kmap1.h.value if ds else 0, dt, int(relu_final), cin, planes, int(want_gin), 0,
                 n, 0 if dy_ld == planes else dy_ld, dy.data_ptr(),
@@ -688,8 +724,14 @@ class HipBackend:
                 b0, b0 + row, b0 + 2 * row, b0 + 3 * row, (b0 + 4 * row) if ds else 0, gind.data_ptr() if ds else 0,
                 gw1.data_ptr(), gw2.data_ptr(), gwd.data_ptr() if ds else 0,
                 dg1.data_ptr(), db1.data_ptr(), dg2.data_ptr(), db2.data_ptr(), dgd.data_ptr() if ds else 0, dbd.data_ptr() if ds else 0,
-                cws, cws)
+                cws, cws, s_raw, s_ws, s_fork, e1, e2, ed)
             engine.check(L.lgs_block_backward(self._blk_addr_b, _stream()))
+            if side is not None:
+                # the side stream reads these after this call returns: their memory may only be reused in ITS order
+                for t in (x, y1, buf):
+                    t.record_stream(side)
+                for p in (pw2, pw1, pwd) if ds else (pw2, pw1):       # the order the engine issued them in
+                    _modules.note_side_wgrad(p)
         gin = (gind if ds else buf[1]) if want_gin else None
         # (all parameters of the fast path are fp32: the engine's fp32 gradients need no cast)
         out = (gin, None, None, None, gw1, dg1, db1, gw2, dg2, db2)

@@ -60,6 +60,15 @@ def grad_slot_view(param):
     return flat[off:off + n].view(shape)
 
 
+def note_side_wgrad(kparam):
+    """book-keeping of one weight gradient issued on the side stream (here, or by lgs_block_backward): its place in the stream's
+    order and the step it belongs to -- BucketedDDP picks the newest event of a bucket from these"""
+    _WGRAD_SEQ[0] += 1
+    kparam._lgs_wgrad_seq = _WGRAD_SEQ[0]
+    owner = getattr(kparam, "_lgs_ddp", None)
+    kparam._lgs_wgrad_step = owner._step if owner is not None else -1
+
+
 def conv_weight_grad(kmap, feats, gout, transposed, kparam, kshape, kdtype):
     """Weight gradient of one convolution.  When the kernel parameter owns a bucket slot the gradient is written straight
     into it ON A SIDE STREAM (off the backward critical path dgrad -> BN -> dgrad ...; both kernels are latency-bound, so
@@ -92,10 +101,7 @@ def conv_weight_grad(kmap, feats, gout, transposed, kparam, kshape, kdtype):
     if ev is None:
         ev = kparam._lgs_wgrad_event = torch.cuda.Event()
     ev.record(side)
-    _WGRAD_SEQ[0] += 1
-    kparam._lgs_wgrad_seq = _WGRAD_SEQ[0]
-    owner = getattr(kparam, "_lgs_ddp", None)
-    kparam._lgs_wgrad_step = owner._step if owner is not None else -1
+    note_side_wgrad(kparam)
     feats.record_stream(side)
     gout.record_stream(side)
     return view                                          # consumers wait for the side stream in BucketedDDP

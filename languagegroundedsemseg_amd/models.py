@@ -144,9 +144,10 @@ _BLOCK_C = _tuning.host("BLOCK_C") != 0
 
 
 def _c_block_ok(x, kmap3, kmap1, cin, planes, be):
-    """the one-call-per-direction entry points (csrc/lgs_block.hip) serve small batches (their weight gradients stay on the
-    compute stream) whose block input is a plain contiguous tensor and whose dgrad shape has the accumulating epilogue"""
-    if not (_BLOCK_C and getattr(kmap3.mgr, "inline_wgrad", False) and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32)):
+    """the one-call-per-direction entry points (csrc/lgs_block.hip) serve blocks whose input is a plain contiguous tensor and whose
+    dgrad shape has the accumulating epilogue (weight gradients: on the compute stream for small batches, else on the side stream
+    from inside the engine call)"""
+    if not (_BLOCK_C and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32)):
         return False
     if getattr(be, "conv_bn_stats", False) or not hasattr(be, "block_forward"):
         return False

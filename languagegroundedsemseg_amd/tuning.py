@@ -7,11 +7,13 @@ import os
 
 HOST_KNOBS = {
     # name: (default, parser, doc)
-    "WGRAD_INLINE_BELOW": (400000, int, "batches below this many input voxels run their weight gradients on the compute stream "
-                                        "(host-bound regime: no fork / join events); larger ones use the side stream"),
+    "WGRAD_INLINE_BELOW": (60000, int, "batches below this many input voxels run their weight gradients on the compute stream (no fork / "
+                                       "join events); larger ones use the side stream.  Was 400000 while a one-scene step was host-bound; "
+                                       "with lgs_block_backward forking inside the engine call one 145 k-voxel scene per step runs "
+                                       "9.6 - 9.9 ms on the side stream against 10.1 - 10.2 inline (backward 5.3 vs 6.6 ms of stream time)"),
     "BLOCK_FUSED": (1, int, "0 = BasicBlocks run module by module instead of as one autograd node "
                             "(bit-identical: test_block_fast_path_is_the_op_by_op_path)"),
-    "BLOCK_C": (1, int, "0 = small batches enqueue a BasicBlock call by call instead of through lgs_block_forward / lgs_block_backward "
+    "BLOCK_C": (1, int, "0 = a BasicBlock is enqueued call by call instead of through lgs_block_forward / lgs_block_backward "
                         "(bit-identical: test_c_side_block_equals_the_call_by_call_block)"),
     "PACK_CACHE": (1, int, "0 = re-pack the MFMA weight image on every conv call instead of once per optimiser step "
                            "(bit-identical: test_packed_weight_cache_never_serves_stale_weights)"),

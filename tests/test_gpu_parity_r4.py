@@ -176,10 +176,12 @@ def test_block_fast_path_declines_other_conv_shapes():
 # ------------------------------------------------------------------------------------------- C-side block entry points
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("with_ddp", [True, False])
-def test_c_side_block_equals_the_call_by_call_block(monkeypatch, dtype, with_ddp):
-    """lgs_block_forward / lgs_block_backward (one engine call per BasicBlock and direction, the small-batch regime) issue the
-    launches of the call-by-call path in the same order: logits, every gradient (through the gradient-bucket slots and without
-    them) and the running statistics are bit-identical; Res16UNet34C has blocks with and without the 1x1 downsample branch and
+@pytest.mark.parametrize("inline", [True, False])
+def test_c_side_block_equals_the_call_by_call_block(monkeypatch, dtype, with_ddp, inline):
+    """lgs_block_forward / lgs_block_backward (one engine call per BasicBlock and direction) issue the launches of the call-by-call
+    path in the same order -- weight gradients on the compute stream (inline: the small-batch regime) or, from inside the engine
+    call, on the side stream behind a fork event with the parameter's event recorded after them (what BucketedDDP waits for) --:
+    logits, every gradient (through the gradient-bucket slots and without them) and the running statistics are bit-identical; Res16UNet34C has blocks with and without the 1x1 downsample branch and
     without a final ReLU is covered by 34D's last block.  Reference: /root/reference/models/modules/resnet_block.py:41-57."""
     from languagegroundedsemseg_amd import engine, models
     from languagegroundedsemseg_amd.ddp import BucketedDDP
@@ -189,7 +191,7 @@ def test_c_side_block_equals_the_call_by_call_block(monkeypatch, dtype, with_ddp
     coords, feats, labels = make_batch([8], voxel=0.05, n_target=9000)
     c, f = torch.from_numpy(coords).to(DEV), torch.from_numpy(feats).to(DEV).to(dtype)
     l = torch.from_numpy(labels % 20).to(DEV)
-    monkeypatch.setattr(backend_hip, "_WGRAD_INLINE_BELOW", 1 << 30)
+    monkeypatch.setattr(backend_hip, "_WGRAD_INLINE_BELOW", (1 << 30) if inline else 0)
 
     def run(c_path, name):
         monkeypatch.setattr(models, "_BLOCK_C", c_path)
@@ -206,7 +208,7 @@ def test_c_side_block_equals_the_call_by_call_block(monkeypatch, dtype, with_ddp
             else:
                 m.zero_grad(set_to_none=True)
             x = ME.SparseTensor(f, c)
-            assert x.coordinate_manager._m.inline_wgrad
+            assert bool(x.coordinate_manager._m.inline_wgrad) == inline
             engine.dispatch_counts(reset=True)
             y = m(x)
             out = y[0].F if isinstance(y, tuple) else y.F
