@@ -221,9 +221,15 @@ class BucketedDDP:
     def zero_grad(self):
         self._next = 0
         self._step += 1
+        # two multi-tensor launches for all buckets (a zero_ and a slice fill per bucket were 11 launches at the head of every step)
+        flats = [b["flat"] for b in self.buckets]
+        if flats:
+            torch._foreach_zero_(flats)
+            flags = getattr(self, "_flag_views", None)
+            if flags is None or len(flags) != len(flats) or any(f._base is not b["flat"] for f, b in zip(flags, self.buckets)):
+                flags = self._flag_views = [b["flat"][b["flag_off"]:b["flag_off"] + b["n"]] for b in self.buckets]
+            torch._foreach_add_(flags, 1.0)          # (just zeroed: the "used" flags are all ones again)
         for b in self.buckets:
-            b["flat"].zero_()
-            b["flat"][b["flag_off"]:b["flag_off"] + b["n"]] = 1.0
             b["pending"] = b["n"]
             b["launched"] = False
             for p, _ in b["views"]:
