@@ -126,6 +126,19 @@ class ConvLog:
         wrap("conv_wgrad", "wgrad")
         self.M_of = {}
         self._patched = True
+        # residual blocks are ONE engine call per direction (lgs_block_forward / lgs_block_backward): their conv launches cannot
+        # be bracketed from here.  A block whose launches are wanted is enqueued call by call (same launches, bit-identical):
+        # every block in the discovery step and under --roctx, only the blocks containing the dominant shape in the timed steps.
+        def veto(rows, cin, planes):
+            if log.mode in ("all", "roctx"):
+                return True
+            if log.mode == "only":
+                mine = {ConvLog.key_of("", 27, cin, planes, rows), ConvLog.key_of("", 27, planes, planes, rows),
+                        ConvLog.key_of("", 27, planes, cin, rows), ConvLog.key_of("", 1, cin, planes, rows),
+                        ConvLog.key_of("", 1, planes, cin, rows)}
+                return log.only_key in mine
+            return False
+        models._BLOCK_C_VETO = veto
 
     def summarize(self):
         """-> (family totals of k_conv_gather launches, wgrad totals, per-shape groups sorted by time)"""
@@ -495,7 +508,9 @@ def roofline_report(clog, disc, dtype_name, workload, steps, ms_per_step, n_vox,
         "mfma_tflops_on_real_pairs": flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
         "mfma_frac_of_peak_on_real_pairs": flop / (avg_ms * 1e-3) / mfma_peak if avg_ms > 0 else 0.0,
         "measured": "HIP events on the launching stream around the %d launches of this shape inside the %d timed steps "
-                    "(weight pack ~6 us + kernel); all other launches of the timed steps are un-instrumented" % (len(samp_ms), steps),
+                    "(weight pack ~6 us + kernel); all other launches of the timed steps are un-instrumented; the residual blocks that "
+                    "contain this shape are enqueued call by call instead of through lgs_block_forward / lgs_block_backward (same "
+                    "launches, bit-identical) so that Python can bracket them" % (len(samp_ms), steps),
         "discovery_step": {
             "note": "one fully instrumented warm-up step (every conv launch bracketed: the step is stretched, durations "
                     "rank the shapes and feed the byte model only)",

@@ -141,6 +141,8 @@ def _bn_bwd(be, x, y, dy, g, b, gp, bp, stats, relu_mode, want_res, need):
 
 
 _BLOCK_C = _tuning.host("BLOCK_C") != 0
+_BLOCK_C_VETO = None    # measurement hook (bench.py's per-launch instrumentation): callable(rows, cin, planes) -> True = enqueue this
+#                         block call by call (same launches, same results), so that its conv launches can be bracketed from Python
 
 
 def _c_block_ok(x, kmap3, kmap1, cin, planes, be):
@@ -150,6 +152,8 @@ def _c_block_ok(x, kmap3, kmap1, cin, planes, be):
     if not (_BLOCK_C and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32)):
         return False
     if getattr(be, "conv_bn_stats", False) or not hasattr(be, "block_forward"):
+        return False
+    if _BLOCK_C_VETO is not None and _BLOCK_C_VETO(x.shape[0], cin, planes):
         return False
     key = ("cblk", cin, planes, x.dtype)
     ok = kmap3._wsb.get(key)
