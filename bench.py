@@ -418,9 +418,10 @@ def make_trainer(model_name, dtype, device, world, args, ctx):
         model.representation_only(True)
     if ctx and ctx["kind"] == "insseg" and ctx["frozen"]:
         model.freeze_trunk(True)
-    if world > 1 and args.sync_bn:
+    force = bool(getattr(args, "dp_world1", False)) and world == 1 and dist.is_initialized()
+    if (world > 1 or force) and args.sync_bn:
         model = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)
-    ddp = BucketedDDP(model, bucket_mb=32.0, allreduce=args.allreduce)
+    ddp = BucketedDDP(model, bucket_mb=32.0, allreduce=args.allreduce, force_collectives=force)
     opt = FlatSGD(ddp, lr=1e-2, momentum=0.9, dampening=0.1, weight_decay=1e-4)  # same rule as lib/solvers.py's SGD
     return model, ddp, opt
 
@@ -551,6 +552,46 @@ def secondary_block(workload, model_name, dtype, coords, feats, labels, device, 
     return out
 
 
+def dp_path_block(coords, feats, labels, device, args, dtype, steps=8, warmup=3):
+    """The code path every rank runs at N > 1 -- MinkowskiSyncBatchNorm (statistics / combine / apply as separate kernels around an
+    all-gather and an all-reduce per layer) and bucketed gradient all-reduces from the backward hooks -- timed on THIS one GPU with
+    RCCL and a world of one rank: the collectives are real RCCL launches the compute stream waits for, only the wire is missing.
+    What a rank pays for the N > 1 path before any inter-GPU time (main.py:121-123; DESIGN section 5 budgets the wire)."""
+    import gc
+    if dist.is_initialized():
+        return None
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    except Exception as e:          # no RCCL in this build: report, do not fail the bench line
+        return {"error": "nccl process group of one rank: %s" % e}
+    prev = ME.MinkowskiSyncBatchNorm.force_sync
+    try:
+        ME.MinkowskiSyncBatchNorm.force_sync = True
+        import copy
+        a2 = copy.copy(args)
+        a2.dp_world1, a2.sync_bn = True, 1
+        model, ddp, opt = make_trainer("Res16UNet34C", dtype, device, 1, a2, None)
+        ddp.enable_timing()
+        res = measure(model, ddp, opt, coords, feats, labels, dtype, steps, warmup, None, None, 1, False, base=40000)
+        n_vox = int(coords.shape[0])
+        out = {"note": "the per-rank code path of N > 1 (SyncBN split kernels + one all-gather and one all-reduce per layer, bucketed "
+                       "gradient all-reduce) on one GPU with RCCL and a world of ONE rank: every collective is a real RCCL launch, "
+                       "only the wire time is missing",
+               "ms_per_step": res["dt"] / steps * 1e3, "value": n_vox * steps / res["dt"], "unit": "voxels/s", "steps": steps,
+               "phases": res["phases"], "ddp": ddp.timing_summary(steps), "backend": dist.get_backend(), "allreduce": args.allreduce}
+        del model, ddp, opt, res
+    finally:
+        ME.MinkowskiSyncBatchNorm.force_sync = prev
+        from languagegroundedsemseg_amd import ddp as _ddp_mod
+        _ddp_mod._TIMING["on"] = False
+        _ddp_mod.EngineComm.close_all()
+        dist.destroy_process_group()
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def _free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
@@ -619,6 +660,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
                                                        "N>1 code path with several ranks on ONE GPU)")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (single-GPU dry run of the N>1 path)")
+    ap.add_argument("--dp-world1", action="store_true", help="N = 1 only: run the per-rank code path of N > 1 (SyncBN collectives, bucketed "
+                                                              "all-reduce) through RCCL with a world of ONE rank (diagnostic; the default "
+                                                              "line carries the same measurement as `dp_path_world1`)")
     args = ap.parse_args()
     if args.model is None:
         args.model = "Res16UNet34C" if args.workload == "ce" else "Res16UNet34D"
@@ -628,6 +672,12 @@ def main():
         if not args.same_device and torch.cuda.device_count() < args.gpus:
             raise RuntimeError("bench.py --gpus %d: this node exposes %d GPUs" % (args.gpus, torch.cuda.device_count()))
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    # ONE JSON line on stdout, whatever the libraries underneath print: RCCL writes its version banner to stdout when the first
+    # communicator comes up.  Everything this process (and the C code it loads) writes to fd 1 goes to stderr; the line is written
+    # to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -650,6 +700,12 @@ def main():
                 dist.init_process_group("nccl")
         else:
             dist.init_process_group(args.backend)
+    if args.dp_world1:
+        if world != 1:
+            raise RuntimeError("--dp-world1 is a single-GPU diagnostic (N > 1 runs that path anyway)")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+        ME.MinkowskiSyncBatchNorm.force_sync = True
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
     # ---- data: scenes shard over ranks (rank r owns seeds r*S .. r*S+S-1); resident in HBM before timing
@@ -686,7 +742,7 @@ def main():
         rl.roctx = ctypes.CDLL("librocprofiler-sdk-roctx.so")
         rl.roctx.roctxRangePushA.argtypes = [ctypes.c_char_p]
         rl.mode = "roctx"
-    if world > 1:
+    if world > 1 or args.dp_world1:
         ddp.enable_timing()
     res = measure(model, ddp, opt, coords, feats, labels, dtype, args.steps, args.warmup, ctx, clog, world, not args.no_roofline)
     dt, loss = res["dt"], res["loss"]
@@ -741,7 +797,7 @@ def main():
         if args.workload == "clip":
             out["roofline"]["mfma"] = clip_mfma_report(out_dim=model.PLANES[7], n=n_vox, dtype=dtype, device=device)
     log("roofline pass done")
-    secondary = rank == 0 and world == 1 and not args.no_secondary and args.workload == "ce" and args.dtype == "bf16"
+    secondary = rank == 0 and world == 1 and not args.no_secondary and args.workload == "ce" and args.dtype == "bf16" and not args.dp_world1
     if rank == 0 and world == 1 and not args.no_single_scene and args.scenes != 1:
         out["single_scene"] = single_scene_line(model, ddp, opt, dtype, device, args, ctx)
         log("single-scene line done")
@@ -764,13 +820,19 @@ def main():
                                             steps=5, warmup=3, note="BASELINE configs[4]: head on frozen pretrained features (eval-mode trunk under "
                                                                     "no_grad, only offsets_pre / bntr_offset / offsets / final are trained)")}
         log("insseg block done")
+        out["dp_path_world1"] = dp_path_block(coords, feats, labels, device, args, dtype)
+        log("dp-path block done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model_name=args.model, voxels=args.voxels)
         log("cpu baseline done")
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
+        from languagegroundedsemseg_amd.ddp import EngineComm
+        EngineComm.close_all()
         dist.destroy_process_group()
 
 

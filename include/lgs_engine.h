@@ -236,6 +236,31 @@ int lgs_bn_backward_apply(const void *x, const void *y, const void *dy, int64_t 
                           const float *beta, const float *stats, const float *sums, float inv_n_total,
                           const float *inv_n_device, int relu, void *dx, void *dresidual, int dtype, void *stream);
 
+/* ---- SyncBatchNorm as one call per direction, on the engine's own RCCL communicator (csrc/lgs_comm.hip) --------
+ * replaces the per-layer statistics exchange of ME.MinkowskiSyncBatchNorm (convert_sync_batchnorm, /root/reference/main.py:121-123;
+ * downstream/insseg/lib/ddp_trainer.py:191-194) when it runs rank per GPU: the split kernels above with ncclAllGather /
+ * ncclAllReduce issued ON THE CALLER'S STREAM between them (no process-group stream hand-over, no host code in between).
+ *   lgs_comm_unique_id   rank 0: 128 opaque bytes (ncclGetUniqueId) for the ranks to share (e.g. one torch.distributed broadcast)
+ *   lgs_comm_create      every rank, collectively (ncclCommInitRank on `device`); lgs_comm_destroy releases it
+ *   lgs_bn_forward_sync  = lgs_bn_stats -> all-gather [world][2C+1] -> lgs_bn_sync_combine -> lgs_bn_apply; stats [2C] and
+ *                          inv_n [1] (device scalar 1 / global rows) are outputs the backward takes back
+ *   lgs_bn_backward_sync = lgs_bn_backward_reduce -> all-reduce [2C] -> lgs_bn_backward_apply (dgamma / dbeta stay local)
+ * RCCL is resolved at run time from the librccl the process has loaded; without one lgs_comm_* fail with a message and the
+ * caller keeps its own collectives.  workspace: lgs_bn_sync_workspace_bytes(n, c, world). */
+typedef struct lgs_comm lgs_comm;
+int lgs_comm_unique_id(void *id128);
+int lgs_comm_create(const void *id128, int world, int rank, int device, lgs_comm **out);
+int lgs_comm_destroy(lgs_comm *comm);
+int lgs_comm_world(const lgs_comm *comm);
+int64_t lgs_bn_sync_workspace_bytes(int64_t n, int c, int world);
+int lgs_bn_forward_sync(lgs_comm *comm, const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps,
+                        float momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                        const void *residual, int relu, void *y, float *stats, float *inv_n, int dtype, void *workspace,
+                        void *stream);
+int lgs_bn_backward_sync(lgs_comm *comm, const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
+                         const float *beta, const float *stats, const float *inv_n, int relu, void *dx, void *dresidual,
+                         float *dgamma, float *dbeta, int dtype, void *workspace, void *stream);
+
 /* ---- one call per residual block and direction (csrc/lgs_block.hip) -----------------------------
  * replaces the call sequence of BasicBlock.forward and of its autograd backward
  *   /root/reference/models/modules/resnet_block.py:41-57   (conv1 - norm1 - relu - conv2 - norm2 - (+ residual) - relu)

@@ -213,7 +213,9 @@ class BucketedDDP:
             return None
         out = {"allreduce_exposed_wait_ms": sum(a.elapsed_time(b) for a, b in t["wait"]) / max(steps, 1),
                "bucket_collectives_per_step": len(t["launch_ev"]) / max(steps, 1),
-               "syncbn_collective_ms": sum(a.elapsed_time(b) for a, b in t["syncbn"]) / max(steps, 1),
+               # (collectives issued by the engine inside its own call are counted, not timed: entries without events)
+               "syncbn_collective_ms": sum(ab[0].elapsed_time(ab[1]) for ab in t["syncbn"] if ab is not None) / max(steps, 1),
+               "syncbn_collectives_in_engine_calls_per_step": sum(1 for ab in t["syncbn"] if ab is None) / max(steps, 1),
                "syncbn_collectives_per_step": len(t["syncbn"]) / max(steps, 1)}
         t["launch_ev"].clear(); t["wait"].clear(); t["syncbn"].clear()
         return out
@@ -397,25 +399,115 @@ class _SyncBNFunction(torch.autograd.Function):
         return dx.to(dy.dtype), dgamma.to(weight.dtype), dbeta.to(weight.dtype), None, None, None, None, None
 
 
+class EngineComm:
+    """The engine's own RCCL communicator for one process group (csrc/lgs_comm.hip): SyncBN's per-layer collectives are issued by
+    the engine ON THE COMPUTE STREAM between its kernels instead of through ProcessGroupNCCL (its stream hand-overs and ~60 us of
+    host work per collective).  Created collectively the first time a SyncBN layer of the group runs: rank 0 draws the id, one
+    torch.distributed broadcast shares it.  `LGS_SYNCBN_ENGINE_COMM=0` keeps torch.distributed's collectives."""
+    _by_group = {}
+
+    def __init__(self, group, device):
+        import ctypes
+        from . import engine
+        L = engine.lib()
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            engine.check(L.lgs_comm_unique_id(buf))
+        box = [bytes(buf.raw)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        h = ctypes.c_void_p(None)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        engine.check(L.lgs_comm_create(ctypes.create_string_buffer(box[0], 128), world, rank, idx, ctypes.byref(h)))
+        self.h, self.world, self.rank, self._L = h, world, rank, L
+
+    def close(self):
+        if self.h is not None and self.h.value:
+            self._L.lgs_comm_destroy(self.h)
+            self.h = None
+
+    @classmethod
+    def get(cls, group, device):
+        """-> EngineComm of this group, or None (off by knob, not an RCCL group, or RCCL could not be reached: said once)"""
+        from . import tuning as _tuning
+        key = (id(group) if group is not None else 0, device.index)
+        if key in cls._by_group:
+            return cls._by_group[key]
+        comm = None
+        if _tuning.host("SYNCBN_ENGINE_COMM") and dist.get_backend(group) == "nccl":
+            try:
+                comm = cls(group, device)
+            except Exception as e:      # every rank takes the same branch: the failure modes (no librccl, init error) are not per rank
+                import sys
+                print("[lgs] engine-side RCCL communicator unavailable (%s): SyncBN keeps torch.distributed's collectives" % e, file=sys.stderr)
+        cls._by_group[key] = comm
+        return comm
+
+    @classmethod
+    def close_all(cls):
+        for c in cls._by_group.values():
+            if c is not None:
+                c.close()
+        cls._by_group.clear()
+
+
+def sync_bn_forward(backend, x, weight, bias, residual, running_mean, running_var, nbt, eps, momentum, relu, group, conv_stats=None):
+    """SyncBN forward on the engine's split kernels: local (mean, M2, count) -> ONE all_gather of 2C+1 floats per rank -> Chan's
+    parallel combination (+ running statistics) -> fused normalise (+residual) (+ReLU).  -> y, stats [2C], inv_n [1] (device)"""
+    c = x.shape[1]
+    world = dist.get_world_size(group)
+    comm = EngineComm.get(group, x.device) if (x.is_cuda and conv_stats is None and hasattr(backend, "bn_forward_sync")) else None
+    if comm is not None:        # ONE engine call: statistics -> ncclAllGather -> combine -> apply, all on the compute stream
+        if _TIMING["on"]:
+            _SYNCBN_EVENTS.append(None)
+        return backend.bn_forward_sync(comm, x, weight, bias, eps, momentum, running_mean, running_var, nbt, residual, relu)
+    # [mean | M2 | count], 2 kernels; the partial sums come from the producing conv's epilogue when it made them
+    local = backend.bn_stats(x, conv_stats) if conv_stats is not None else backend.bn_stats(x)
+    allst = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=x.device)
+    if dist.get_backend(group) == "nccl":
+        _timed_collective(lambda: dist.all_gather_into_tensor(allst, local, group=group), x.is_cuda)
+    else:  # gloo (single-GPU dry runs / CPU tests) has no flat all-gather
+        _timed_collective(lambda: dist.all_gather(list(allst.unbind(0)), local, group=group), x.is_cuda)
+    # one kernel: Chan's combination, running statistics, num_batches_tracked, 1/N (device scalar)
+    stats, inv_n = backend.bn_sync_combine(allst, c, eps, momentum, running_mean, running_var, nbt)
+    y = backend.bn_apply(x, weight, bias, stats, residual, relu)
+    return y, stats, inv_n
+
+
+def sync_bn_backward(backend, x, y, dy, weight, bias, stats, inv_n, relu_mode, want_res, group, gparam, bparam):
+    """SyncBN backward: local [sum dy' | sum dy' xhat] -> ONE all_reduce of 2C floats -> apply.  Parameter gradients stay local
+    (DDP averages them): written by the reduce kernel, straight into the gradient-bucket slots when gparam / bparam own them.
+    -> dx, dres, dgamma, dbeta, slots (True: dgamma / dbeta ARE the slot views)"""
+    from .me.modules import grad_slot_view
+    c = x.shape[1]
+    gview = grad_slot_view(gparam) if gparam is not None else None
+    bview = grad_slot_view(bparam) if bparam is not None else None
+    if gview is None or bview is None:
+        gview = bview = None
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    else:
+        dgamma, dbeta = gview, bview
+    comm = EngineComm.get(group, x.device) if (x.is_cuda and hasattr(backend, "bn_backward_sync")) else None
+    if comm is not None:        # ONE engine call: reduce -> ncclAllReduce -> apply
+        if _TIMING["on"]:
+            _SYNCBN_EVENTS.append(None)
+        dx, dres = backend.bn_backward_sync(comm, x, y, dy, weight, bias, stats, inv_n, relu_mode, want_res, dgamma, dbeta)
+        return dx, dres, dgamma, dbeta, gview is not None
+    sums = backend.bn_backward_reduce(x, y, dy, weight, bias, stats, relu_mode, dgamma, dbeta)
+    _timed_collective(lambda: dist.all_reduce(sums, group=group), x.is_cuda)
+    dx, dres = backend.bn_backward_apply(x, y, dy, weight, bias, stats, sums, inv_n, relu_mode, want_res)
+    return dx, dres, dgamma, dbeta, gview is not None
+
+
 class _SyncBNFused(torch.autograd.Function):
-    """SyncBN on the engine's split kernels (lgs_bn_stats / lgs_bn_apply / lgs_bn_backward_reduce /
-    lgs_bn_backward_apply): local (mean, M2, count) -> ONE all_gather of 2C+1 floats per rank -> Chan's parallel
-    combination -> fused normalise(+residual)(+ReLU); backward: local sums -> ONE all_reduce of 2C floats."""
+    """SyncBN as one autograd node around sync_bn_forward / sync_bn_backward (the whole-block node of models.py calls the
+    same two functions)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, nbt, eps, momentum, relu, group, backend, conv_stats=None):
-        c = x.shape[1]
-        world = dist.get_world_size(group)
-        # [mean | M2 | count], 2 kernels; the partial sums come from the producing conv's epilogue when it made them
-        local = backend.bn_stats(x, conv_stats) if conv_stats is not None else backend.bn_stats(x)
-        allst = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=x.device)
-        if dist.get_backend(group) == "nccl":
-            _timed_collective(lambda: dist.all_gather_into_tensor(allst, local, group=group), x.is_cuda)
-        else:  # gloo (single-GPU dry runs / CPU tests) has no flat all-gather
-            _timed_collective(lambda: dist.all_gather(list(allst.unbind(0)), local, group=group), x.is_cuda)
-        # one kernel: Chan's combination, running statistics, num_batches_tracked, 1/N (device scalar)
-        stats, inv_n = backend.bn_sync_combine(allst, c, eps, momentum, running_mean, running_var, nbt)
-        y = backend.bn_apply(x, weight, bias, stats, residual, relu)
+        y, stats, inv_n = sync_bn_forward(backend, x, weight, bias, residual, running_mean, running_var, nbt, eps, momentum, relu,
+                                          group, conv_stats)
         ctx.backend, ctx.group, ctx.has_res = backend, group, residual is not None
         ctx.relu_mode = 0 if not relu else (1 if residual is not None else 2)
         ctx.gparam = weight if isinstance(weight, torch.nn.Parameter) else None
@@ -425,27 +517,13 @@ class _SyncBNFused(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        from .me.modules import grad_slot_view
         x, weight, bias, stats, y, inv_n = ctx.saved_tensors
         dy = dy.contiguous()
         yy = y if ctx.relu_mode == 1 else None
-        c = x.shape[1]
-        # parameter gradients stay local (DDP averages them): written by the reduce kernel, straight into the gradient
-        # bucket slots when the parameters have them
-        gview = grad_slot_view(ctx.gparam) if ctx.gparam is not None else None
-        bview = grad_slot_view(ctx.bparam) if ctx.bparam is not None else None
-        if gview is None or bview is None:
-            gview = bview = None
-            dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
-            dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
-        else:
-            dgamma, dbeta = gview, bview
-        sums = ctx.backend.bn_backward_reduce(x, yy, dy, weight, bias, stats, ctx.relu_mode, dgamma, dbeta)
-        _timed_collective(lambda: dist.all_reduce(sums, group=ctx.group), x.is_cuda)
-        dx, dres = ctx.backend.bn_backward_apply(x, yy, dy, weight, bias, stats, sums, inv_n, ctx.relu_mode,
-                                                 ctx.has_res and ctx.needs_input_grad[3])
-        if gview is not None:
-            return dx, gview, bview, dres, None, None, None, None, None, None, None, None, None
+        dx, dres, dgamma, dbeta, slots = sync_bn_backward(ctx.backend, x, yy, dy, weight, bias, stats, inv_n, ctx.relu_mode,
+                                                          ctx.has_res and ctx.needs_input_grad[3], ctx.group, ctx.gparam, ctx.bparam)
+        if slots:
+            return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
         return dx, dgamma.to(weight.dtype), dbeta.to(weight.dtype), dres, None, None, None, None, None, None, None, None, None
 
 

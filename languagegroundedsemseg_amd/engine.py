@@ -94,6 +94,8 @@ EXPORTS = [
     "lgs_clip_anchor_grad_workspace_bytes", "lgs_clip_loss_backward_anchors",
     "lgs_ce_forward_backward",
     "lgs_ce_count_valid",
+    "lgs_comm_unique_id", "lgs_comm_create", "lgs_comm_destroy", "lgs_comm_world", "lgs_bn_sync_workspace_bytes",
+    "lgs_bn_forward_sync", "lgs_bn_backward_sync",
     "lgs_voxelize", "lgs_label_vote", "lgs_cluster_workspace_bytes", "lgs_cluster", "lgs_sgd_step",
 ]
 
@@ -158,6 +160,12 @@ def lib():
         "lgs_clip_similarity": [vp, i64, ci, vp, ci, vp, vp, ci, vp, vp],
         "lgs_ce_forward_backward": [vp, i64, ci, vp, i64, vp, vp, vp, ci, vp],
         "lgs_ce_count_valid": [vp, i64, ci, i64, vp, vp],
+        "lgs_comm_unique_id": [vp],
+        "lgs_comm_create": [vp, ci, ci, ci, ctypes.POINTER(vp)],
+        "lgs_comm_destroy": [vp],
+        "lgs_comm_world": [vp],
+        "lgs_bn_forward_sync": [vp, vp, i64, ci, vp, vp, cf, cf, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp],
+        "lgs_bn_backward_sync": [vp, vp, vp, vp, i64, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp],
         "lgs_clip_loss_forward": [vp, i64, ci, vp, ci, vp, vp, ci, i64, vp, vp, vp, vp, vp, vp, ci, vp, vp],
         "lgs_clip_loss_backward": [vp, i64, ci, vp, ci, vp, vp, ci, i64, vp, vp, vp, vp, vp, vp, ci, vp],
         "lgs_clip_loss_backward_anchors": [vp, i64, ci, ci, vp, vp, ci, i64, vp, vp, vp, vp, ci, vp, vp],
@@ -178,6 +186,8 @@ def lib():
     L.lgs_conv_workspace_bytes.argtypes = [vp, ci, ci, ci, ci]
     L.lgs_bn_workspace_bytes.restype = i64
     L.lgs_bn_workspace_bytes.argtypes = [i64, ci]
+    L.lgs_bn_sync_workspace_bytes.restype = i64
+    L.lgs_bn_sync_workspace_bytes.argtypes = [i64, ci, ci]
     L.lgs_clip_workspace_bytes.restype = i64
     L.lgs_clip_workspace_bytes.argtypes = [ci, ci, ci]
     L.lgs_clip_loss_workspace_bytes.restype = i64

@@ -776,6 +776,36 @@ class HipBackend:
                                         _dtype_code(x), _stream()))
         return y
 
+    # ---- SyncBN as one call per direction on the engine's own RCCL communicator (csrc/lgs_comm.hip)
+    def bn_forward_sync(self, comm, x, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, residual, relu):
+        """-> y, stats [2C], inv_n [1]"""
+        L = engine.lib()
+        x = x.contiguous()
+        n, c = x.shape
+        with _dev(x.device):
+            y = torch.empty_like(x)
+            stats = torch.empty(2 * c + 1, dtype=torch.float32, device=x.device)      # [mean | invstd | 1 / global rows]
+            res = residual.contiguous() if residual is not None else None
+            ws = _ws(L.lgs_bn_sync_workspace_bytes(n, c, comm.world), x.device)
+            engine.check(L.lgs_bn_forward_sync(comm.h, _ptr(x), n, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
+                                               _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(res), int(relu),
+                                               _ptr(y), stats.data_ptr(), stats.data_ptr() + 8 * c, _dtype_code(x), _ptr(ws), _stream()))
+        _written_by_engine(running_mean, running_var, num_batches_tracked)
+        return y, stats[:2 * c], stats[2 * c:]
+
+    def bn_backward_sync(self, comm, x, y, dy, gamma, beta, stats, inv_n, relu, want_residual, dgamma_out=None, dbeta_out=None):
+        """-> dx, dres (dgamma_out / dbeta_out receive the LOCAL parameter gradients)"""
+        L = engine.lib()
+        n, c = x.shape
+        with _dev(x.device):
+            dx = torch.empty_like(x)
+            dres = torch.empty_like(x) if want_residual else None
+            ws = _ws(L.lgs_bn_sync_workspace_bytes(n, c, comm.world), x.device)
+            engine.check(L.lgs_bn_backward_sync(comm.h, _ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(inv_n),
+                                                int(relu), _ptr(dx), _ptr(dres), _ptr(dgamma_out), _ptr(dbeta_out), _dtype_code(x),
+                                                _ptr(ws), _stream()))
+        return dx, dres
+
     def bn_backward_reduce(self, x, y, dy, gamma, beta, stats, relu, dgamma_out=None, dbeta_out=None):
         """-> sums [2C] (local sum dy', sum dy' xhat); the same vectors are also written to dgamma_out / dbeta_out"""
         L = engine.lib()

@@ -98,9 +98,25 @@ def _block_fast_path_ok(blk, x):
         return False
     for n in norms:
         b = n.bn
-        if type(n) is not ME.MinkowskiBatchNorm or not (b.training and b.affine and b.track_running_stats) or not _plain(n) or not _plain(b):
+        if (type(n) not in (ME.MinkowskiBatchNorm, ME.MinkowskiSyncBatchNorm) or type(n) is not type(norms[0])
+                or not (b.training and b.affine and b.track_running_stats) or not _plain(n) or not _plain(b)):
             return False
+    if type(norms[0]) is ME.MinkowskiSyncBatchNorm and any(n.process_group is not norms[0].process_group for n in norms):
+        return False
     return x.F.dtype in (torch.bfloat16, torch.float32) and x.F.shape[1] == blk.conv1.in_channels
+
+
+def _sync_group(norm):
+    """-> (True, process group) when this norm exchanges statistics across ranks in this call (MinkowskiSyncBatchNorm.forward's
+    own condition), else (False, None)"""
+    if type(norm) is not ME.MinkowskiSyncBatchNorm:
+        return False, None
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False, None
+    if dist.get_world_size(norm.process_group) > 1 or ME.MinkowskiSyncBatchNorm.force_sync:
+        return True, norm.process_group
+    return False, None
 
 
 def _block_fast_forward(blk, x):
@@ -118,18 +134,33 @@ def _block_fast_forward(blk, x):
     return ME.SparseTensor(y, coordinate_map_key=key, coordinate_manager=mgr)
 
 
-def _bn_fwd(be, x, bn, g, b, residual, relu, conv_stats):
+def _bn_fwd(be, x, bn, g, b, residual, relu, conv_stats, sync=(False, None)):
+    """-> y, stats, inv_n (inv_n: device scalar 1 / global rows of a SyncBN layer, else None)"""
     if conv_stats is not None and (conv_stats[1] is None):
         conv_stats = None                                  # pivot convention of MinkowskiBatchNorm.forward
+    if sync[0]:
+        from .ddp import sync_bn_forward
+        return sync_bn_forward(be, x, g, b, residual, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum,
+                               relu, sync[1], conv_stats)
+    return _bn_fwd_local(be, x, bn, g, b, residual, relu, conv_stats) + (None,)
+
+
+def _bn_fwd_local(be, x, bn, g, b, residual, relu, conv_stats):
     if conv_stats is not None:
         return be.bn_forward(x, g, b, bn.eps, bn.momentum, bn.running_mean, bn.running_var, residual, relu, bn.num_batches_tracked,
                              conv_stats=conv_stats)
     return be.bn_forward(x, g, b, bn.eps, bn.momentum, bn.running_mean, bn.running_var, residual, relu, bn.num_batches_tracked)
 
 
-def _bn_bwd(be, x, y, dy, g, b, gp, bp, stats, relu_mode, want_res, need):
+def _bn_bwd(be, x, y, dy, g, b, gp, bp, stats, relu_mode, want_res, need, sync=(False, None), inv_n=None):
     """-> dx, dres, d gamma, d beta (the last two as bucket-slot views when the parameters gp / bp own slots)"""
     from .me.modules import grad_slot_view
+    if sync[0]:
+        from .ddp import sync_bn_backward
+        dx, dres, dg, db, slots = sync_bn_backward(be, x, y, dy.contiguous(), g, b, stats, inv_n, relu_mode, want_res, sync[1], gp, bp)
+        if slots:
+            return dx, dres, dg, db
+        return dx, dres, (dg.to(g.dtype) if need else None), (db.to(g.dtype) if need else None)
     gv = grad_slot_view(gp) if gp is not None else None
     bv = grad_slot_view(bp) if bp is not None else None
     if gv is None or bv is None:
@@ -170,7 +201,11 @@ class _BasicBlockFunction(torch.autograd.Function):
         be = ME.get_backend()
         n1, n2 = blk.norm1.bn, blk.norm2.bn
         pc1, pc2 = blk.conv1._cache_for(x), blk.conv2._cache_for(x)
-        ctx.c_path = g1.dtype == torch.float32 and _c_block_ok(x, kmap3, kmap1, w1.shape[1], w1.shape[2], be)
+        # MinkowskiSyncBatchNorm blocks (N > 1): the same node, its norms exchange their statistics through the process group
+        # (ddp.sync_bn_forward / sync_bn_backward, the functions the module itself runs) -- call by call, the engine's one-call
+        # path has no collectives inside
+        sync = ctx.sync = _sync_group(blk.norm1)
+        ctx.c_path = (not sync[0]) and g1.dtype == torch.float32 and _c_block_ok(x, kmap3, kmap1, w1.shape[1], w1.shape[2], be)
         if ctx.c_path:
             # ONE engine call for the whole block (same launches, same order: bit-identical to the sequence below)
             ctx.has_ds = wd is not None
@@ -190,7 +225,7 @@ class _BasicBlockFunction(torch.autograd.Function):
         want = bool(getattr(be, "conv_bn_stats", False)) and be.want_conv_bn_stats(x.shape[0], w1.shape[-1], x.element_size())
         o1, s1 = kmap3.conv_forward(x, w1, None, False, bn_pivot=n1.running_mean, want_bn_stats=True, pack_cache=pc1) if want else \
             (kmap3.conv_forward(x, w1, None, False, pack_cache=pc1), None)
-        y1, st1 = _bn_fwd(be, o1, n1, g1, b1, None, True, s1)
+        y1, st1, inv1 = _bn_fwd(be, o1, n1, g1, b1, None, True, s1, sync)
         o2, s2 = kmap3.conv_forward(y1, w2, None, False, bn_pivot=n2.running_mean, want_bn_stats=True, pack_cache=pc2) if want else \
             (kmap3.conv_forward(y1, w2, None, False, pack_cache=pc2), None)
         ctx.has_ds = wd is not None
@@ -199,17 +234,18 @@ class _BasicBlockFunction(torch.autograd.Function):
             pcd = blk.downsample[0]._cache_for(x)
             od, sd = kmap1.conv_forward(x, wd, None, False, bn_pivot=nd.running_mean, want_bn_stats=True, pack_cache=pcd) if want else \
                 (kmap1.conv_forward(x, wd, None, False, pack_cache=pcd), None)
-            res, std = _bn_fwd(be, od, nd, gd, bd, None, False, sd)
+            res, std, invd = _bn_fwd(be, od, nd, gd, bd, None, False, sd, sync)
         else:
-            res = x
+            res, invd = x, None
         relu = bool(blk.final_relu)
-        y2, st2 = _bn_fwd(be, o2, n2, g2, b2, res, relu, s2)
+        y2, st2, inv2 = _bn_fwd(be, o2, n2, g2, b2, res, relu, s2, sync)
         ctx.kmap3, ctx.kmap1, ctx.relu, ctx.pc = kmap3, kmap1, relu, (pc1, pc2, pcd if ctx.has_ds else None)
         ctx.params = tuple(t if isinstance(t, nn.Parameter) else None for t in (w1, g1, b1, w2, g2, b2, wd, gd, bd))
+        inv = ((inv1, inv2, invd) if ctx.has_ds else (inv1, inv2)) if sync[0] else ()
         if ctx.has_ds:
-            ctx.save_for_backward(x, w1, g1, b1, w2, g2, b2, o1, st1, y1, o2, st2, y2, wd, gd, bd, od, std)
+            ctx.save_for_backward(x, w1, g1, b1, w2, g2, b2, o1, st1, y1, o2, st2, y2, wd, gd, bd, od, std, *inv)
         else:
-            ctx.save_for_backward(x, w1, g1, b1, w2, g2, b2, o1, st1, y1, o2, st2, y2)
+            ctx.save_for_backward(x, w1, g1, b1, w2, g2, b2, o1, st1, y1, o2, st2, y2, *inv)
         return y2
 
     @staticmethod
@@ -223,19 +259,22 @@ class _BasicBlockFunction(torch.autograd.Function):
         pw1, pg1, pb1, pw2, pg2, pb2, pwd, pgd, pbd = ctx.params
         # inputs: 0 x | 1 blk 2 kmap3 3 kmap1 | 4 w1 5 g1 6 b1 | 7 w2 8 g2 9 b2 | 10 wd 11 gd 12 bd
         if ctx.c_path and all(need[i] for i in (4, 5, 6, 7, 8, 9)) and (not ctx.has_ds or all(need[i] for i in (10, 11, 12))):
-            extra = sv[13:] if ctx.has_ds else (None, None, None, None, None)
+            extra = sv[13:18] if ctx.has_ds else (None, None, None, None, None)
             return be.block_backward(dy, sv[:13], extra, kmap3, ctx.kmap1, ctx.pc, ctx.params, ctx.relu, bool(need[0]))
+        sync = ctx.sync
+        n_base = 18 if ctx.has_ds else 13
+        inv1, inv2, invd = (tuple(sv[n_base:]) + (None,))[:3] if sync[0] else (None, None, None)
         # norm2 (+ residual) (+ ReLU): mask from the saved output when there is a ReLU (a residual was added)
         dx2, dres, dg2, db2 = _bn_bwd(be, o2, y2 if ctx.relu else None, dy, g2, b2, pg2, pb2, st2, 1 if ctx.relu else 0, True,
-                                      need[8] or need[9])
+                                      need[8] or need[9], sync, inv2)
         gw2 = conv_weight_grad(kmap3, y1, dx2, False, pw2, w2.shape, w2.dtype) if need[7] else None
         dy1 = kmap3.conv_dgrad(dx2, w2, False, pack_cache=pc2)
-        dx1, _, dg1, db1 = _bn_bwd(be, o1, None, dy1, g1, b1, pg1, pb1, st1, 2, False, need[5] or need[6])
+        dx1, _, dg1, db1 = _bn_bwd(be, o1, None, dy1, g1, b1, pg1, pb1, st1, 2, False, need[5] or need[6], sync, inv1)
         gw1 = conv_weight_grad(kmap3, x, dx1, False, pw1, w1.shape, w1.dtype) if need[4] else None
         gin = None
         if ctx.has_ds:
-            wd, gd, bd, od, std = sv[13:]
-            dxd, _, dgd, dbd = _bn_bwd(be, od, None, dres, gd, bd, pgd, pbd, std, 0, False, need[11] or need[12])
+            wd, gd, bd, od, std = sv[13:18]
+            dxd, _, dgd, dbd = _bn_bwd(be, od, None, dres, gd, bd, pgd, pbd, std, 0, False, need[11] or need[12], sync, invd)
             gwd = conv_weight_grad(ctx.kmap1, x, dxd, False, pwd, wd.shape, wd.dtype) if need[10] else None
             if need[0]:
                 gin = kmap3.conv_dgrad(dx1, w1, False, pack_cache=pc1,

@@ -24,6 +24,8 @@ HOST_KNOBS = {
                                   "e.g. the 1x1 512->544 dgrad 1.37 instead of 11.6 ms, but the step is the sum of its kernels either way)"),
     "CONV_BN_STATS": ("", str, "'1' / 'big' = BatchNorm statistics from the conv epilogue (measured slower: 31.5 vs 30.9 ms; off)"),
     "DBG_WGRAD": ("", str, "'skip' / 'inline': step-time attribution experiments only ('skip' produces no weight gradients)"),
+    "SYNCBN_ENGINE_COMM": (1, int, "1 = MinkowskiSyncBatchNorm's collectives are issued by the engine on its own RCCL communicator, on the "
+                                   "compute stream (csrc/lgs_comm.hip); 0 = torch.distributed collectives between the split kernels"),
     "SET_HW_QUEUES": (0, int, "1 = importing the package sets GPU_MAX_HW_QUEUES=8 before the HIP runtime starts (see configure_hw_queues)"),
 }
 

@@ -77,11 +77,54 @@ def _worker(rank, port, ret):
         c = build(True)
         dc = BucketedDDP(c, bucket_mb=1.0, force_collectives=True)
         _, _, gc_ = _step(c, dc, FlatSGD(dc, lr=1e-3), coords, f32, dev)
+        # (3) the whole-block autograd node with SyncBN inside (models._BasicBlockFunction calling ddp.sync_bn_forward /
+        # sync_bn_backward) against the module-by-module path: same kernels, same collectives, same order -> bit-identical
+        from languagegroundedsemseg_amd import models as _models
+        calls = {"n": 0}
+        orig_apply = _models._BasicBlockFunction.apply
+
+        def counting_apply(*a, **k):
+            calls["n"] += 1
+            return orig_apply(*a, **k)
+        _models._BasicBlockFunction.apply = counting_apply
+        try:
+            h = build(True)
+            dh = BucketedDDP(h, bucket_mb=1.0, force_collectives=True)
+            gh, ph, _ = _step(h, dh, FlatSGD(dh, lr=1e-3), coords, feats, dev)
+            node_calls = calls["n"]
+            _models._BLOCK_FUSED = False
+            i = build(True)
+            di = BucketedDDP(i, bucket_mb=1.0, force_collectives=True)
+            gi, pi, _ = _step(i, di, FlatSGD(di, lr=1e-3), coords, feats, dev)
+        finally:
+            _models._BLOCK_FUSED = True
+            _models._BasicBlockFunction.apply = orig_apply
+        same_blk = (node_calls > 0 and calls["n"] == node_calls and set(gh) == set(gi) and all(torch.equal(gh[k], gi[k]) for k in gi)
+                    and all(torch.equal(ph[k], pi[k]) for k in pi)
+                    and all(torch.equal(a_.detach().cpu(), b_.detach().cpu()) for (_, a_), (_, b_) in zip(h.named_buffers(), i.named_buffers())))
+        # (4) the collectives of (2) and (3) were issued by the ENGINE on its own RCCL communicator (one call per layer and
+        # direction, csrc/lgs_comm.hip); the same step with torch.distributed's collectives between the split kernels: bit-identical
+        from languagegroundedsemseg_amd.ddp import EngineComm
+        used_engine_comm = any(v is not None for v in EngineComm._by_group.values())
+        EngineComm.close_all()
+        os.environ["LGS_SYNCBN_ENGINE_COMM"] = "0"
+        try:
+            j = build(True)
+            dj = BucketedDDP(j, bucket_mb=1.0, force_collectives=True)
+            gj, pj, _ = _step(j, dj, FlatSGD(dj, lr=1e-3), coords, feats, dev)
+            torch_path = all(v is None for v in EngineComm._by_group.values())
+        finally:
+            del os.environ["LGS_SYNCBN_ENGINE_COMM"]
+            EngineComm._by_group.clear()
+        same_comm = (used_engine_comm and torch_path and set(gj) == set(gh) and all(torch.equal(gj[k], gh[k]) for k in gh)
+                     and all(torch.equal(pj[k], ph[k]) for k in ph))
         ME.MinkowskiSyncBatchNorm.force_sync = False
         worst = max(float((gc_[k] - gd[k]).norm() / gd[k].norm().clamp_min(1e-12)) for k in gd)
         rm = float((c.bn0.bn.running_mean - d.bn0.bn.running_mean).abs().max())
-        ret["out"] = (same, worst, rm, int(c.bn0.bn.num_batches_tracked), same_rs)
+        ret["out"] = (same, worst, rm, int(c.bn0.bn.num_batches_tracked), same_rs, same_blk, node_calls, same_comm)
     finally:
+        from languagegroundedsemseg_amd.ddp import EngineComm as _EC
+        _EC.close_all()
         dist.destroy_process_group()
 
 
@@ -89,7 +132,9 @@ def test_rccl_collective_paths_with_one_rank_reproduce_the_local_step():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(_free_port(), ret), nprocs=1, join=True)
-    same, worst, rm, nbt, same_rs = ret["out"]
+    same, worst, rm, nbt, same_rs, same_blk, node_calls, same_comm = ret["out"]
+    assert same_comm, "SyncBN through the engine's RCCL communicator must equal SyncBN through torch.distributed's collectives bit for bit"
+    assert same_blk, "SyncBN blocks as ONE autograd node (%d node calls) must equal the module-by-module SyncBN path bit for bit" % node_calls
     assert same, "RCCL all_reduce of the gradient buckets (world 1) must leave the step bit-identical"
     assert same_rs, "RCCL in-place reduce_scatter_tensor + all_gather_into_tensor of the buckets (world 1) must leave the step bit-identical"
     print("SyncBN over RCCL (world 1) vs local BatchNorm: worst gradient rel-L2 %.3e, running_mean diff %.3e" % (worst, rm))
