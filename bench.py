@@ -552,6 +552,14 @@ def secondary_block(workload, model_name, dtype, coords, feats, labels, device, 
     return out
 
 
+def _syncbn_issuer():
+    from languagegroundedsemseg_amd.ddp import EngineComm
+    if not EngineComm._by_group:
+        return None
+    return ("the engine, on its own RCCL communicator and the compute stream (csrc/lgs_comm.hip)"
+            if any(v is not None for v in EngineComm._by_group.values()) else "torch.distributed between the engine's split kernels")
+
+
 def dp_path_block(coords, feats, labels, device, args, dtype, steps=8, warmup=3):
     """The code path every rank runs at N > 1 -- MinkowskiSyncBatchNorm (statistics / combine / apply as separate kernels around an
     all-gather and an all-reduce per layer) and bucketed gradient all-reduces from the backward hooks -- timed on THIS one GPU with
@@ -579,7 +587,8 @@ def dp_path_block(coords, feats, labels, device, args, dtype, steps=8, warmup=3)
                        "gradient all-reduce) on one GPU with RCCL and a world of ONE rank: every collective is a real RCCL launch, "
                        "only the wire time is missing",
                "ms_per_step": res["dt"] / steps * 1e3, "value": n_vox * steps / res["dt"], "unit": "voxels/s", "steps": steps,
-               "phases": res["phases"], "ddp": ddp.timing_summary(steps), "backend": dist.get_backend(), "allreduce": args.allreduce}
+               "phases": res["phases"], "ddp": ddp.timing_summary(steps), "backend": dist.get_backend(), "allreduce": args.allreduce,
+               "syncbn_collectives_issued_by": _syncbn_issuer()}
         del model, ddp, opt, res
     finally:
         ME.MinkowskiSyncBatchNorm.force_sync = prev
@@ -789,7 +798,8 @@ def main():
                          "backend": dist.get_backend() if world > 1 else None,
                          "self_launched": os.environ.get("LGS_BENCH_SELF_LAUNCHED") == "1",
                          "bucket_collectives_per_step": mine["ddp"]["bucket_collectives_per_step"] if mine["ddp"] else None,
-                         "syncbn_collectives_per_step": mine["ddp"]["syncbn_collectives_per_step"] if mine["ddp"] else None}
+                         "syncbn_collectives_per_step": mine["ddp"]["syncbn_collectives_per_step"] if mine["ddp"] else None,
+                         "syncbn_collectives_issued_by": _syncbn_issuer()}
 
     if clog is not None and res["disc"] is not None:
         out["roofline"] = roofline_report(clog, res["disc"], args.dtype, args.workload, args.steps, ms_per_step, n_vox,

@@ -222,19 +222,22 @@ int lgs_bn_backward(const void *x, const void *y, const void *dy, int64_t dy_row
  *                             vectors also go to dgamma / dbeta (may be NULL): parameter gradients stay local
  *   (all-reduce of sums)
  *   lgs_bn_backward_apply  <- sums[2C] (all-reduced), 1/N either by value (inv_n_total) or, if inv_n_device != NULL,
- *                             read from the device scalar lgs_bn_sync_combine wrote (no host sync) */
+ *                             read from the device scalar lgs_bn_sync_combine wrote (no host sync)
+ * y_row_stride / dy_row_stride (elements, 0 = c): y / dy may be column slices of wider row-major buffers (zero-copy ME.cat: the
+ * norm writes into, and its backward reads from, the concat buffer), rows 16-byte aligned. */
 int lgs_bn_stats(const void *x, int64_t n, int c, float *rec /* [2C+1] */, int dtype, void *workspace,
                  const float *conv_partials, int conv_partial_rows, const float *pivot, void *stream);
 int lgs_bn_sync_combine(const float *all_stats, int world, int c, float eps, float momentum, float *running_mean,
                         float *running_var, int64_t *num_batches_tracked, float *stats, float *inv_n_total, void *stream);
 int lgs_bn_apply(const void *x, int64_t n, int c, const float *gamma, const float *beta, const float *stats,
-                 const void *residual, int relu, void *y, int dtype, void *stream);
+                 const void *residual, int relu, void *y, int dtype, int64_t y_row_stride, void *stream);
 int lgs_bn_backward_reduce(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
                            const float *beta, const float *stats, int relu, float *sums, float *dgamma, float *dbeta,
-                           int dtype, void *workspace, void *stream);
+                           int dtype, void *workspace, int64_t dy_row_stride, int64_t y_row_stride, void *stream);
 int lgs_bn_backward_apply(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
                           const float *beta, const float *stats, const float *sums, float inv_n_total,
-                          const float *inv_n_device, int relu, void *dx, void *dresidual, int dtype, void *stream);
+                          const float *inv_n_device, int relu, void *dx, void *dresidual, int dtype, int64_t dy_row_stride,
+                          int64_t y_row_stride, void *stream);
 
 /* ---- SyncBatchNorm as one call per direction, on the engine's own RCCL communicator (csrc/lgs_comm.hip) --------
  * replaces the per-layer statistics exchange of ME.MinkowskiSyncBatchNorm (convert_sync_batchnorm, /root/reference/main.py:121-123;
@@ -256,10 +259,11 @@ int64_t lgs_bn_sync_workspace_bytes(int64_t n, int c, int world);
 int lgs_bn_forward_sync(lgs_comm *comm, const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps,
                         float momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked,
                         const void *residual, int relu, void *y, float *stats, float *inv_n, int dtype, void *workspace,
-                        void *stream);
+                        int64_t y_row_stride, void *stream);
 int lgs_bn_backward_sync(lgs_comm *comm, const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
                          const float *beta, const float *stats, const float *inv_n, int relu, void *dx, void *dresidual,
-                         float *dgamma, float *dbeta, int dtype, void *workspace, void *stream);
+                         float *dgamma, float *dbeta, int dtype, void *workspace, int64_t dy_row_stride, int64_t y_row_stride,
+                         void *stream);
 
 /* ---- one call per residual block and direction (csrc/lgs_block.hip) -----------------------------
  * replaces the call sequence of BasicBlock.forward and of its autograd backward

@@ -124,7 +124,7 @@ int64_t lgs_bn_sync_workspace_bytes(int64_t n, int c, int world) {
 // (+ residual) (+ ReLU); stats [2C] and inv_n [1] (device: 1 / global rows) are what the backward needs
 int lgs_bn_forward_sync(lgs_comm *comm, const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps,
                         float momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked, const void *residual,
-                        int relu, void *y, float *stats, float *inv_n, int dtype, void *workspace, void *stream) {
+                        int relu, void *y, float *stats, float *inv_n, int dtype, void *workspace, int64_t y_row_stride, void *stream) {
   LGS_REQUIRE(comm && comm->comm && x && y && gamma && beta && stats && inv_n && workspace, "lgs_bn_forward_sync: null argument");
   char *ws = reinterpret_cast<char *>(workspace);
   float *local = reinterpret_cast<float *>(ws + align256(lgs_bn_workspace_bytes(n, c)));
@@ -134,20 +134,22 @@ int lgs_bn_forward_sync(lgs_comm *comm, const void *x, int64_t n, int c, const f
   LGS_NCCL(rccl().AllGather(local, all, (size_t)(2 * c + 1), kNcclFloat32, comm->comm, (hipStream_t)stream));
   if ((rc = lgs_bn_sync_combine(all, comm->world, c, eps, momentum, running_mean, running_var, num_batches_tracked, stats, inv_n, stream)))
     return rc;
-  return lgs_bn_apply(x, n, c, gamma, beta, stats, residual, relu, y, dtype, stream);
+  return lgs_bn_apply(x, n, c, gamma, beta, stats, residual, relu, y, dtype, y_row_stride, stream);
 }
 
 // backward: local [sum dy' | sum dy' xhat] (also the parameter gradients, which stay local) -> all-reduce -> apply
 int lgs_bn_backward_sync(lgs_comm *comm, const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
                          const float *beta, const float *stats, const float *inv_n, int relu, void *dx, void *dresidual, float *dgamma,
-                         float *dbeta, int dtype, void *workspace, void *stream) {
+                         float *dbeta, int dtype, void *workspace, int64_t dy_row_stride, int64_t y_row_stride, void *stream) {
   LGS_REQUIRE(comm && comm->comm && x && dy && dx && gamma && stats && inv_n && workspace, "lgs_bn_backward_sync: null argument");
   char *ws = reinterpret_cast<char *>(workspace);
   float *sums = reinterpret_cast<float *>(ws + align256(lgs_bn_workspace_bytes(n, c)) + align256((int64_t)(comm->world + 1) * (2 * c + 1) * 4));
   int rc;
-  if ((rc = lgs_bn_backward_reduce(x, y, dy, n, c, gamma, beta, stats, relu, sums, dgamma, dbeta, dtype, workspace, stream))) return rc;
+  if ((rc = lgs_bn_backward_reduce(x, y, dy, n, c, gamma, beta, stats, relu, sums, dgamma, dbeta, dtype, workspace, dy_row_stride, y_row_stride,
+                                   stream)))
+    return rc;
   LGS_NCCL(rccl().AllReduce(sums, sums, (size_t)(2 * c), kNcclFloat32, kNcclSum, comm->comm, (hipStream_t)stream));
-  return lgs_bn_backward_apply(x, y, dy, n, c, gamma, beta, stats, sums, 0.f, inv_n, relu, dx, dresidual, dtype, stream);
+  return lgs_bn_backward_apply(x, y, dy, n, c, gamma, beta, stats, sums, 0.f, inv_n, relu, dx, dresidual, dtype, dy_row_stride, y_row_stride, stream);
 }
 
 }  // extern "C"

@@ -868,21 +868,22 @@ int bn_stats_t(const void *xv, int64_t n, int c, float *mean_m2, void *workspace
 }
 template <typename T>
 int bn_apply_t(const void *xv, int64_t n, int c, const float *gamma, const float *beta, const float *stats, const void *res,
-               int relu, void *yv, hipStream_t s) {
+               int relu, void *yv, hipStream_t s, int64_t y_ld) {
   constexpr int W = Vec<T>::W;
   LGS_REQUIRE(c % W == 0 && c / W <= kNT, "lgs_bn_apply: channel count unsupported");
   int64_t total = n * (int64_t)(c / W);
   if (total > 0) {
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
     LGS_KLAUNCH((k_bn_apply<T>), grid, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(res), n, c,
-                       gamma, beta, stats, relu, reinterpret_cast<T *>(yv), (int64_t)c);
+                       gamma, beta, stats, relu, reinterpret_cast<T *>(yv), y_ld);
   }
   LGS_HIP(hipGetLastError());
   return 0;
 }
 template <typename T>
 int bn_bwd_reduce_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *gamma, const float *beta,
-                    const float *stats, int relu, float *sums, float *dgamma, float *dbeta, void *workspace, hipStream_t s) {
+                    const float *stats, int relu, float *sums, float *dgamma, float *dbeta, void *workspace, hipStream_t s,
+                    int64_t dy_ld, int64_t y_ld) {
   constexpr int W = Vec<T>::W;
   LGS_REQUIRE(c % W == 0 && c / W <= kNT && c <= 2048, "lgs_bn_backward_reduce: channel count unsupported");
   int64_t rpb;
@@ -890,7 +891,7 @@ int bn_bwd_reduce_t(const void *xv, const void *yv, const void *dyv, int64_t n, 
   float *scratch = reinterpret_cast<float *>(workspace);
   float *tmp = scratch + (size_t)2 * c * nb;  // dgamma/dbeta land here when the caller does not want them
   LGS_KLAUNCH((k_colreduce<T, 1>), nb, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
-                     reinterpret_cast<const T *>(dyv), stats, gamma, beta, n, c, relu, rpb, scratch, (int64_t)c, (int64_t)c);
+                     reinterpret_cast<const T *>(dyv), stats, gamma, beta, n, c, relu, rpb, scratch, dy_ld, y_ld);
   LGS_KLAUNCH(k_fold_bwd, (c + kFoldCh - 1) / kFoldCh, 256, 0, s, scratch, nb, c, dgamma ? dgamma : tmp + c, dbeta ? dbeta : tmp, sums);
   LGS_HIP(hipGetLastError());
   return 0;
@@ -898,7 +899,7 @@ int bn_bwd_reduce_t(const void *xv, const void *yv, const void *dyv, int64_t n, 
 template <typename T>
 int bn_bwd_apply_t(const void *xv, const void *yv, const void *dyv, int64_t n, int c, const float *gamma, const float *beta,
                    const float *stats, const float *sums, float inv_n_total, const float *inv_n_dev, int relu, void *dxv, void *dresv,
-                   hipStream_t s) {
+                   hipStream_t s, int64_t dy_ld, int64_t y_ld) {
   constexpr int W = Vec<T>::W;
   LGS_REQUIRE(c % W == 0 && c / W <= kNT, "lgs_bn_backward_apply: channel count unsupported");
   int64_t total = n * (int64_t)(c / W);
@@ -906,10 +907,15 @@ int bn_bwd_apply_t(const void *xv, const void *yv, const void *dyv, int64_t n, i
     int grid = (int)((total + kNT - 1) / kNT < 4096 ? (total + kNT - 1) / kNT : 4096);
     LGS_KLAUNCH((k_bn_bwd_apply<T>), grid, kNT, 0, s, reinterpret_cast<const T *>(xv), reinterpret_cast<const T *>(yv),
                        reinterpret_cast<const T *>(dyv), n, c, gamma, beta, stats, sums, inv_n_total, relu, reinterpret_cast<T *>(dxv),
-                       reinterpret_cast<T *>(dresv), (int64_t)c, inv_n_dev, (int64_t)c);
+                       reinterpret_cast<T *>(dresv), dy_ld, inv_n_dev, y_ld);
   }
   LGS_HIP(hipGetLastError());
   return 0;
+}
+
+// row stride of a [n, c] operand that may be a column slice of a wider row-major buffer: 0 = c; rows must start 16-byte aligned
+inline bool stride_ok(const void *p, int64_t ld, int c, int dtype) {
+  return ld >= c && ld % (dtype == LGS_BF16 ? 8 : 4) == 0 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
 }
 
 }  // namespace lgs
@@ -926,10 +932,12 @@ int lgs_bn_stats(const void *x, int64_t n, int c, float *mean_m2, int dtype, voi
   LGS_REQUIRE(false, "lgs_bn_stats: unknown dtype");
 }
 int lgs_bn_apply(const void *x, int64_t n, int c, const float *gamma, const float *beta, const float *stats,
-                 const void *residual, int relu, void *y, int dtype, void *stream) {
+                 const void *residual, int relu, void *y, int dtype, int64_t y_row_stride, void *stream) {
   LGS_REQUIRE(x && y && gamma && beta && stats, "lgs_bn_apply: null argument");
-  if (dtype == LGS_F32) return bn_apply_t<float>(x, n, c, gamma, beta, stats, residual, relu, y, (hipStream_t)stream);
-  if (dtype == LGS_BF16) return bn_apply_t<bf16_t>(x, n, c, gamma, beta, stats, residual, relu, y, (hipStream_t)stream);
+  const int64_t y_ld = y_row_stride > 0 ? y_row_stride : c;
+  LGS_REQUIRE(stride_ok(y, y_ld, c, dtype), "lgs_bn_apply: y rows must start 16-byte aligned (row stride a multiple of 16 bytes)");
+  if (dtype == LGS_F32) return bn_apply_t<float>(x, n, c, gamma, beta, stats, residual, relu, y, (hipStream_t)stream, y_ld);
+  if (dtype == LGS_BF16) return bn_apply_t<bf16_t>(x, n, c, gamma, beta, stats, residual, relu, y, (hipStream_t)stream, y_ld);
   LGS_REQUIRE(false, "lgs_bn_apply: unknown dtype");
 }
 int lgs_bn_sync_combine(const float *all_stats, int world, int c, float eps, float momentum, float *running_mean,
@@ -942,22 +950,29 @@ int lgs_bn_sync_combine(const float *all_stats, int world, int c, float eps, flo
 }
 int lgs_bn_backward_reduce(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
                            const float *beta, const float *stats, int relu, float *sums, float *dgamma, float *dbeta, int dtype,
-                           void *workspace, void *stream) {
+                           void *workspace, int64_t dy_row_stride, int64_t y_row_stride, void *stream) {
   LGS_REQUIRE(x && dy && stats && sums && workspace, "lgs_bn_backward_reduce: null argument");
+  const int64_t dy_ld = dy_row_stride > 0 ? dy_row_stride : c, y_ld = y_row_stride > 0 ? y_row_stride : c;
+  LGS_REQUIRE(stride_ok(dy, dy_ld, c, dtype) && (!y || stride_ok(y, y_ld, c, dtype)),
+              "lgs_bn_backward_reduce: dy / y rows must start 16-byte aligned (row stride a multiple of 16 bytes)");
   LGS_REQUIRE(relu != 1 || y, "lgs_bn_backward_reduce: relu mode 1 needs the forward output");
   LGS_REQUIRE(relu != 2 || (gamma && beta), "lgs_bn_backward_reduce: relu mode 2 needs gamma and beta");
-  if (dtype == LGS_F32) return bn_bwd_reduce_t<float>(x, y, dy, n, c, gamma, beta, stats, relu, sums, dgamma, dbeta, workspace, (hipStream_t)stream);
-  if (dtype == LGS_BF16) return bn_bwd_reduce_t<bf16_t>(x, y, dy, n, c, gamma, beta, stats, relu, sums, dgamma, dbeta, workspace, (hipStream_t)stream);
+  if (dtype == LGS_F32) return bn_bwd_reduce_t<float>(x, y, dy, n, c, gamma, beta, stats, relu, sums, dgamma, dbeta, workspace, (hipStream_t)stream, dy_ld, y_ld);
+  if (dtype == LGS_BF16) return bn_bwd_reduce_t<bf16_t>(x, y, dy, n, c, gamma, beta, stats, relu, sums, dgamma, dbeta, workspace, (hipStream_t)stream, dy_ld, y_ld);
   LGS_REQUIRE(false, "lgs_bn_backward_reduce: unknown dtype");
 }
 int lgs_bn_backward_apply(const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
                           const float *beta, const float *stats, const float *sums, float inv_n_total,
-                          const float *inv_n_device, int relu, void *dx, void *dresidual, int dtype, void *stream) {
+                          const float *inv_n_device, int relu, void *dx, void *dresidual, int dtype, int64_t dy_row_stride,
+                          int64_t y_row_stride, void *stream) {
   LGS_REQUIRE(x && dy && dx && gamma && stats && sums, "lgs_bn_backward_apply: null argument");
+  const int64_t dy_ld = dy_row_stride > 0 ? dy_row_stride : c, y_ld = y_row_stride > 0 ? y_row_stride : c;
+  LGS_REQUIRE(stride_ok(dy, dy_ld, c, dtype) && (!y || stride_ok(y, y_ld, c, dtype)),
+              "lgs_bn_backward_apply: dy / y rows must start 16-byte aligned (row stride a multiple of 16 bytes)");
   LGS_REQUIRE(relu != 1 || y, "lgs_bn_backward_apply: relu mode 1 needs the forward output");
   LGS_REQUIRE(relu != 2 || beta, "lgs_bn_backward_apply: relu mode 2 needs beta");
-  if (dtype == LGS_F32) return bn_bwd_apply_t<float>(x, y, dy, n, c, gamma, beta, stats, sums, inv_n_total, inv_n_device, relu, dx, dresidual, (hipStream_t)stream);
-  if (dtype == LGS_BF16) return bn_bwd_apply_t<bf16_t>(x, y, dy, n, c, gamma, beta, stats, sums, inv_n_total, inv_n_device, relu, dx, dresidual, (hipStream_t)stream);
+  if (dtype == LGS_F32) return bn_bwd_apply_t<float>(x, y, dy, n, c, gamma, beta, stats, sums, inv_n_total, inv_n_device, relu, dx, dresidual, (hipStream_t)stream, dy_ld, y_ld);
+  if (dtype == LGS_BF16) return bn_bwd_apply_t<bf16_t>(x, y, dy, n, c, gamma, beta, stats, sums, inv_n_total, inv_n_device, relu, dx, dresidual, (hipStream_t)stream, dy_ld, y_ld);
   LGS_REQUIRE(false, "lgs_bn_backward_apply: unknown dtype");
 }
 

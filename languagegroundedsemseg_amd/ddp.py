@@ -451,7 +451,8 @@ class EngineComm:
         cls._by_group.clear()
 
 
-def sync_bn_forward(backend, x, weight, bias, residual, running_mean, running_var, nbt, eps, momentum, relu, group, conv_stats=None):
+def sync_bn_forward(backend, x, weight, bias, residual, running_mean, running_var, nbt, eps, momentum, relu, group, conv_stats=None,
+                    out_into=None):
     """SyncBN forward on the engine's split kernels: local (mean, M2, count) -> ONE all_gather of 2C+1 floats per rank -> Chan's
     parallel combination (+ running statistics) -> fused normalise (+residual) (+ReLU).  -> y, stats [2C], inv_n [1] (device)"""
     c = x.shape[1]
@@ -460,7 +461,7 @@ def sync_bn_forward(backend, x, weight, bias, residual, running_mean, running_va
     if comm is not None:        # ONE engine call: statistics -> ncclAllGather -> combine -> apply, all on the compute stream
         if _TIMING["on"]:
             _SYNCBN_EVENTS.append(None)
-        return backend.bn_forward_sync(comm, x, weight, bias, eps, momentum, running_mean, running_var, nbt, residual, relu)
+        return backend.bn_forward_sync(comm, x, weight, bias, eps, momentum, running_mean, running_var, nbt, residual, relu, out_into)
     # [mean | M2 | count], 2 kernels; the partial sums come from the producing conv's epilogue when it made them
     local = backend.bn_stats(x, conv_stats) if conv_stats is not None else backend.bn_stats(x)
     allst = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=x.device)
@@ -470,7 +471,8 @@ def sync_bn_forward(backend, x, weight, bias, residual, running_mean, running_va
         _timed_collective(lambda: dist.all_gather(list(allst.unbind(0)), local, group=group), x.is_cuda)
     # one kernel: Chan's combination, running statistics, num_batches_tracked, 1/N (device scalar)
     stats, inv_n = backend.bn_sync_combine(allst, c, eps, momentum, running_mean, running_var, nbt)
-    y = backend.bn_apply(x, weight, bias, stats, residual, relu)
+    y = backend.bn_apply(x, weight, bias, stats, residual, relu, out_into) if out_into is not None else \
+        backend.bn_apply(x, weight, bias, stats, residual, relu)
     return y, stats, inv_n
 
 
@@ -505,9 +507,11 @@ class _SyncBNFused(torch.autograd.Function):
     same two functions)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, nbt, eps, momentum, relu, group, backend, conv_stats=None):
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, nbt, eps, momentum, relu, group, backend, conv_stats=None,
+                out_into=None):
+        # out_into (_CatSlot): y goes straight into a column slice of the concat buffer (zero-copy ME.cat; not a tensor input)
         y, stats, inv_n = sync_bn_forward(backend, x, weight, bias, residual, running_mean, running_var, nbt, eps, momentum, relu,
-                                          group, conv_stats)
+                                          group, conv_stats, (out_into.buf, out_into.off) if out_into is not None else None)
         ctx.backend, ctx.group, ctx.has_res = backend, group, residual is not None
         ctx.relu_mode = 0 if not relu else (1 if residual is not None else 2)
         ctx.gparam = weight if isinstance(weight, torch.nn.Parameter) else None
@@ -518,16 +522,15 @@ class _SyncBNFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight, bias, stats, y, inv_n = ctx.saved_tensors
-        dy = dy.contiguous()
-        yy = y if ctx.relu_mode == 1 else None
+        yy = y if ctx.relu_mode == 1 else None      # (dy / y may be column slices of a concat buffer: the engine reads them in place)
         dx, dres, dgamma, dbeta, slots = sync_bn_backward(ctx.backend, x, yy, dy, weight, bias, stats, inv_n, ctx.relu_mode,
                                                           ctx.has_res and ctx.needs_input_grad[3], ctx.group, ctx.gparam, ctx.bparam)
         if slots:
-            return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
-        return dx, dgamma.to(weight.dtype), dbeta.to(weight.dtype), dres, None, None, None, None, None, None, None, None, None
+            return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma.to(weight.dtype), dbeta.to(weight.dtype), dres, None, None, None, None, None, None, None, None, None, None
 
 
-def sync_batch_norm(x, bn, group=None, residual=None, relu=False, conv_stats=None):
+def sync_batch_norm(x, bn, group=None, residual=None, relu=False, conv_stats=None, out_into=None):
     """Batch statistics over the rows of all ranks.  Device tensors run on the engine's fused kernels; the pure
     torch formulation below is only reachable with CPU tensors (the gloo host-logic tests)."""
     rm = bn.running_mean if bn.track_running_stats else None
@@ -537,7 +540,8 @@ def sync_batch_norm(x, bn, group=None, residual=None, relu=False, conv_stats=Non
         from .me.core import get_backend
         if conv_stats is not None and (conv_stats[1] is not None) != (rm is not None):
             conv_stats = None
-        return _SyncBNFused.apply(x, bn.weight, bn.bias, residual, rm, rv, nbt, bn.eps, bn.momentum, relu, group, get_backend(), conv_stats)
+        return _SyncBNFused.apply(x, bn.weight, bn.bias, residual, rm, rv, nbt, bn.eps, bn.momentum, relu, group, get_backend(), conv_stats,
+                                  out_into)
     if nbt is not None:
         nbt += 1
     y = _SyncBNFunction.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, group)

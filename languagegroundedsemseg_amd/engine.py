@@ -153,10 +153,10 @@ def lib():
         "lgs_bn_forward": [vp, i64, ci, vp, vp, cf, cf, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, vp, i64, vp],
         "lgs_bn_backward": [vp, vp, vp, i64, i64, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, i64, vp],
         "lgs_bn_stats": [vp, i64, ci, vp, ci, vp, vp, ci, vp, vp],
-        "lgs_bn_apply": [vp, i64, ci, vp, vp, vp, vp, ci, vp, ci, vp],
-        "lgs_bn_backward_reduce": [vp, vp, vp, i64, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp],
+        "lgs_bn_apply": [vp, i64, ci, vp, vp, vp, vp, ci, vp, ci, i64, vp],
+        "lgs_bn_backward_reduce": [vp, vp, vp, i64, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, i64, i64, vp],
         "lgs_bn_sync_combine": [vp, ci, ci, cf, cf, vp, vp, vp, vp, vp, vp],
-        "lgs_bn_backward_apply": [vp, vp, vp, i64, ci, vp, vp, vp, vp, cf, vp, ci, vp, vp, ci, vp],
+        "lgs_bn_backward_apply": [vp, vp, vp, i64, ci, vp, vp, vp, vp, cf, vp, ci, vp, vp, ci, i64, i64, vp],
         "lgs_clip_similarity": [vp, i64, ci, vp, ci, vp, vp, ci, vp, vp],
         "lgs_ce_forward_backward": [vp, i64, ci, vp, i64, vp, vp, vp, ci, vp],
         "lgs_ce_count_valid": [vp, i64, ci, i64, vp, vp],
@@ -164,8 +164,8 @@ def lib():
         "lgs_comm_create": [vp, ci, ci, ci, ctypes.POINTER(vp)],
         "lgs_comm_destroy": [vp],
         "lgs_comm_world": [vp],
-        "lgs_bn_forward_sync": [vp, vp, i64, ci, vp, vp, cf, cf, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp],
-        "lgs_bn_backward_sync": [vp, vp, vp, vp, i64, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp],
+        "lgs_bn_forward_sync": [vp, vp, i64, ci, vp, vp, cf, cf, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, i64, vp],
+        "lgs_bn_backward_sync": [vp, vp, vp, vp, i64, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, i64, i64, vp],
         "lgs_clip_loss_forward": [vp, i64, ci, vp, ci, vp, vp, ci, i64, vp, vp, vp, vp, vp, vp, ci, vp, vp],
         "lgs_clip_loss_backward": [vp, i64, ci, vp, ci, vp, vp, ci, i64, vp, vp, vp, vp, vp, vp, ci, vp],
         "lgs_clip_loss_backward_anchors": [vp, i64, ci, ci, vp, vp, ci, i64, vp, vp, vp, vp, ci, vp, vp],

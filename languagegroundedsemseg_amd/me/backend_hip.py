@@ -765,31 +765,53 @@ class HipBackend:
         _written_by_engine(running_mean, running_var, num_batches_tracked)
         return stats, inv_n
 
-    def bn_apply(self, x, gamma, beta, stats, residual, relu):
+    def bn_apply(self, x, gamma, beta, stats, residual, relu, out_into=None):
         L = engine.lib()
         x = x.contiguous()
         n, c = x.shape
         with _dev(x.device):
-            y = torch.empty_like(x)
+            y, y_ld = self._y_out(x, out_into)
             res = residual.contiguous() if residual is not None else None
             engine.check(L.lgs_bn_apply(_ptr(x), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(res), int(relu), _ptr(y),
-                                        _dtype_code(x), _stream()))
+                                        _dtype_code(x), int(y_ld), _stream()))
         return y
 
     # ---- SyncBN as one call per direction on the engine's own RCCL communicator (csrc/lgs_comm.hip)
-    def bn_forward_sync(self, comm, x, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, residual, relu):
+    @staticmethod
+    def _y_out(x, out_into):
+        """-> (y, row stride for the engine): a fresh tensor, or the column slice of a concat buffer (zero-copy ME.cat)"""
+        if out_into is None:
+            return torch.empty_like(x), 0
+        buf, off = out_into
+        n, c = x.shape
+        y = buf[:, off:off + c]
+        assert buf.dtype == x.dtype and buf.shape[0] == n and (buf.stride(0) * x.element_size()) % 16 == 0 and y.data_ptr() % 16 == 0
+        return y, buf.stride(0)
+
+    @staticmethod
+    def _strided_in(t, c):
+        """-> (tensor, row stride for the engine) of a [n, c] operand read in place when it is an aligned column slice, else a copy"""
+        if t is None:
+            return None, 0
+        ld = _row_strided(t, c)
+        if ld is not None:
+            return t, ld
+        return t.contiguous(), 0
+
+    def bn_forward_sync(self, comm, x, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, residual, relu,
+                        out_into=None):
         """-> y, stats [2C], inv_n [1]"""
         L = engine.lib()
         x = x.contiguous()
         n, c = x.shape
         with _dev(x.device):
-            y = torch.empty_like(x)
+            y, y_ld = self._y_out(x, out_into)
             stats = torch.empty(2 * c + 1, dtype=torch.float32, device=x.device)      # [mean | invstd | 1 / global rows]
             res = residual.contiguous() if residual is not None else None
             ws = _ws(L.lgs_bn_sync_workspace_bytes(n, c, comm.world), x.device)
             engine.check(L.lgs_bn_forward_sync(comm.h, _ptr(x), n, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
                                                _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(res), int(relu),
-                                               _ptr(y), stats.data_ptr(), stats.data_ptr() + 8 * c, _dtype_code(x), _ptr(ws), _stream()))
+                                               _ptr(y), stats.data_ptr(), stats.data_ptr() + 8 * c, _dtype_code(x), _ptr(ws), int(y_ld), _stream()))
         _written_by_engine(running_mean, running_var, num_batches_tracked)
         return y, stats[:2 * c], stats[2 * c:]
 
@@ -797,24 +819,28 @@ class HipBackend:
         """-> dx, dres (dgamma_out / dbeta_out receive the LOCAL parameter gradients)"""
         L = engine.lib()
         n, c = x.shape
+        dy, dy_ld = self._strided_in(dy, c)
+        y, y_ld = self._strided_in(y, c)
         with _dev(x.device):
-            dx = torch.empty_like(x)
-            dres = torch.empty_like(x) if want_residual else None
+            dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+            dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_residual else None
             ws = _ws(L.lgs_bn_sync_workspace_bytes(n, c, comm.world), x.device)
             engine.check(L.lgs_bn_backward_sync(comm.h, _ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(inv_n),
                                                 int(relu), _ptr(dx), _ptr(dres), _ptr(dgamma_out), _ptr(dbeta_out), _dtype_code(x),
-                                                _ptr(ws), _stream()))
+                                                _ptr(ws), int(dy_ld), int(y_ld), _stream()))
         return dx, dres
 
     def bn_backward_reduce(self, x, y, dy, gamma, beta, stats, relu, dgamma_out=None, dbeta_out=None):
         """-> sums [2C] (local sum dy', sum dy' xhat); the same vectors are also written to dgamma_out / dbeta_out"""
         L = engine.lib()
         n, c = x.shape
+        dy, dy_ld = self._strided_in(dy, c)
+        y, y_ld = self._strided_in(y, c)
         with _dev(x.device):
             sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
             ws = _ws(_bn_ws_bytes(L, n, c), x.device)
             engine.check(L.lgs_bn_backward_reduce(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), int(relu), _ptr(sums),
-                                                  _ptr(dgamma_out), _ptr(dbeta_out), _dtype_code(x), _ptr(ws), _stream()))
+                                                  _ptr(dgamma_out), _ptr(dbeta_out), _dtype_code(x), _ptr(ws), int(dy_ld), int(y_ld), _stream()))
         return sums
 
     def bn_backward_apply(self, x, y, dy, gamma, beta, stats, sums, inv_n_total, relu, want_residual):
@@ -822,12 +848,14 @@ class HipBackend:
         L = engine.lib()
         n, c = x.shape
         dev_inv = inv_n_total if torch.is_tensor(inv_n_total) else None
+        dy, dy_ld = self._strided_in(dy, c)
+        y, y_ld = self._strided_in(y, c)
         with _dev(x.device):
-            dx = torch.empty_like(x)
-            dres = torch.empty_like(x) if want_residual else None
+            dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+            dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_residual else None
             engine.check(L.lgs_bn_backward_apply(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(sums),
                                                  0.0 if dev_inv is not None else float(inv_n_total), _ptr(dev_inv), int(relu), _ptr(dx),
-                                                 _ptr(dres), _dtype_code(x), _stream()))
+                                                 _ptr(dres), _dtype_code(x), int(dy_ld), int(y_ld), _stream()))
         return dx, dres
 
     # ---- CLIP contraction: lgs_clip_similarity

@@ -391,19 +391,7 @@ class MinkowskiBatchNorm(nn.Module):
             cs = getattr(input, "_bn_stats", None)
             if cs is not None and (cs[1] is not None) != (rm is not None):
                 cs = None                                  # pivot convention mismatch (cannot happen for the conv's own bn)
-            slot = None
-            c = x.shape[1]
-            al = 8 if x.dtype == torch.bfloat16 else 4
-            if getattr(backend, "bn_out_into", False) and x.is_cuda and type(self) is MinkowskiBatchNorm:
-                if cat_up > 0 and cat_up % al == 0 and c % al == 0:
-                    buf = torch.empty((x.shape[0], cat_up + c), dtype=x.dtype, device=x.device)
-                    slot = _CatSlot(buf, cat_up, c)
-                elif cat_into is not None:
-                    other = getattr(cat_into, "_cat_slot", None)
-                    if (other is not None and other.off == c and other.buf.shape[0] == x.shape[0] and other.buf.dtype == x.dtype
-                            and not getattr(other, "taken", False)):
-                        slot = _CatSlot(other.buf, 0, c)
-                        other.taken = True
+            slot = self._cat_slot_for(x, cat_up, cat_into, backend) if type(self) is MinkowskiBatchNorm else None
             y = FusedBatchNormFunction.apply(x, bn.weight, bn.bias, res, rm, rv, bn.eps, bn.momentum, relu, backend, nbt, cs, slot)
             out = SparseTensor(y, coordinate_map_key=input.coordinate_map_key, coordinate_manager=input.coordinate_manager)
             out._cat_slot = slot
@@ -428,6 +416,24 @@ class MinkowskiBatchNorm(nn.Module):
                 y = torch.relu(y)
         return SparseTensor(y, coordinate_map_key=input.coordinate_map_key, coordinate_manager=input.coordinate_manager)
 
+    @staticmethod
+    def _cat_slot_for(x, cat_up, cat_into, backend):
+        """the column slice of a concat buffer this norm's output goes to (zero-copy ME.cat), or None"""
+        if not (getattr(backend, "bn_out_into", False) and x.is_cuda):
+            return None
+        c = x.shape[1]
+        al = 8 if x.dtype == torch.bfloat16 else 4
+        if cat_up > 0 and cat_up % al == 0 and c % al == 0:
+            buf = torch.empty((x.shape[0], cat_up + c), dtype=x.dtype, device=x.device)
+            return _CatSlot(buf, cat_up, c)
+        if cat_into is not None:
+            other = getattr(cat_into, "_cat_slot", None)
+            if (other is not None and other.off == c and other.buf.shape[0] == x.shape[0] and other.buf.dtype == x.dtype
+                    and not getattr(other, "taken", False)):
+                other.taken = True
+                return _CatSlot(other.buf, 0, c)
+        return None
+
     def __repr__(self):
         b = self.bn
         return "MinkowskiBatchNorm(%d, eps=%g, momentum=%g, affine=%s, track_running_stats=%s)" % (
@@ -446,15 +452,19 @@ class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
         self.process_group = process_group
 
     def forward(self, input, relu=False, residual=None, cat_up=0, cat_into=None):
-        # cat_up / cat_into (zero-copy ME.cat hints) are ignored here: ME.cat then copies, as it does for any ordinary tensor
         import torch.distributed as dist
         if not (self.training and dist.is_available() and dist.is_initialized()
                 and (dist.get_world_size(self.process_group) > 1 or MinkowskiSyncBatchNorm.force_sync)):
-            return super().forward(input, relu=relu, residual=residual)
+            return super().forward(input, relu=relu, residual=residual, cat_up=cat_up, cat_into=cat_into)
         from ..ddp import sync_batch_norm
         res = residual.F if isinstance(residual, SparseTensor) else residual
-        y = sync_batch_norm(input.F, self.bn, self.process_group, residual=res, relu=relu, conv_stats=getattr(input, "_bn_stats", None))
-        return SparseTensor(y, coordinate_map_key=input.coordinate_map_key, coordinate_manager=input.coordinate_manager)
+        backend = get_backend()
+        slot = self._cat_slot_for(input.F, cat_up, cat_into, backend) if hasattr(backend, "bn_forward_sync") else None
+        y = sync_batch_norm(input.F, self.bn, self.process_group, residual=res, relu=relu, conv_stats=getattr(input, "_bn_stats", None),
+                            out_into=slot)
+        out = SparseTensor(y, coordinate_map_key=input.coordinate_map_key, coordinate_manager=input.coordinate_manager)
+        out._cat_slot = slot
+        return out
 
     @classmethod
     def convert_sync_batchnorm(cls, module, process_group=None):
