@@ -4,7 +4,8 @@ Round 3 shipped a hot kernel (k_wgrad_wide: 19 % of the CLIP step's kernel time)
 (>= 200 k positions) sat between the test sizes and the benchmark size.  Every kernel launch of the engine is counted per launch
 site -- kernel expression + template bindings, e.g. "k_wgrad_ps<KIND,NCS> [KIND=0,NCS=3]" or "k_conv_gather<T,2,3,4,1,...>
 [T=unsignedshort]" -- and tests/conftest.py records the sites every GPU test hits.  This module runs LAST: it executes the steps
-bench.py's default line times (BASELINE configs[1] bf16 + fp32, configs[2], configs[4] full / frozen, the single-scene line) on
+bench.py's default line times (BASELINE configs[1] bf16 + fp32, configs[2], configs[4] full / frozen, the per-rank path of N > 1
+at a world of one rank, the single-scene line) on
 the benchmark's 8-scene batch and asserts that each site they dispatch was also dispatched by an earlier (parity) test.
 
 Reference workloads: /root/reference/scripts/train_models.sh (configs[1]), scripts/text_representation_train.sh:7 (configs[2]),
@@ -53,6 +54,23 @@ def _bench_sites():
     run("clip (configs[2])", "clip", "Res16UNet34D", torch.bfloat16, c, f, l)
     run("insseg full (configs[4])", "insseg", "InsSegRes16UNet34C", torch.bfloat16, c, f, l)
     run("insseg frozen trunk (configs[4])", "insseg_frozen", "InsSegRes16UNet34C", torch.bfloat16, c, f, l)
+    # the per-rank code path of N > 1 (bench.py's `dp_path_world1` block): SyncBN through the engine's RCCL communicator + forced
+    # bucket collectives with a world of one rank
+    import torch.distributed as dist
+    import MinkowskiEngine as ME
+    from languagegroundedsemseg_amd.ddp import EngineComm
+    if not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % bench._free_port(), rank=0, world_size=1)
+        try:
+            ME.MinkowskiSyncBatchNorm.force_sync = True
+            args.dp_world1 = True
+            run("N > 1 per-rank path at a world of one rank", "ce", "Res16UNet34C", torch.bfloat16, c, f, l)
+        finally:
+            args.dp_world1 = False
+            ME.MinkowskiSyncBatchNorm.force_sync = False
+            EngineComm.close_all()
+            dist.destroy_process_group()
     del c, f, l
     c, f, l = (torch.from_numpy(a).to(dev) for a in make_batch([1000], voxel=0.02, n_target=150000))
     run("single scene", "ce", "Res16UNet34C", torch.bfloat16, c, f, l)

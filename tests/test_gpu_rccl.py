@@ -122,6 +122,8 @@ def _worker(rank, port, ret):
         worst = max(float((gc_[k] - gd[k]).norm() / gd[k].norm().clamp_min(1e-12)) for k in gd)
         rm = float((c.bn0.bn.running_mean - d.bn0.bn.running_mean).abs().max())
         ret["out"] = (same, worst, rm, int(c.bn0.bn.num_batches_tracked), same_rs, same_blk, node_calls, same_comm)
+        from languagegroundedsemseg_amd import engine as _engine
+        ret["sites"] = sorted(_engine.dispatch_counts())      # launch sites this worker hit (for tests/test_gpu_dispatch_coverage.py)
     finally:
         from languagegroundedsemseg_amd.ddp import EngineComm as _EC
         _EC.close_all()
@@ -133,6 +135,8 @@ def test_rccl_collective_paths_with_one_rank_reproduce_the_local_step():
     ret = mgr.dict()
     mp.spawn(_worker, args=(_free_port(), ret), nprocs=1, join=True)
     same, worst, rm, nbt, same_rs, same_blk, node_calls, same_comm = ret["out"]
+    import conftest
+    conftest.DISPATCHED["tests/test_gpu_rccl.py::worker"] = set(ret["sites"])
     assert same_comm, "SyncBN through the engine's RCCL communicator must equal SyncBN through torch.distributed's collectives bit for bit"
     assert same_blk, "SyncBN blocks as ONE autograd node (%d node calls) must equal the module-by-module SyncBN path bit for bit" % node_calls
     assert same, "RCCL all_reduce of the gradient buckets (world 1) must leave the step bit-identical"
