@@ -807,7 +807,11 @@ GatherCfg gather_cfg(const View &v, int nb_total) {
   if (!kF32 && small_override == 7 && nb_total % 4 == 0) return {7, 2, 4, 128};     // 128 positions x 128 channels (32 x 128 per wave)
   if (!kF32 && small_override == 12) return {12, 8, 2, 128};
   if (!kF32 && small_override == 13) return {13, 8, 4, 128};
-  if (!kF32) return {8, 4, 2, 128};   // measured best on the L3/L4 shapes (tools/microbench.py coarse): 128 positions x 64 channels
+  // 3^3 maps of 16 k+ positions with 256 output channels (level 3 of the 8-scene batch): 128 positions x 128 channels per workgroup
+  // gathers every row half as often as the 64-channel tile (stand-alone 256 -> 256 at 19.6 k rows: 0.127 vs 0.147 ms; the other
+  // coarse shapes -- level 3 128 -> 128, level 4 256 -> 256 at 5 k rows -- are faster on the small tile, r04_experiments.txt)
+  if (!kF32 && nb_total == 8 && v.KS > 1 && v.n_pad >= 16384) return {7, 2, 4, 128};
+  if (!kF32) return {8, 4, 2, 128};   // measured best on the other L3/L4 shapes (tools/microbench.py coarse): 128 positions x 64 channels
   return {5, 2, 2, 64};
 }
 

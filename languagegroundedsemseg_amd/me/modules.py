@@ -107,6 +107,19 @@ def conv_weight_grad(kmap, feats, gout, transposed, kparam, kshape, kdtype):
     return view                                          # consumers wait for the side stream in BucketedDDP
 
 
+def _bias_grad(gout):
+    """column sums of the output gradient in fp32.  On the engine: the BatchNorm statistics reduction (two launches at the
+    streaming rate: per-block sums about a pivot, folded in double in a fixed order) read as mean x count -- torch's reduction
+    of the [1.2 M, 200] bf16 gradient of the classifier took 190 us of the step."""
+    backend = get_backend()
+    c = gout.shape[1]
+    if hasattr(backend, "bn_stats") and gout.is_cuda and gout.is_contiguous() and gout.shape[0] > 0 and \
+            c % (8 if gout.dtype == torch.bfloat16 else 4) == 0 and gout.dtype in (torch.bfloat16, torch.float32):
+        rec = backend.bn_stats(gout)                           # [mean | M2 | count]
+        return (rec[:c] * rec[2 * c]).view(1, c)
+    return gout.sum(0, keepdim=True, dtype=torch.float32)      # fp32 accumulation without an fp32 copy of gout
+
+
 class MinkowskiConvolutionFunction(torch.autograd.Function):
     """out = conv(in) over a cached kernel map; backward = dgrad + wgrad (conv_weight_grad) (+ bias grad) on the same map."""
 
@@ -138,7 +151,7 @@ class MinkowskiConvolutionFunction(torch.autograd.Function):
             else:
                 gin = ctx.kmap.conv_dgrad(gout, kernel, ctx.transposed)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gout.sum(0, keepdim=True, dtype=torch.float32)   # fp32 accumulation without an fp32 copy of gout
+            gb = _bias_grad(gout)
         return gin, gw, gb, None, None, None, None, None
 
 
