@@ -960,7 +960,12 @@ int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype) 
   }
   if (dtype == LGS_BF16 && cin % 8 != 0) {
     int64_t nmax = km->fwd.n_in > km->bwd.n_in ? km->fwd.n_in : km->bwd.n_in;
-    bytes += align256(nmax * (int64_t)((cin + 7) / 8 * 8) * 2);
+    const int c8 = (cin + 7) / 8 * 8;
+    const int64_t padded = align256(nmax * (int64_t)c8 * 2);
+    bytes += padded;
+    // ... or the position-stationary kernel on the padded rows (lgs_conv_wgrad): partial slabs | padded input
+    const PsPlan f8 = ps_plan(km->fwd, c8, cout);
+    if (f8.ok && align256(f8.partial_bytes) + 256 + padded + 256 > bytes) bytes = align256(f8.partial_bytes) + 256 + padded + 256;
   }
   if (dtype == LGS_BF16 && cout % 8 != 0) {
     int64_t nmax = km->fwd.n_out > km->bwd.n_out ? km->fwd.n_out : km->bwd.n_out;
@@ -1011,7 +1016,8 @@ int launch_wgrad_ps(const PsArgs &a, const PsPlan &p, hipStream_t s) {
 // 2^3 view); transposed = 0: gathered operand = in (rows of v's input side), stationary = gout;  transposed = 1 (the
 // transposed conv that reuses the strided conv's map): gathered = gout (fine rows), stationary = in (coarse rows).
 int conv_wgrad_ps(const View &v, int transposed, const bf16_t *in, int cin, const bf16_t *go, int cout, float *gw, void *workspace,
-                  hipStream_t s, bool *done, int in_ld) {
+                  hipStream_t s, bool *done, int in_ld, int cin_out = -1) {
+  // cin_out (> 0, forward direction only): `in` was zero-padded to cin channels by the caller; gw has cin_out input channels
   *done = false;
   if (!ps_enabled()) return 0;
   const int cg = transposed ? cout : cin, cs = transposed ? cin : cout;
@@ -1042,8 +1048,9 @@ int conv_wgrad_ps(const View &v, int transposed, const bf16_t *in, int cin, cons
     else rc = launch_wgrad_ps<8, 4>(a, p, s);
   }
   if (rc) return rc;
-  const int64_t total = (int64_t)v.K * cg * ((cs + 3) / 4);
-  LGS_KLAUNCH(k_wgrad_reduce_ps, (unsigned)((total + 255) / 256), 256, 0, s, a.partial, p.n_lanes, v.K, p.cg_pad, p.cs_pad, cg, cs,
+  const int cg_o = (!transposed && cin_out > 0) ? cin_out : cg;
+  const int64_t total = (int64_t)v.K * cg_o * ((cs + 3) / 4);
+  LGS_KLAUNCH(k_wgrad_reduce_ps, (unsigned)((total + 255) / 256), 256, 0, s, a.partial, p.n_lanes, v.K, p.cg_pad, p.cs_pad, cg_o, cs,
                      transposed, gw);
   LGS_HIP(hipGetLastError());
   *done = true;
@@ -1245,8 +1252,23 @@ int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const 
     }
     if (km->fwd.n_pad > 0 && (km->ks == 3 || km->ks == 2)) {
       bool done = false;
-      int rc = conv_wgrad_ps(km->fwd, transposed, reinterpret_cast<const bf16_t *>(in), cin, reinterpret_cast<const bf16_t *>(grad_out),
-                             cout, grad_weight, workspace, s, &done, in_row_stride);
+      int rc = 0;
+      if (!transposed && km->ks == 3 && cin % 8 != 0 && cout % 8 == 0 && (in_row_stride == 0 || in_row_stride == cin) && ps_enabled()) {
+        // the 3-channel colour input of the network's first convolution: rows zero-padded to 8 channels behind the partial slabs,
+        // then the position-stationary kernel (this launch is the LAST of the backward pass: `finalize` waits for exactly it;
+        // the pair-list kernel took 0.31 ms at 1.2 M voxels)
+        const int c8 = (cin + 7) / 8 * 8;
+        const PsPlan pp = ps_plan(km->fwd, c8, cout);
+        if (pp.ok) {
+          bf16_t *padded = reinterpret_cast<bf16_t *>(reinterpret_cast<char *>(workspace) + align256(pp.partial_bytes) + 256);
+          const int64_t tot = km->fwd.n_in * (int64_t)c8;
+          if (tot > 0) LGS_KLAUNCH(k_pad_rows_bf16, (unsigned)((tot + 255) / 256), 256, 0, s, reinterpret_cast<const bf16_t *>(in), km->fwd.n_in, cin, c8, padded);
+          rc = conv_wgrad_ps(km->fwd, 0, padded, c8, reinterpret_cast<const bf16_t *>(grad_out), cout, grad_weight, workspace, s, &done, 0, cin);
+          if (rc || done) return rc;
+        }
+      }
+      rc = conv_wgrad_ps(km->fwd, transposed, reinterpret_cast<const bf16_t *>(in), cin, reinterpret_cast<const bf16_t *>(grad_out),
+                         cout, grad_weight, workspace, s, &done, in_row_stride);
       if (rc || done) return rc;
     }
     LGS_REQUIRE(in_row_stride == 0 || in_row_stride == cin, "lgs_conv_wgrad: a strided input is only supported by the position-stationary bf16 kernel");
