@@ -897,7 +897,7 @@ struct PsPlan {
   int cg_pad = 0, cs_pad = 0, n_cg = 0, n_cs = 0, n_lanes = 0, cpl = 0, n_chunks = 0, xcd_map = 1;
   int64_t partial_bytes = 0;
 };
-inline PsPlan ps_plan(const View &v, int cg, int cs) {
+inline PsPlan ps_plan(const View &v, int cg, int cs, int cus_override = 0) {
   PsPlan p;
   if (!(v.K == 27 || v.K == 8) || v.KS != v.K || v.nbr == nullptr || v.n_pad < kPsChunk || v.n_pad % kPsChunk != 0) return p;
   if (cg % 8 != 0 || cs % 8 != 0) return p;
@@ -927,7 +927,7 @@ inline PsPlan ps_plan(const View &v, int cg, int cs) {
   // compute-stream kernel waits for weight-gradient workgroups to retire before it gets anywhere.  Leaving 12 CUs per XCD makes
   // the weight gradients ~1.3 x longer on their own stream (which has the slack) and the 8-scene step 0.7 ms shorter
   // (32: 29.97, 28: 29.6, 24: 29.4, 20: 29.27, 16: 29.36 ms; `finalize`, the side stream's tail, stays 0.40 ms down to 20)
-  const int cus_env = (int)tune(T_PS_CUS);
+  const int cus_env = cus_override > 0 ? cus_override : (int)tune(T_PS_CUS);
   const int per_xcd = (cus_env >= 4 && cus_env <= 32 ? cus_env : 32) * wg_per_cu, n_sl = p.n_cg * p.n_cs;
   p.xcd_map = n_sl <= per_xcd ? 1 : 0;
   int lanes = p.xcd_map ? 8 * (per_xcd / n_sl) : (8 * per_xcd) / n_sl;
@@ -964,7 +964,7 @@ int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype) 
     const int64_t padded = align256(nmax * (int64_t)c8 * 2);
     bytes += padded;
     // ... or the position-stationary kernel on the padded rows (lgs_conv_wgrad): partial slabs | padded input
-    const PsPlan f8 = ps_plan(km->fwd, c8, cout);
+    const PsPlan f8 = ps_plan(km->fwd, c8, cout, 32);
     if (f8.ok && align256(f8.partial_bytes) + 256 + padded + 256 > bytes) bytes = align256(f8.partial_bytes) + 256 + padded + 256;
   }
   if (dtype == LGS_BF16 && cout % 8 != 0) {
@@ -1016,12 +1016,12 @@ int launch_wgrad_ps(const PsArgs &a, const PsPlan &p, hipStream_t s) {
 // 2^3 view); transposed = 0: gathered operand = in (rows of v's input side), stationary = gout;  transposed = 1 (the
 // transposed conv that reuses the strided conv's map): gathered = gout (fine rows), stationary = in (coarse rows).
 int conv_wgrad_ps(const View &v, int transposed, const bf16_t *in, int cin, const bf16_t *go, int cout, float *gw, void *workspace,
-                  hipStream_t s, bool *done, int in_ld, int cin_out = -1) {
+                  hipStream_t s, bool *done, int in_ld, int cin_out = -1, int cus_override = 0) {
   // cin_out (> 0, forward direction only): `in` was zero-padded to cin channels by the caller; gw has cin_out input channels
   *done = false;
   if (!ps_enabled()) return 0;
   const int cg = transposed ? cout : cin, cs = transposed ? cin : cout;
-  const PsPlan p = ps_plan(v, cg, cs);
+  const PsPlan p = ps_plan(v, cg, cs, cus_override);
   if (!p.ok) return 0;
   const int64_t g_rows = v.n_in, s_rows = v.n_out;
   const int g_ld = transposed ? cg : (in_ld > 0 ? in_ld : cg), s_ld = transposed ? (in_ld > 0 ? in_ld : cs) : cs;
@@ -1258,12 +1258,13 @@ int lgs_conv_wgrad(lgs_kmap *km, int transposed, const void *in, int cin, const 
         // then the position-stationary kernel (this launch is the LAST of the backward pass: `finalize` waits for exactly it;
         // the pair-list kernel took 0.31 ms at 1.2 M voxels)
         const int c8 = (cin + 7) / 8 * 8;
-        const PsPlan pp = ps_plan(km->fwd, c8, cout);
+        // nothing runs beside the last launch of the backward pass: all 32 CUs of every XCD instead of PS_CUS
+        const PsPlan pp = ps_plan(km->fwd, c8, cout, 32);
         if (pp.ok) {
           bf16_t *padded = reinterpret_cast<bf16_t *>(reinterpret_cast<char *>(workspace) + align256(pp.partial_bytes) + 256);
           const int64_t tot = km->fwd.n_in * (int64_t)c8;
           if (tot > 0) LGS_KLAUNCH(k_pad_rows_bf16, (unsigned)((tot + 255) / 256), 256, 0, s, reinterpret_cast<const bf16_t *>(in), km->fwd.n_in, cin, c8, padded);
-          rc = conv_wgrad_ps(km->fwd, 0, padded, c8, reinterpret_cast<const bf16_t *>(grad_out), cout, grad_weight, workspace, s, &done, 0, cin);
+          rc = conv_wgrad_ps(km->fwd, 0, padded, c8, reinterpret_cast<const bf16_t *>(grad_out), cout, grad_weight, workspace, s, &done, 0, cin, 32);
           if (rc || done) return rc;
         }
       }
