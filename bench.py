@@ -39,6 +39,8 @@ if ROOT not in sys.path:
 
 import MinkowskiEngine as ME  # noqa: E402
 from languagegroundedsemseg_amd import models  # noqa: E402
+from languagegroundedsemseg_amd.me import block as _block  # noqa: E402
+from languagegroundedsemseg_amd.me import deferred as _deferred  # noqa: E402
 from languagegroundedsemseg_amd.ddp import BucketedDDP, FlatSGD  # noqa: E402
 from languagegroundedsemseg_amd.losses import fused_cross_entropy  # noqa: E402
 from languagegroundedsemseg_amd.synthetic import make_batch  # noqa: E402
@@ -138,7 +140,7 @@ class ConvLog:
                         ConvLog.key_of("", 1, planes, cin, rows)}
                 return log.only_key in mine
             return False
-        models._BLOCK_C_VETO = veto
+        _block._BLOCK_C_VETO = veto
 
     def summarize(self):
         """-> (family totals of k_conv_gather launches, wgrad totals, per-shape groups sorted by time)"""
@@ -444,13 +446,12 @@ def measure(model, ddp, opt, coords, feats, labels, dtype, steps, warmup, ctx, c
                 fam, wg, top = clog.summarize()
                 disc = dict(fam=fam, wg=wg, top=top, rows=list(clog.rows))
                 clog.rows = []
-                clog.mode = "only"              # from here on only the dominant shape's launches are bracketed
-                clog.only_key = top[0][0]
+                clog.mode = None                # the timed steps are the pure production path: nothing bracketed, no block enqueued call by call
         else:
             train_step(model, ddp, opt, coords, feats, labels, dtype, base + i, ctx=ctx)
     torch.cuda.synchronize()
     if clog is not None:
-        clog.rows = []                          # keep only the samples of the timed steps
+        clog.rows = []
     if ddp.timing is not None:
         ddp.timing_summary(1)                   # drop the warm-up's collective events
     del _PHASES[:]
@@ -469,11 +470,24 @@ def measure(model, ddp, opt, coords, feats, labels, dtype, steps, warmup, ctx, c
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"dt": dt, "loss": loss, "disc": disc, "phases": phase_summary(steps, origin=(marks[0], t0)),
-            "step_ms": [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]}
+    out = {"dt": dt, "loss": loss, "disc": disc, "phases": phase_summary(steps, origin=(marks[0], t0)),
+           "step_ms": [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]}
+    if clog is not None and disc is not None:
+        # SAMPLING pass, after the timed region (advisor, round 4: the headline must not be measured on an instrumented path): a few
+        # more steps in which only the dominant shape's launches are bracketed by HIP events on their stream -- its residual blocks
+        # are enqueued call by call for that (same launches, bit-identical), everything else runs as in the timed steps
+        clog.rows, clog.mode, clog.only_key = [], "only", disc["top"][0][0]
+        n_samp = max(2, min(steps, 6))
+        for i in range(n_samp):
+            train_step(model, ddp, opt, coords, feats, labels, dtype, base + warmup + steps + i, ctx=ctx)
+        torch.cuda.synchronize()
+        clog.mode = None
+        out["sample_steps"] = n_samp
+        del _PHASES[:]
+    return out
 
 
-def roofline_report(clog, disc, dtype_name, workload, steps, ms_per_step, n_vox, traffic_pair):
+def roofline_report(clog, disc, dtype_name, workload, steps, ms_per_step, n_vox, traffic_pair, sample_steps=0):
     """the `roofline` object of the JSON line from a ConvLog's discovery step + its in-step samples of the dominant shape"""
     clog.mode = None
     fam, wg, top = disc["fam"], disc["wg"], disc["top"]
@@ -508,10 +522,11 @@ def roofline_report(clog, disc, dtype_name, workload, steps, ms_per_step, n_vox,
         "alg_bytes_per_launch": alg_bytes,
         "mfma_tflops_on_real_pairs": flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
         "mfma_frac_of_peak_on_real_pairs": flop / (avg_ms * 1e-3) / mfma_peak if avg_ms > 0 else 0.0,
-        "measured": "HIP events on the launching stream around the %d launches of this shape inside the %d timed steps "
-                    "(weight pack ~6 us + kernel); all other launches of the timed steps are un-instrumented; the residual blocks that "
-                    "contain this shape are enqueued call by call instead of through lgs_block_forward / lgs_block_backward (same "
-                    "launches, bit-identical) so that Python can bracket them" % (len(samp_ms), steps),
+        "measured": "HIP events on the launching stream around the %d launches of this shape inside %d SAMPLING steps run right after "
+                    "the %d timed steps (same batch, same state; all other launches un-instrumented; the residual blocks that contain "
+                    "this shape are enqueued call by call there instead of through lgs_block_forward / lgs_block_backward -- same "
+                    "launches, bit-identical -- so that Python can bracket them).  The timed steps themselves carry no "
+                    "instrumentation" % (len(samp_ms), sample_steps, steps),
         "discovery_step": {
             "note": "one fully instrumented warm-up step (every conv launch bracketed: the step is stretched, durations "
                     "rank the shapes and feed the byte model only)",
@@ -543,7 +558,7 @@ def secondary_block(workload, model_name, dtype, coords, feats, labels, device, 
     if clog is not None and res["disc"] is not None:
         tp = pmc_traffic(res["disc"]["top"][0][0], args) if (workload == "clip" and dtype == torch.bfloat16) else (None, None)
         out["roofline"] = roofline_report(clog, res["disc"], dname, "clip" if workload == "clip" else ("ce" if workload == "ce" else "insseg"),
-                                          steps, ms, n_vox, tp)
+                                          steps, ms, n_vox, tp, res.get("sample_steps", 0))
         if workload == "clip":
             out["roofline"]["mfma"] = clip_mfma_report(out_dim=model.PLANES[7], n=n_vox, dtype=dtype, device=device)
     del model, ddp, opt, res
@@ -779,7 +794,14 @@ def main():
                    "parallelism": "dp%d" % world, "sync_bn": bool(world > 1 and args.sync_bn),
                    "allreduce": args.allreduce,
                    "storage": "bf16 features / fp32 master weights, fp32 accumulate + BN statistics" if args.dtype == "bf16"
-                   else "fp32"},
+                   else "fp32",
+                   # what issues the engine calls of the timed steps (round-4 review: say which model the number belongs to)
+                   "model_impl": "languagegroundedsemseg_amd.models: the reference's call sequence (resnet_block.py:41-57, "
+                                 "res16unet.py:196-270: conv; norm; relu in place; out += residual; me.cat) with standard "
+                                 "MinkowskiEngine signatures only -- the reference's unchanged model files record the same units "
+                                 "(tests/test_deferred_cpu.py); fused behind the ME surface by deferred execution (me/deferred.py), "
+                                 "LGS_DEFER=%d" % int(_deferred.ENABLED),
+                   "timed_steps_instrumented": False},
         "final_loss": final_loss,
         "phases": res["phases"],
     }
@@ -803,7 +825,7 @@ def main():
 
     if clog is not None and res["disc"] is not None:
         out["roofline"] = roofline_report(clog, res["disc"], args.dtype, args.workload, args.steps, ms_per_step, n_vox,
-                                          pmc_traffic(res["disc"]["top"][0][0], args))
+                                          pmc_traffic(res["disc"]["top"][0][0], args), res.get("sample_steps", 0))
         if args.workload == "clip":
             out["roofline"]["mfma"] = clip_mfma_report(out_dim=model.PLANES[7], n=n_vox, dtype=dtype, device=device)
     log("roofline pass done")
@@ -812,6 +834,18 @@ def main():
         out["single_scene"] = single_scene_line(model, ddp, opt, dtype, device, args, ctx)
         log("single-scene line done")
     if secondary:
+        # the SAME model and batch with every ME call executed as it is made (LGS_DEFER=0): what the call sequence costs without the
+        # deferred surface -- separate norm, ReLU, add and concat-copy launches, one autograd node per call
+        _deferred.ENABLED = False
+        try:
+            ub = secondary_block("ce", "Res16UNet34C", torch.bfloat16, coords, feats, labels, device, args, None, steps=5, warmup=3,
+                                 note="LGS_DEFER=0: the reference call sequence executed call by call (unfused); the headline is the same "
+                                      "sequence executed through the deferred ME surface")
+        finally:
+            _deferred.ENABLED = True
+        out["reference_calls"] = {"fused_ms_per_step": ms_per_step, "call_by_call_ms_per_step": ub["ms_per_step"],
+                                  "call_by_call": ub, "deferred_stats": dict(_deferred.STATS)}
+        log("call-by-call block done")
         # the other BASELINE configurations, each a few timed steps on the same 8-scene batch, so that their numbers sit in
         # the driver's record next to the headline instead of in builder-only files
         del model, ddp, opt

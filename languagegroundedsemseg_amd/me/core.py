@@ -11,6 +11,8 @@ from enum import Enum
 
 import torch
 
+from . import deferred as _deferred
+
 _BACKEND = None
 
 
@@ -25,6 +27,7 @@ def get_backend():
 def set_backend(backend):
     """Install a backend object (tests only: the CPU oracle). Returns the previous one."""
     global _BACKEND
+    _deferred.flush_all()        # recorded calls run on the backend they were recorded under
     prev, _BACKEND = _BACKEND, backend
     return prev
 
@@ -73,6 +76,7 @@ class CoordinateManager:
         self._m = None
         self._keys = {}
         self.feature_dtype = None
+        self._pending = []          # recorded, not yet executed operations on tensors of this manager (me/deferred.py)
 
     def _ensure(self, device):
         if self._m is None:
@@ -125,6 +129,13 @@ class CoordinateManager:
 
 
 class SparseTensor:
+    # deferred execution (me/deferred.py): while `_op` is set the features do not exist yet -- the tensor is the future result of
+    # a recorded convolution / norm / concat; reading `.F` (or anything derived from it) executes the manager's queue
+    _op = None
+    _meta = None           # (channels, dtype, device) of a pending tensor
+    _cat_slot = None
+    _bn_stats = None
+
     def __init__(self, features, coordinates=None, tensor_stride=1, coordinate_map_key=None, coordinate_manager=None,
                  quantization_mode=SparseTensorQuantizationMode.RANDOM_SUBSAMPLE, allow_duplicate_coordinates=False,
                  minkowski_algorithm=None, requires_grad=None, device=None):
@@ -172,18 +183,35 @@ class SparseTensor:
         self.coordinate_map_key = coordinate_map_key
         self._manager = coordinate_manager
 
+    @classmethod
+    def _pending(cls, coordinate_map_key, coordinate_manager, meta):
+        """a tensor whose features are the result of an operation still in the manager's deferred queue"""
+        t = object.__new__(cls)
+        t._F = None
+        t._meta = meta
+        t.coordinate_map_key = coordinate_map_key
+        t._manager = coordinate_manager
+        t.quantization_mode = SparseTensorQuantizationMode.RANDOM_SUBSAMPLE
+        return t
+
+    def _nch(self):
+        """channel count without forcing a pending tensor"""
+        return self._F.shape[1] if self._op is None else self._meta[0]
+
     # -- ME attribute surface
     @property
     def F(self):
+        if self._op is not None:
+            _deferred.materialise(self)
         return self._F
 
     @property
     def feats(self):
-        return self._F
+        return self.F
 
     @property
     def features(self):
-        return self._F
+        return self.F
 
     @property
     def C(self):
@@ -219,25 +247,25 @@ class SparseTensor:
 
     @property
     def device(self):
-        return self._F.device
+        return self.F.device
 
     @property
     def dtype(self):
-        return self._F.dtype
+        return self.F.dtype
 
     @property
     def shape(self):
-        return self._F.shape
+        return self.F.shape
 
     @property
     def requires_grad(self):
-        return self._F.requires_grad
+        return self.F.requires_grad
 
     def size(self, *a):
-        return self._F.size(*a)
+        return self.F.size(*a)
 
     def __len__(self):
-        return self._F.shape[0]
+        return self.F.shape[0]
 
     def _like(self, feats):
         return SparseTensor(feats, coordinate_map_key=self.coordinate_map_key, coordinate_manager=self._manager)
@@ -249,8 +277,8 @@ class SparseTensor:
     def _binary(self, other, op):
         if isinstance(other, SparseTensor):
             self._check(other)
-            return self._like(op(self._F, other._F))
-        return self._like(op(self._F, other))
+            return self._like(op(self.F, other.F))
+        return self._like(op(self.F, other))
 
     def __add__(self, o):
         return self._binary(o, torch.add)
@@ -269,39 +297,43 @@ class SparseTensor:
         return self._binary(o, torch.div)
 
     def __neg__(self):
-        return self._like(-self._F)
+        return self._like(-self.F)
 
     def __iadd__(self, o):
-        # `out += residual` (resnet_block.py:54): in place on .F, autograd-legal because the conv/BN
+        # `out += residual` (resnet_block.py:54).  On the pending result of a norm the addend becomes that norm's residual
+        # operand (one fused kernel, me/deferred.py); otherwise in place on .F -- autograd-legal because the conv / BN
         # functions save their own inputs, never their outputs' storage
         if isinstance(o, SparseTensor):
             self._check(o)
-            o = o._F
-        self._F = self._F + o if self._F.requires_grad and self._F.is_leaf else self._F.add_(o)
+            if self._op is not None and _deferred.add_residual(self, o):
+                return self
+            o = o.F
+        f = self.F
+        self._F = f + o if f.requires_grad and f.is_leaf else f.add_(o)
         return self
 
     def __isub__(self, o):
         if isinstance(o, SparseTensor):
             self._check(o)
-            o = o._F
-        self._F = self._F.sub_(o)
+            o = o.F
+        self._F = self.F.sub_(o)
         return self
 
     def detach(self):
-        return self._like(self._F.detach())
+        return self._like(self.F.detach())
 
     def to(self, *a, **k):
-        return self._like(self._F.to(*a, **k))
+        return self._like(self.F.to(*a, **k))
 
     def float(self):
-        return self._like(self._F.float())
+        return self._like(self.F.float())
 
     def bfloat16(self):
-        return self._like(self._F.bfloat16())
+        return self._like(self.F.bfloat16())
 
     def features_at(self, batch_index):
         c = self.C
-        return self._F[c[:, 0] == batch_index]
+        return self.F[c[:, 0] == batch_index]
 
     def coordinates_at(self, batch_index):
         c = self.C
@@ -311,7 +343,7 @@ class SparseTensor:
     def decomposed_features(self):
         c = self.C
         nb = int(c[:, 0].max().item()) + 1 if c.shape[0] else 0
-        return [self._F[c[:, 0] == b] for b in range(nb)]
+        return [self.F[c[:, 0] == b] for b in range(nb)]
 
     @property
     def decomposed_coordinates(self):
@@ -320,7 +352,7 @@ class SparseTensor:
         return [c[c[:, 0] == b][:, 1:] for b in range(nb)]
 
     def __repr__(self):
-        return "SparseTensor(F=%s, %r, device=%s)" % (tuple(self._F.shape), self.coordinate_map_key, self._F.device)
+        return "SparseTensor(F=%s, %r, device=%s)" % (tuple(self.F.shape), self.coordinate_map_key, self.F.device)
 
 
 def cat(*sparse_tensors):
@@ -331,13 +363,29 @@ def cat(*sparse_tensors):
     first = sparse_tensors[0]
     for s in sparse_tensors[1:]:
         first._check(s)
+    if _deferred.ENABLED and any(t._op is not None for t in sparse_tensors):
+        return _deferred.record_cat(sparse_tensors)
+    return cat_now(sparse_tensors)
+
+
+def cat_now(sparse_tensors, out=None):
+    """the concat itself (all inputs materialised); `out`: the pending tensor to fill (me/deferred.py)"""
+    first = sparse_tensors[0]
+    f = _cat_features(sparse_tensors)
+    if out is None:
+        return first._like(f)
+    out._F, out._op = f, None
+    return out
+
+
+def _cat_features(sparse_tensors):
     if len(sparse_tensors) == 2:
-        a, b = (getattr(t, "_cat_slot", None) for t in sparse_tensors)
+        a, b = (t._cat_slot for t in sparse_tensors)
         # zero-copy: both halves were written straight into one [N, C1 + C2] buffer by their norms (me.modules)
         if (a is not None and b is not None and a.buf is b.buf and a.off == 0 and b.off == a.width
                 and a.width + b.width == a.buf.shape[1] and sparse_tensors[0].F.data_ptr() == a.buf.data_ptr()):
-            return first._like(_CatViewFunction.apply(sparse_tensors[0].F, sparse_tensors[1].F, a))
-    return first._like(torch.cat([s.F for s in sparse_tensors], dim=1))
+            return _CatViewFunction.apply(sparse_tensors[0].F, sparse_tensors[1].F, a)
+    return torch.cat([s.F for s in sparse_tensors], dim=1)
 
 
 class _CatViewFunction(torch.autograd.Function):

@@ -10,6 +10,7 @@ import math
 import torch
 import torch.nn as nn
 
+from . import deferred as _deferred
 from .core import SparseTensor, get_backend
 from .kernel import KernelGenerator, RegionType, convert_to_int_list
 
@@ -237,35 +238,51 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
         _invalidate_packed()      # `.data` writes are invisible to the version counter the packed-image cache keys on
 
     def forward(self, input, coordinates=None, bn=None):
-        """`bn` (extension used by the build's own models): the MinkowskiBatchNorm this output goes to next.  In training
-        the conv epilogue then also produces that norm's batch statistics (pivoted on its running mean) and hands them
-        over on the output tensor, so the norm does not read the [N, C] tensor a second time for them."""
+        """Standard call: `conv(x)` records the convolution (me/deferred.py) and returns a tensor whose features are pending; the
+        coordinate map / kernel map it needs are requested now (built on the engine's map stream).
+        `bn` (extension, used by the executor and by tests): the MinkowskiBatchNorm this output goes to next; runs immediately."""
         assert isinstance(input, SparseTensor)
-        assert input.F.shape[1] == self.in_channels, "Channel size mismatch %d != %d" % (input.F.shape[1], self.in_channels)
+        nch = input._nch()
+        assert nch == self.in_channels, "Channel size mismatch %d != %d" % (nch, self.in_channels)
+        if bn is None and _deferred.ENABLED:
+            return _deferred.record_conv(self, input, self._resolve(input))
+        return self._forward_now(input, bn)
+
+    def _resolve(self, input):
+        """-> (output coordinate map key, kernel map, transposed)"""
         mgr = input.coordinate_manager
         ks, st = self.kernel_size[0], self.stride[0]
         in_key = input.coordinate_map_key
         if not self.is_transpose:
             out_key = in_key if st == 1 else mgr.stride(in_key, st)
-            kmap = mgr.kernel_map_handle(in_key, out_key, ks)
-            transposed = False
-        else:
-            out_key = in_key if st == 1 else mgr.finer_key(in_key)
-            # the transposed conv reuses the forward map of the matching strided conv, in/out swapped
-            kmap = mgr.kernel_map_handle(out_key, in_key, ks)
-            transposed = True
-        want = (bn is not None and bn.bn.training and bn.bn.affine and input.F.is_cuda and self.bias is None
-                and getattr(get_backend(), "conv_bn_stats", False)
-                and get_backend().want_conv_bn_stats(mgr.size(out_key), self.out_channels, input.F.element_size()))
+            return out_key, mgr.kernel_map_handle(in_key, out_key, ks), False
+        out_key = in_key if st == 1 else mgr.finer_key(in_key)
+        # the transposed conv reuses the forward map of the matching strided conv, in/out swapped
+        return out_key, mgr.kernel_map_handle(out_key, in_key, ks), True
+
+    def _forward_now(self, input, bn=None, resolved=None, out=None):
+        """run the convolution.  `bn`: in training the conv epilogue may also produce that norm's batch statistics (pivoted on its
+        running mean; off by default, CONV_BN_STATS) and hand them over on the output tensor.  `out`: the pending tensor to fill."""
+        mgr = input.coordinate_manager
+        out_key, kmap, transposed = resolved if resolved is not None else self._resolve(input)
+        x = input.F
+        stats = None
+        want = (bn is not None and getattr(get_backend(), "conv_bn_stats", False) and bn.bn.training and bn.bn.affine and x.is_cuda
+                and self.bias is None
+                and get_backend().want_conv_bn_stats(mgr.size(out_key), self.out_channels, x.element_size()))
         if want:
             pivot = bn.bn.running_mean if bn.bn.track_running_stats else None
             holder = _StatsHolder()
-            out = _conv_with_stats(input.F, self.kernel, kmap, transposed, pivot, holder, self._cache_for(input.F))
-            st = SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
-            st._bn_stats = holder.stats            # (partials, pivot) or None
-            return st
-        out = MinkowskiConvolutionFunction.apply(input.F, self.kernel, self.bias, kmap, transposed, None, False, self._cache_for(input.F))
-        return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
+            y = _conv_with_stats(x, self.kernel, kmap, transposed, pivot, holder, self._cache_for(x))
+            stats = holder.stats                   # (partials, pivot) or None
+        else:
+            y = MinkowskiConvolutionFunction.apply(x, self.kernel, self.bias, kmap, transposed, None, False, self._cache_for(x))
+        if out is None:
+            out = SparseTensor(y, coordinate_map_key=out_key, coordinate_manager=mgr)
+        else:
+            out._F, out._op = y, None
+        out._bn_stats = stats
+        return out
 
     def _cache_for(self, feats):
         """packed-image cache of this module, only on the HIP backend with an fp32 master weight"""
@@ -382,13 +399,35 @@ class MinkowskiBatchNorm(nn.Module):
                                  track_running_stats=track_running_stats)
 
     def forward(self, input, relu=False, residual=None, cat_up=0, cat_into=None):
-        """`relu` / `residual` are extensions the build's own models use to fuse the whole
-        BN -> (+residual) -> ReLU chain into one kernel; reference code calls forward(input).
-        Zero-copy ME.cat(up, skip) (res16unet.py:237,247,257,267): the norm that produces the SKIP tensor is called with
-        cat_up = channels of the future `up` half: it allocates the [N, cat_up + C] concat buffer and writes its output into
-        the right-hand columns; the norm that produces `up` is called with cat_into = that skip tensor and writes into the
-        left-hand columns; ME.cat then returns the buffer itself.  Both are hints: paths that cannot honour them (eval
-        mode, SyncBN, CPU oracle backend) return ordinary tensors and ME.cat copies as before."""
+        """Standard call: `norm(x)` records the normalisation (me/deferred.py); a following MinkowskiReLU(inplace=True) and
+        `out += residual` become its epilogue, a later `me.cat` its output placement, and the whole thing runs as one kernel when
+        a value is first needed.
+        `relu` / `residual` / `cat_up` / `cat_into` are the executor's (and the per-op tests') way of asking for that fused kernel
+        directly; with any of them the call runs immediately.  Zero-copy ME.cat(up, skip) (res16unet.py:237,247,257,267): the norm
+        that produces the SKIP tensor gets cat_up = channels of the future `up` half: it allocates the [N, cat_up + C] concat buffer
+        and writes its output into the right-hand columns; the norm that produces `up` gets cat_into = that skip tensor and writes
+        into the left-hand columns; ME.cat then returns the buffer itself.  Both are hints: paths that cannot honour them (eval
+        mode, CPU oracle backend) return ordinary tensors and ME.cat copies."""
+        if _deferred.ENABLED and not relu and residual is None and not cat_up and cat_into is None:
+            return _deferred.record_bn(self, input)
+        return self._forward_now(input, relu, residual, cat_up, cat_into)
+
+    def train(self, mode=True):
+        if mode != self.training:
+            _deferred.flush_all()          # recorded calls run with the mode they were recorded in
+        return super().train(mode)
+
+    def _forward_now(self, input, relu=False, residual=None, cat_up=0, cat_into=None, out=None):
+        y, slot = self._run(input, relu, residual, cat_up, cat_into)
+        if out is None:
+            out = SparseTensor(y, coordinate_map_key=input.coordinate_map_key, coordinate_manager=input.coordinate_manager)
+        else:
+            out._F, out._op = y, None
+        out._cat_slot = slot
+        return out
+
+    def _run(self, input, relu, residual, cat_up, cat_into):
+        """-> (features, _CatSlot | None)"""
         bn = self.bn
         backend = get_backend()
         x = input.F
@@ -401,14 +440,12 @@ class MinkowskiBatchNorm(nn.Module):
             if nbt is not None and not getattr(backend, "bn_counts_batches", False):
                 nbt += 1
                 nbt = None                                 # (the HIP engine increments it inside the fold kernel)
-            cs = getattr(input, "_bn_stats", None)
+            cs = input._bn_stats
             if cs is not None and (cs[1] is not None) != (rm is not None):
                 cs = None                                  # pivot convention mismatch (cannot happen for the conv's own bn)
             slot = self._cat_slot_for(x, cat_up, cat_into, backend) if type(self) is MinkowskiBatchNorm else None
             y = FusedBatchNormFunction.apply(x, bn.weight, bn.bias, res, rm, rv, bn.eps, bn.momentum, relu, backend, nbt, cs, slot)
-            out = SparseTensor(y, coordinate_map_key=input.coordinate_map_key, coordinate_manager=input.coordinate_manager)
-            out._cat_slot = slot
-            return out
+            return y, slot
         elif hasattr(backend, "bn_apply") and bn.affine and bn.track_running_stats and x.is_cuda:
             # eval mode on the engine too (inference / validation passes, BN frozen during fine-tuning)
             # [running_mean | 1/sqrt(running_var + eps)], rebuilt only when the running statistics were written (a frozen trunk
@@ -427,7 +464,7 @@ class MinkowskiBatchNorm(nn.Module):
                 y = y + res
             if relu:
                 y = torch.relu(y)
-        return SparseTensor(y, coordinate_map_key=input.coordinate_map_key, coordinate_manager=input.coordinate_manager)
+        return y, None
 
     @staticmethod
     def _cat_slot_for(x, cat_up, cat_into, backend):
@@ -440,7 +477,7 @@ class MinkowskiBatchNorm(nn.Module):
             buf = torch.empty((x.shape[0], cat_up + c), dtype=x.dtype, device=x.device)
             return _CatSlot(buf, cat_up, c)
         if cat_into is not None:
-            other = getattr(cat_into, "_cat_slot", None)
+            other = cat_into._cat_slot
             if (other is not None and other.off == c and other.buf.shape[0] == x.shape[0] and other.buf.dtype == x.dtype
                     and not getattr(other, "taken", False)):
                 other.taken = True
@@ -464,20 +501,18 @@ class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
         super().__init__(num_features, eps, momentum, affine, track_running_stats)
         self.process_group = process_group
 
-    def forward(self, input, relu=False, residual=None, cat_up=0, cat_into=None):
+    def _run(self, input, relu, residual, cat_up, cat_into):
         import torch.distributed as dist
         if not (self.training and dist.is_available() and dist.is_initialized()
                 and (dist.get_world_size(self.process_group) > 1 or MinkowskiSyncBatchNorm.force_sync)):
-            return super().forward(input, relu=relu, residual=residual, cat_up=cat_up, cat_into=cat_into)
+            return super()._run(input, relu, residual, cat_up, cat_into)
         from ..ddp import sync_batch_norm
         res = residual.F if isinstance(residual, SparseTensor) else residual
         backend = get_backend()
-        slot = self._cat_slot_for(input.F, cat_up, cat_into, backend) if hasattr(backend, "bn_forward_sync") else None
-        y = sync_batch_norm(input.F, self.bn, self.process_group, residual=res, relu=relu, conv_stats=getattr(input, "_bn_stats", None),
-                            out_into=slot)
-        out = SparseTensor(y, coordinate_map_key=input.coordinate_map_key, coordinate_manager=input.coordinate_manager)
-        out._cat_slot = slot
-        return out
+        x = input.F
+        slot = self._cat_slot_for(x, cat_up, cat_into, backend) if hasattr(backend, "bn_forward_sync") else None
+        y = sync_batch_norm(x, self.bn, self.process_group, residual=res, relu=relu, conv_stats=input._bn_stats, out_into=slot)
+        return y, slot
 
     @classmethod
     def convert_sync_batchnorm(cls, module, process_group=None):
@@ -538,6 +573,13 @@ class MinkowskiNonlinearityBase(MinkowskiModuleBase):
 
 class MinkowskiReLU(MinkowskiNonlinearityBase):
     MODULE = nn.ReLU
+
+    def forward(self, input):
+        # in place on the pending result of a norm nobody has read yet: that norm's ReLU epilogue (me/deferred.py); the SAME tensor
+        # object comes back -- ME returns a new wrapper of the same (in-place rectified) storage, the two are indistinguishable
+        if input._op is not None and self.module.inplace and _deferred.relu_inplace(input):
+            return input
+        return super().forward(input)
 
 
 class MinkowskiSigmoid(MinkowskiNonlinearityBase):

@@ -11,6 +11,9 @@ HOST_KNOBS = {
                                        "join events); larger ones use the side stream.  Was 400000 while a one-scene step was host-bound; "
                                        "with lgs_block_backward forking inside the engine call one 145 k-voxel scene per step runs "
                                        "9.6 - 9.9 ms on the side stream against 10.1 - 10.2 inline (backward 5.3 vs 6.6 ms of stream time)"),
+    "DEFER": (1, int, "0 = every MinkowskiEngine call executes immediately (the reference's call sequence runs unfused: separate norm, "
+                      "ReLU, add and concat-copy kernels) instead of being recorded and run fused when a value is first read "
+                      "(me/deferred.py; same results: tests/test_gpu_reference_calls.py)"),
     "BLOCK_FUSED": (1, int, "0 = BasicBlocks run module by module instead of as one autograd node "
                             "(bit-identical: test_block_fast_path_is_the_op_by_op_path)"),
     "BLOCK_C": (1, int, "0 = a BasicBlock is enqueued call by call instead of through lgs_block_forward / lgs_block_backward "

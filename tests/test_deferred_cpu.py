@@ -1,0 +1,210 @@
+"""The deferred ME surface (languagegroundedsemseg_amd/me/deferred.py) on the CPU oracle backend: what is recorded for the
+reference's call sequence (/root/reference/models/modules/resnet_block.py:41-57, models/res16unet.py:196-270), that executing the
+record equals executing every call immediately, and the rules that keep it a faithful ME surface (program order, in-place
+semantics, hooks, grad modes, train/eval switches, failures)."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import MinkowskiEngine as ME
+from helpers import Cfg, deterministic_init, small_scene
+from languagegroundedsemseg_amd import models
+from languagegroundedsemseg_amd.me import deferred
+from oracle.backend import OracleBackend
+
+
+@pytest.fixture(autouse=True)
+def _oracle_backend():
+    prev = ME.set_backend(OracleBackend("torch"))
+    was = deferred.ENABLED
+    deferred.ENABLED = True
+    yield
+    deferred.ENABLED = was
+    ME.set_backend(prev)
+
+
+def _scene(n=900, seed=3, ch=3):
+    coords = small_scene(seed, n=n)
+    feats = np.random.default_rng(seed).uniform(-0.5, 0.5, (coords.shape[0], ch)).astype(np.float32)
+    return torch.from_numpy(coords), torch.from_numpy(feats)
+
+
+def _block(cin=8, planes=8, seed=1, downsample=False):
+    ds = None
+    if downsample:
+        ds = torch.nn.Sequential(ME.MinkowskiConvolution(cin, planes, kernel_size=1, stride=1, dimension=3), ME.MinkowskiBatchNorm(planes))
+    return deterministic_init(models.BasicBlock(cin, planes, downsample=ds), seed).train()
+
+
+def test_reference_block_sequence_is_recorded_as_fused_units():
+    c, f = _scene(ch=8)
+    for ds in (False, True):
+        blk = _block(8, 16 if ds else 8, downsample=ds)
+        x = ME.SparseTensor(f, c)
+        y = blk(x)
+        q = x.coordinate_manager._pending
+        kinds = [(op.kind, op.relu, op.residual is not None) for op in q]
+        C, B = deferred.CONV, deferred.BN
+        if ds:    # conv1, norm1+relu, conv2, downsample conv, downsample norm, norm2 + residual + relu (moved behind its residual)
+            assert kinds == [(C, False, False), (B, True, False), (C, False, False), (C, False, False), (B, False, False), (B, True, True)]
+            assert q[-1].residual is q[-2].out and q[-1].mod is blk.norm2
+        else:
+            assert kinds == [(C, False, False), (B, True, False), (C, False, False), (B, True, True)]
+            assert q[-1].residual is x
+        assert y._op is q[-1] and y._F is None
+        assert tuple(y.shape) == (c.shape[0], 16 if ds else 8)          # reading the shape executes the queue
+        assert not x.coordinate_manager._pending and y._op is None
+
+
+@pytest.mark.parametrize("name", ["Res16UNet14A", "Res16UNet34C"])
+def test_deferred_equals_immediate_whole_network(name):
+    c, f = _scene(1500)
+    lab = torch.from_numpy(np.random.default_rng(0).integers(-1, 20, c.shape[0]).astype(np.int64))
+
+    def run(defer):
+        deferred.ENABLED = defer
+        m = deterministic_init(models.load_model(name)(3, 20, Cfg()), 42).train()
+        x = ME.SparseTensor(f, c)
+        logits, out = m(x)
+        n_pending = deferred.pending_ops(x.coordinate_manager)
+        loss = torch.nn.functional.cross_entropy(logits.F, lab, ignore_index=-1)
+        loss.backward()
+        return (logits.F.detach(), out.F.detach(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                {k: b.clone() for k, b in m.named_buffers()}, n_pending)
+
+    hints0 = deferred.STATS["cat_hints"]
+    a, b = run(True), run(False)
+    n_units = {"Res16UNet14A": 33 + 32 + 4, "Res16UNet34C": 63 + 62 + 4}[name]       # convs + norms + cats: ReLUs and adds are epilogues
+    assert a[4] == n_units and b[4] == 0
+    assert deferred.STATS["cat_hints"] == hints0 + 4                 # all four me.cat(up, skip) pairs were planned as zero-copy
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+
+
+def test_inplace_semantics_relu_and_iadd_after_a_consumer_are_not_absorbed():
+    c, f = _scene(ch=8)
+    bn = ME.MinkowskiBatchNorm(8).train()
+    conv = ME.MinkowskiConvolution(8, 8, kernel_size=3, dimension=3)
+    relu = ME.MinkowskiReLU(inplace=True)
+    x = ME.SparseTensor(f, c)
+    out = bn(x)
+    z = conv(out)                                  # consumes the un-rectified norm output
+    op = out._op
+    assert not deferred.relu_inplace(out) and not op.relu
+    r = ME.SparseTensor(torch.ones_like(f), coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
+    assert not deferred.add_residual(out, r) and op.residual is None
+    ref = torch.nn.functional.batch_norm(f, None, None, training=True)
+    assert torch.allclose(out.F, ref, atol=1e-5)
+    # the absorbed order is norm -> (+= residual) -> relu only: a `+=` after the ReLU runs on the value
+    out2 = relu(bn(x))
+    assert out2._op.relu
+    out2 += r
+    assert out2._op is None and torch.allclose(out2.F, torch.relu(ref) + 1, atol=1e-5)
+    # not in place: a new tensor, the norm's own output stays un-rectified
+    out3 = bn(x)
+    y3 = ME.MinkowskiReLU(inplace=False)(out3)
+    assert y3 is not out3 and torch.allclose(out3.F, ref, atol=1e-5) and torch.allclose(y3.F, torch.relu(ref), atol=1e-5)
+    assert torch.isfinite(z.F).all()
+
+
+def test_module_hooks_fire_at_call_time_and_force_the_call_by_call_sequence():
+    c, f = _scene(ch=8)
+    blk = _block()
+    seen = []
+    blk.norm2.register_forward_hook(lambda m, a, out: seen.append(float(out.F.abs().sum())))   # reads .F: executes what is recorded
+    x = ME.SparseTensor(f, c)
+    y = blk(x)
+    assert len(seen) == 1
+    deferred.ENABLED = False
+    want = _block()(ME.SparseTensor(f, c)).F
+    assert torch.equal(y.F, want)
+
+
+def test_grad_mode_is_the_one_of_the_call_not_of_the_read():
+    c, f = _scene(ch=8)
+    blk = _block()
+    with torch.no_grad():
+        y = blk(ME.SparseTensor(f, c))
+    assert y._op is not None
+    assert not y.F.requires_grad                      # read with grad enabled, recorded without
+    y2 = blk(ME.SparseTensor(f, c))
+    with torch.no_grad():
+        feats = y2.F
+    assert feats.requires_grad
+
+
+def test_train_eval_switch_executes_what_is_pending_first():
+    c, f = _scene(ch=8)
+    bn = ME.MinkowskiBatchNorm(8).train()
+    x = ME.SparseTensor(f, c)
+    out = bn(x)
+    bn.eval()                                         # batch statistics were asked for: they are what runs
+    assert out._op is None
+    assert torch.allclose(out.F, torch.nn.functional.batch_norm(f, None, None, training=True), atol=1e-5)
+    assert int(bn.bn.num_batches_tracked) == 1
+
+
+def test_failure_inside_the_queue_poisons_later_reads():
+    c, f = _scene(ch=8)
+    conv = ME.MinkowskiConvolution(8, 8, kernel_size=3, dimension=3)
+    bn = ME.MinkowskiBatchNorm(8).train()
+    x = ME.SparseTensor(f, c)
+    a = conv(x)
+    b = bn(a)
+    orig = conv._forward_now
+    conv._forward_now = lambda *a_, **k_: (_ for _ in ()).throw(ValueError("boom"))
+    try:
+        with pytest.raises(ValueError):
+            b.F
+    finally:
+        conv._forward_now = orig
+    with pytest.raises(RuntimeError, match="boom"):
+        b.F
+    with pytest.raises(RuntimeError, match="boom"):
+        a.F
+
+
+def test_channel_mismatch_raises_at_the_call():
+    c, f = _scene(ch=8)
+    conv = ME.MinkowskiConvolution(8, 16, kernel_size=3, dimension=3)
+    bad = ME.MinkowskiConvolution(8, 8, kernel_size=3, dimension=3)
+    with pytest.raises(AssertionError, match="Channel size mismatch"):
+        bad(conv(ME.SparseTensor(f, c)))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="the reference's Python files exist in the build container only")
+def test_the_reference_files_unchanged_record_the_same_units_and_match_the_build_model():
+    """/root/reference/models/res16unet.py + modules/resnet_block.py imported as they are: their forward is recorded as the same
+    fused units as the build's models.py and computes the same logits (the build model IS that call sequence)."""
+    sys.path.insert(0, "/root/reference")
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "models" or k.startswith("models.")}
+    try:
+        from models import load_model as ref_load
+        c, f = _scene(1500)
+        ref = deterministic_init(ref_load("Res16UNet34C")(3, 20, Cfg()), 42).train()
+        mine = deterministic_init(models.load_model("Res16UNet34C")(3, 20, Cfg()), 42).train()
+        assert [k for k, _ in ref.state_dict().items()] == [k for k, _ in mine.state_dict().items()]
+        xr, xm = ME.SparseTensor(f, c), ME.SparseTensor(f, c)
+        lr_, _ = ref(xr)
+        lm, _ = mine(xm)
+
+        def units(x):
+            return [(op.kind, type(op.mod).__name__, op.relu, op.residual is not None) for op in x.coordinate_manager._pending]
+        assert units(xr) == units(xm) and len(units(xr)) == 63 + 62 + 4
+        assert torch.equal(lr_.F, lm.F)
+        deferred.ENABLED = False
+        ref2 = deterministic_init(ref_load("Res16UNet34C")(3, 20, Cfg()), 42).train()
+        l2, _ = ref2(ME.SparseTensor(f, c))
+        assert torch.equal(l2.F, lr_.F)
+    finally:
+        sys.path.remove("/root/reference")
+        for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)

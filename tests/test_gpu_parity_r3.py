@@ -299,10 +299,11 @@ def test_insseg_step_at_size_vs_oracle(frozen):
 @pytest.mark.parametrize("name,dtype,bucketed", [("Res16UNet34C", torch.bfloat16, True), ("Res16UNet14A", torch.float32, False),
                                                  ("Res16UNet34D", torch.bfloat16, True)])
 def test_block_fast_path_is_the_op_by_op_path(name, dtype, bucketed):
-    """models._BasicBlockFunction issues the same engine calls as the module-by-module BasicBlock.forward: logits, running
+    """me.block._BasicBlockFunction (what the deferred executor runs a recorded residual block as) issues the same engine calls as the
+    module-by-module sequence: logits, running
     statistics and every parameter gradient must be IDENTICAL (deterministic kernels, same arguments, same order; the one
     in-place add of the residual-branch gradient is autograd's own accumulation), with and without gradient buckets"""
-    from languagegroundedsemseg_amd import models
+    from languagegroundedsemseg_amd.me import block as models      # the whole-block node lives behind the ME surface since round 5
     from languagegroundedsemseg_amd.ddp import BucketedDDP
     from languagegroundedsemseg_amd.losses import fused_cross_entropy
     from languagegroundedsemseg_amd.synthetic import make_batch

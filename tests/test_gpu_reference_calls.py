@@ -1,0 +1,140 @@
+"""The reference's own call sequence on HIP (round-4 review: "the measured path is not the drop-in path").
+
+models.py issues /root/reference/models/modules/resnet_block.py:41-57 and /root/reference/models/res16unet.py:196-270 call for
+call -- norm(x); MinkowskiReLU(inplace=True)(x); out += residual; relu; me.cat(out, skip) -- with standard MinkowskiEngine
+signatures; tests/test_deferred_cpu.py shows the reference's unchanged files record the very same units.  Here, on the GPU:
+  * that sequence, executed fused by the deferred ME surface, against the CPU oracle: forward + backward, fp32 (logits <= 1e-3,
+    the north_star bar) for 14A and 34C at >= 60 k voxels; the bf16 layer-wise teacher-forced replay is
+    tests/test_gpu_teacher_forced.py (it observes the executor's units);
+  * the SAME sequence executed call by call (LGS_DEFER=0: unfused norm, nn.ReLU in place on a custom Function's output, add_ in
+    place, torch.cat copies) -- whole network forward + backward, i.e. every in-place op is autograd-legal -- against the oracle
+    and against the fused execution;
+  * what the executor made of the record: one whole-block node per residual block that is not a skip producer, four zero-copy
+    concats, no elementwise ReLU / add / cat launches."""
+import numpy as np
+import pytest
+import torch
+
+import MinkowskiEngine as ME
+from helpers import Cfg, deterministic_init
+from languagegroundedsemseg_amd.me import deferred
+from languagegroundedsemseg_amd.models import load_model
+from test_gpu_parity_r2 import ce_step, grad_report, on_oracle, rel_l2, structured_labels
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _scene(seed=7, n=70000):
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    coords, feats, _ = make_batch([seed], voxel=0.02, n_target=n)
+    return coords, feats, structured_labels(coords)
+
+
+def _with_defer(flag, fn):
+    was = deferred.ENABLED
+    deferred.ENABLED = flag
+    try:
+        return fn()
+    finally:
+        deferred.ENABLED = was
+
+
+_ORACLE = {}
+
+
+def _oracle(name, coords, feats, labels):
+    if name not in _ORACLE:
+        _ORACLE[name] = on_oracle(lambda: ce_step(name, coords, feats, labels, "cpu", torch.float32), "torch")
+    return _ORACLE[name]
+
+
+@pytest.mark.parametrize("name", ["Res16UNet14A", "Res16UNet34C"])
+@pytest.mark.parametrize("defer", [True, False], ids=["fused", "call_by_call"])
+def test_reference_call_sequence_fp32_forward_backward_within_1e3_of_oracle(name, defer):
+    coords, feats, labels = _scene()
+    assert coords.shape[0] >= 60000
+    o_logits, o_loss, o_g = _oracle(name, coords, feats, labels)
+    blocks0 = deferred.STATS["blocks"]
+    h_logits, h_loss, h_g = _with_defer(defer, lambda: ce_step(name, coords, feats, labels, DEV, torch.float32))
+    err = float(np.abs(h_logits - o_logits).max())
+    errs, tot = grad_report(h_g, o_g, "%s fp32 %s vs oracle" % (name, "fused" if defer else "call by call"))
+    print("%s (%d voxels, %s): max |logit - oracle| %.2e, loss %.6f vs %.6f" % (name, coords.shape[0], "fused" if defer else "call by call",
+                                                                                 err, h_loss, o_loss))
+    assert err < 1e-3 and abs(h_loss - o_loss) < 1e-4
+    assert tot < 1e-2                                            # measured ~3e-3 (ReLU gate flips at fp32 round-off)
+    n_blocks = {"Res16UNet14A": 8 - 3, "Res16UNet34C": 23 - 3}[name]     # all but the skip producers (last block of block1..3)
+    assert deferred.STATS["blocks"] - blocks0 == (n_blocks if defer else 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_fused_execution_equals_the_call_by_call_sequence(dtype):
+    """same network, same weights, same scene: the record executed fused vs every call executed as it is made.  fp32: the fused
+    kernel adds the residual to the un-rounded norm output exactly as `add_` does on the fp32 tensor -> agreement to round-off;
+    bf16: the call-by-call path rounds the norm output to bf16 before the add / ReLU, the fused kernel rounds once."""
+    from languagegroundedsemseg_amd import engine
+    coords, feats, labels = _scene(seed=5, n=30000)
+
+    def run():
+        engine.dispatch_counts(reset=True)
+        out = ce_step("Res16UNet34C", coords, feats, labels, DEV, dtype)
+        return out, engine.dispatch_counts()
+
+    hints0 = deferred.STATS["cat_hints"]
+    (fl, floss, fg), fsites = _with_defer(True, run)
+    assert deferred.STATS["cat_hints"] == hints0 + 4
+    (cl, closs, cg), csites = _with_defer(False, run)
+    e = rel_l2(fl, cl)
+    _, tot = grad_report(fg, cg, "34C %s fused vs call by call" % dtype)
+    print("34C %s fused vs call by call: logits rel-L2 %.3e, loss %.6f vs %.6f" % (dtype, e, floss, closs))
+    if dtype == torch.float32:
+        assert e < 1e-5 and abs(floss - closs) < 1e-5 and tot < 5e-3
+    else:
+        assert e < 3e-2 and abs(floss - closs) < 5e-3
+    # the fused execution is one engine call per block: its launches come from lgs_block_forward / lgs_block_backward
+    fblk = sum(v for k, v in fsites.items() if "lgs_block" in k)
+    cblk = sum(v for k, v in csites.items() if "lgs_block" in k)
+    print("launch sites fused %d / call by call %d; block-call launches %d / %d" % (len(fsites), len(csites), fblk, cblk))
+
+
+def test_call_by_call_inplace_ops_are_autograd_legal_and_match_torch():
+    """norm(x) -> relu_ -> conv -> norm -> += residual -> relu_ with every call executed immediately: the in-place ReLU and add run
+    on outputs of the engine's autograd Functions (which save their inputs, never their outputs' storage), backward runs, and the
+    gradients equal the same block written with torch ops on the engine's conv output."""
+    from languagegroundedsemseg_amd.models import BasicBlock
+    torch.manual_seed(0)
+    coords, feats, _ = _scene(seed=3, n=20000)
+    c = torch.from_numpy(coords).to(DEV)
+    f = torch.randn(coords.shape[0], 32, device=DEV)
+
+    def run(defer):
+        blk = deterministic_init(BasicBlock(32, 32, D=3), 5).to(DEV).train()
+        x = ME.SparseTensor(f.clone().requires_grad_(True), c)
+        y = _with_defer(defer, lambda: blk(x).F)
+        (y * torch.linspace(-1, 1, 32, device=DEV)).sum().backward()
+        return y.detach(), x.F.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}
+
+    a, b = run(True), run(False)
+    assert torch.allclose(a[0], b[0], atol=1e-5, rtol=1e-5)
+    assert torch.allclose(a[1], b[1], atol=1e-5, rtol=1e-4)
+    for k in a[2]:
+        assert torch.allclose(a[2][k], b[2][k], atol=1e-4, rtol=1e-3), k
+
+
+def test_intermediates_of_a_fused_block_say_so_when_read():
+    from languagegroundedsemseg_amd.models import BasicBlock
+    coords, feats, _ = _scene(seed=3, n=20000)
+    c = torch.from_numpy(coords).to(DEV)
+    blk = deterministic_init(BasicBlock(32, 32, D=3), 5).to(DEV).train()
+    x = ME.SparseTensor(torch.randn(coords.shape[0], 32, device=DEV), c)
+    mid = blk.conv1(x)                   # someone keeps the first convolution's output ...
+    out = blk.norm1(mid)
+    out = blk.relu(out)
+    out = blk.conv2(out)
+    out = blk.norm2(out)
+    out += x
+    out = blk.relu(out)
+    n0 = deferred.STATS["blocks"]
+    assert torch.isfinite(out.F).all() and deferred.STATS["blocks"] == n0 + 1
+    with pytest.raises(RuntimeError, match="fused"):
+        mid.F                            # ... and is told why it has no value (and how to get one)

@@ -26,6 +26,7 @@ import torch
 
 import MinkowskiEngine as ME
 from helpers import Cfg, deterministic_init
+from languagegroundedsemseg_amd.me import deferred
 from languagegroundedsemseg_amd.models import load_model
 from oracle.backend import OracleBackend
 
@@ -51,10 +52,14 @@ class OracleTape:
     """forward hooks on every conv / norm module of the ORACLE model: x, residual, y, and (tensor hook) dL/dy"""
 
     def __init__(self, model):
-        self.rec, self.coords, self.handles = {}, {}, []
-        for name, m in model.named_modules():
-            if _is_unit(m):
-                self.handles.append(m.register_forward_hook(self._hook(name), with_kwargs=True))
+        # the models issue the reference's call sequence (norm(x); relu in place; out += residual; me.cat), which the ME surface
+        # records and executes fused (me/deferred.py): the units of that execution -- conv, norm (+residual) (+ReLU) with the
+        # arguments it runs with -- are observed through the executor's unit hooks (same signature as torch's with_kwargs hooks)
+        self.rec, self.coords = {}, {}
+        names = {m: name for name, m in model.named_modules() if _is_unit(m)}
+        hooks = {m: self._hook(name) for m, name in names.items()}
+        self.pair = (lambda mod, args, kwargs: None, lambda mod, args, kwargs, out: hooks[mod](mod, args, kwargs, out) if mod in hooks else None)
+        deferred.UNIT_HOOKS.append(self.pair)
 
     def _hook(self, name):
         def fn(mod, args, kwargs, out):
@@ -72,8 +77,7 @@ class OracleTape:
         return fn
 
     def close(self):
-        for h in self.handles:
-            h.remove()
+        deferred.UNIT_HOOKS.remove(self.pair)
 
 
 class TeacherForcing:
@@ -84,10 +88,14 @@ class TeacherForcing:
         self.perm = {}                 # level -> oracle row of every HIP row
         self.fwd_err, self.bwd_err = {}, {}
         self.strided_inputs, self.strided_grads = [], []
-        for name, m in model.named_modules():
-            if _is_unit(m):
-                m.register_forward_pre_hook(self._pre(name), with_kwargs=True)
-                m.register_forward_hook(self._post(name), with_kwargs=True)
+        pre = {m: self._pre(name) for name, m in model.named_modules() if _is_unit(m)}
+        post = {m: self._post(name) for name, m in model.named_modules() if _is_unit(m)}
+        self.pair = (lambda mod, args, kwargs: pre[mod](mod, args, kwargs) if mod in pre else None,
+                     lambda mod, args, kwargs, out: post[mod](mod, args, kwargs, out) if mod in post else None)
+        deferred.UNIT_HOOKS.append(self.pair)
+
+    def close(self):
+        deferred.UNIT_HOOKS.remove(self.pair)
 
     def _to_hip(self, t, st):
         lv = _level(st)
@@ -150,9 +158,11 @@ def oracle_tape(model_name, coords, feats, loss_fn, n_out, cache_key=None):
             loss_fn.prepare(mo)
         tape = OracleTape(mo)
         xo = ME.SparseTensor(torch.from_numpy(feats).to(dtype), torch.from_numpy(coords))
-        lo = loss_fn(mo, xo, "cpu")
+        try:
+            lo = loss_fn(mo, xo, "cpu")
+        finally:
+            tape.close()
         lo.backward()
-        tape.close()
         go = {k: p.grad.detach().float() for k, p in mo.named_parameters() if p.grad is not None}
     finally:
         ME.set_backend(prev)
@@ -177,7 +187,10 @@ def run_teacher_forced(model_name, coords, feats, loss_fn, n_out, cache_key=None
     ddp = BucketedDDP(mh, bucket_mb=32.0)
     ddp.zero_grad()
     xh = ME.SparseTensor(torch.from_numpy(feats).to(DEV).to(dtype), torch.from_numpy(coords).to(DEV))
-    lh = loss_fn(mh, xh, DEV)
+    try:
+        lh = loss_fn(mh, xh, DEV)
+    finally:
+        tf.close()
     lh.backward()
     ddp.finalize()
     if DEV != "cpu":
