@@ -167,7 +167,10 @@ class ContrastiveLanguageLoss(nn.Module):
           l1: mean_j sum_c (f_c - t_jc) -- the reference sums SIGNED differences (no abs; reproduced as written) = sum(f) - sum(t_j).
         Not the measured path (config.py:159 defaults to 'cos', which owns the fused kernels): plain torch device ops."""
         f, t = features.float(), anchors.float()
-        lab = labels.clamp_min(0)
+        # a label outside [0, A) is an ignored row (what the fused cos kernel and the CE kernel do), never an index: a
+        # non-negative ignore_label such as 255 with 200 anchors must not reach the gathers
+        valid = (labels != ignore_label) & (labels >= 0) & (labels < t.shape[0])
+        lab = torch.where(valid, labels, torch.zeros_like(labels))
         if self.distance_type == "l1":
             fs, ts = f.sum(1), t.sum(1)
             d_pos = fs - ts[lab]
@@ -176,7 +179,6 @@ class ContrastiveLanguageLoss(nn.Module):
             d2 = ((f * f).sum(1)[:, None] - 2.0 * (f @ t.t()) + (t * t).sum(1)[None, :]).clamp_min(0)
             d_pos = torch.sqrt(d2.gather(1, lab[:, None]).squeeze(1) + 1e-7)
             d_neg = torch.sqrt(d2.gather(1, neg_indices) + 1e-7).mean(1)
-        valid = labels != ignore_label
         zero = torch.zeros((), dtype=d_pos.dtype, device=d_pos.device)
         return torch.where(valid, d_pos, zero), torch.where(valid, d_neg, zero)
 
@@ -209,8 +211,8 @@ class ContrastiveLanguageLoss(nn.Module):
             # > 224 anchors, more than 7 negatives, or the CPU oracle backend of the tests: dense similarity matrix + index
             # gathers (learned anchor projections take the fused path too: lgs_clip_loss_backward_anchors)
             sim = clip_similarity(features, anchor_feats)         # [N, num_labels] -- the MFMA contraction
-            valid = labels != ign
-            lab = labels.clamp_min(0)
+            valid = (labels != ign) & (labels >= 0) & (labels < sim.shape[1])
+            lab = torch.where(valid, labels, torch.zeros_like(labels))
             d_pos = 1.0 - sim.gather(1, lab[:, None]).squeeze(1)
             d_neg = 1.0 - sim.gather(1, neg_indices).mean(1)
             zero = torch.zeros((), dtype=sim.dtype, device=sim.device)
@@ -273,16 +275,65 @@ class ReferenceContrastiveLanguageLoss(ContrastiveLanguageLoss):
         self.num_negative_samples = k
         self.register_buffer("confusion_hist", torch.zeros((num_labels, num_labels)).long())
         self.augment_categories = torch.empty(0)
+        # latent attribute augmentation (:46-60): eight learned linear maps ("A red ", ..., "A small "), weights from
+        # config.scannet_path / config.projection_model_path when that file exists (else the module's initial weights, as in
+        # the reference), eval mode
+        import os
+        import numpy as np
+        from .projection_models import AttributeFittingModel
+        self.attributes = np.array(['A red ', 'A green ', 'A blue ', 'A yellow ', 'A dark ', 'A bright ', 'A big ', 'A small '])
+        self.augment_probability = float(getattr(config, "instance_augmentation_color_aug_prob", 0.0))
+        self.projection_model = AttributeFittingModel(feature_dim, feature_dim, self.attributes.shape[0])
+        model_path = "%s/%s" % (getattr(config, "scannet_path", ""), getattr(config, "projection_model_path", ""))
+        if os.path.isfile(model_path):
+            self.projection_model.load_state_dict(torch.load(model_path))
+        self.projection_model.eval()
 
-    def forward(self, features, labels, anchor_feats, preds=None, neg_indices=None):
+    def plan_latent_augmentation(self, generator=None, device="cpu"):
+        """The reference decides per unique (category, attribute) target of the batch, inside a thread pool, with the host RNGs
+        (`random.random() < p`, then `np.random.randint(0, 8)`, :62-70).  Here ONE independent draw per possible (category,
+        attribute-slot) pair, on the device, no host loop: -> (augment? [L * A] bool, new attribute [L * A] int64) for A slots."""
+        A = self.attributes.shape[0] + 1                                   # slot 0 = the raw category, 1..8 = attributes
+        u = torch.rand(self.num_labels * A, generator=generator, device=device)
+        k = torch.randint(0, self.attributes.shape[0], (self.num_labels * A,), generator=generator, device=device)
+        return u < self.augment_probability, k
+
+    def latent_augmentation(self, features, labels, plan=None, generator=None):
+        """ContrastiveLanguageLoss.py:62-70,160-165 for the whole batch at once: rows whose category is in `augment_categories`
+        and whose (category, attribute) target drew "augment" are replaced IN PLACE (like the reference's
+        `features[ut_inds, :] = aug_feats`) by attribute a's projection of themselves; their attribute label becomes a and the
+        positive anchor slot a + 1 (:68, `current_aug + 1`).  -> (features, labels, positive attribute slot [N])"""
+        cat, att = labels[:, 0].long(), labels[:, 1].long()
+        A = self.attributes.shape[0] + 1
+        dev = features.device
+        if plan is None:
+            plan = self.plan_latent_augmentation(generator, dev)
+        on, new_attr = plan[0].to(dev), plan[1].to(dev)
+        cats = self.augment_categories.to(dev).long()
+        in_aug = torch.zeros(self.num_labels + 1, dtype=torch.bool, device=dev)
+        if cats.numel():
+            in_aug[cats.clamp(0, self.num_labels)] = True
+        valid = (cat != self.ignore_label) & (cat >= 0) & (cat < self.num_labels) & (att >= 0) & (att < A)
+        pair = torch.where(valid, cat * A + att, torch.zeros_like(cat))
+        do = valid & in_aug[torch.where(valid, cat, torch.full_like(cat, self.num_labels))] & on[pair]
+        k = new_attr[pair]
+        idx = do.nonzero().squeeze(1)                                      # (one host sync; the reference loops over classes)
+        if self.projection_model.attr_linears[0].weight.device != dev:
+            self.projection_model = self.projection_model.to(dev)
+        if idx.numel():
+            proj = self.projection_model.project(features[idx].float(), k[idx])
+            features.index_copy_(0, idx, proj.to(features.dtype))
+        labels[:, 1] = torch.where(do, k, att).to(labels.dtype)
+        return features, labels, torch.where(do, k + 1, att)
+
+    def forward(self, features, labels, anchor_feats, preds=None, neg_indices=None, aug_plan=None):
         if labels.dim() == 2:                                        # (category, attribute) targets, :149-181
-            if getattr(self.config, "instance_augmentation", None) == "latent":
-                raise NotImplementedError("latent instance augmentation (ContrastiveLanguageLoss.py:160-165) needs the pretrained "
-                                          "AttributeFittingModel; it is outside the engine's hot path")
             if anchor_feats.dim() != 3:
                 raise ValueError("[N, 2] labels need [num_labels, num_attributes, C] anchors")
             A = anchor_feats.shape[1]
             cat, att = labels[:, 0].long(), labels[:, 1].long()
+            if getattr(self.config, "instance_augmentation", None) == "latent":
+                features, labels, att = self.latent_augmentation(features, labels, plan=aug_plan)
             if neg_indices is None:
                 neg_indices = self.sample_negatives(cat)
             valid = cat != self.ignore_label
@@ -293,6 +344,67 @@ class ReferenceContrastiveLanguageLoss(ContrastiveLanguageLoss):
                                   ignore_label=-1)
             return out[:3]
         return super().forward(features, labels, anchor_feats, neg_indices=neg_indices)[:3]
+
+
+class _ClipCE(torch.autograd.Function):
+    """cross-entropy over the cosine similarities to ALL anchors, one autograd node: forward = lgs_clip_similarity (the MFMA
+    contraction normalize(F) . normalize(T)^T, [N, A] fp32) + lgs_ce_forward_backward (loss only); backward = the CE kernel again
+    (d S, already scaled by the upstream gradient) pushed through dS/df = (t^ - s f^) / |f| (and dS/dT for learned anchors)."""
+
+    @staticmethod
+    def forward(ctx, feats, anchors, labels, ignore_index):
+        be = get_backend()
+        sim, inv = be.clip_similarity(feats, anchors)
+        loss, _, inv_valid = be.cross_entropy(sim, labels, ignore_index, want_grad=False)
+        ctx.save_for_backward(feats, anchors, sim, inv, labels, inv_valid)
+        ctx.ignore_index = ignore_index
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, anchors, sim, inv, labels, inv_valid = ctx.saved_tensors
+        _, gs, _ = get_backend().cross_entropy(sim, labels, ctx.ignore_index, grad_scale=g, inv_valid=inv_valid)
+        tn = torch.nn.functional.normalize(anchors.float(), dim=1)
+        fh = feats.float() * inv[:, None]
+        gf = ((gs @ tn - (gs * sim).sum(1, keepdim=True) * fh) * inv[:, None]).to(feats.dtype) if ctx.needs_input_grad[0] else None
+        ga = None
+        if ctx.needs_input_grad[1]:
+            an = anchors.float().norm(dim=1, keepdim=True).clamp_min(1e-12)
+            gt = gs.t() @ fh
+            ga = ((gt - (gt * tn).sum(1, keepdim=True) * tn) / an).to(anchors.dtype)
+        return gf, ga, None, None
+
+
+class ReferenceContrastiveLanguageCELoss(ReferenceContrastiveLanguageLoss):
+    """Drop-in for /root/reference/lib/losses/ContrastiveLanguageLoss.py:196-237 (`embedding_loss_type=contrast_ce`,
+    lib/train_test/pl_RepresentationTrainer.py:42-43): nn.CrossEntropyLoss(ignore_index, reduction) over the per-voxel
+    "distances" to ALL num_labels anchors -- for 'cos' literally normalize(F) . normalize(T)^T in [N, num_labels] (no temperature:
+    the reference never applies it), the one dense contraction of the hot path; for 'l2' sqrt(|f - t^|^2 + 1e-7) against the
+    NORMALISED anchors (as written, :208-211,:230).  forward(features, labels, anchor_feats, preds=None) -> (loss, zeros(1), loss)."""
+
+    def __init__(self, config, num_labels, temperature=0.07, base_temperature=0.07, reduction="mean"):
+        super().__init__(config, num_labels, temperature, base_temperature, reduction)
+
+    def forward(self, features, labels, anchor_feats, preds=None):
+        if features.dim() != 2:
+            raise ValueError("`features` needs to be [n_points, feat_dim]")
+        labels = labels.long()
+        be = get_backend()
+        if self.distance_type == "cos":
+            if (self.reduction == "mean" and hasattr(be, "cross_entropy") and features.is_cuda
+                    and anchor_feats.shape[0] <= 512 and features.dtype in (torch.float32, torch.bfloat16)):
+                loss = _ClipCE.apply(features, anchor_feats, labels, self.ignore_label)
+            else:
+                out = clip_similarity(features, anchor_feats)
+                loss = torch.nn.functional.cross_entropy(out, labels, ignore_index=self.ignore_label, reduction=self.reduction)
+        elif self.distance_type == "l2":
+            f = features.float()
+            t = torch.nn.functional.normalize(anchor_feats.float(), p=2, dim=1)
+            d2 = ((f * f).sum(1)[:, None] - 2.0 * (f @ t.t()) + (t * t).sum(1)[None, :]).clamp_min(0)
+            loss = torch.nn.functional.cross_entropy(torch.sqrt(d2 + 1e-7), labels, ignore_index=self.ignore_label, reduction=self.reduction)
+        else:
+            raise ValueError("ContrastiveLanguageCELoss supports representation_distance_type 'cos' and 'l2' (:206-220)")
+        return loss, torch.zeros(1), loss
 
 
 def sample_categories_for_balancing(loss, targets, frequency_organized_cats, head_ratio, common_ratio, ignore_label=-1,

@@ -119,6 +119,100 @@ def distance_fixture():
     print("distance fixture:", sorted(out)[:4], "...")
 
 
+def ce_and_latent_fixture():
+    """2e. contrastive_ce_latent.npz
+    (a) the reference's ContrastiveLanguageCELoss.forward (lib/losses/ContrastiveLanguageLoss.py:196-237) on CPU, 'cos' and 'l2';
+    (b) the reference's ContrastiveLanguageLoss.forward with (category, attribute) labels and instance_augmentation='latent'
+        (:62-70,:149-181) run on CPU: its two `torch.cuda.FloatTensor(...)` allocations are pointed at the CPU allocator for the
+        duration of the call, the joblib pool is one worker (sequential, in unique-target order), and the host RNG draws it makes
+        -- per unique target "augment?" / "which attribute", and the negatives -- are RECORDED so that the engine-side loss can be
+        given the same decisions explicitly (the reference's own draw order is not reproducible in a thread pool).
+        Every row's original attribute slot is 0, so no relabelled row is picked up a second time by a later unique target
+        (an order-dependent quirk of the reference loop that is not part of the fixture)."""
+    for mod in ("torchmetrics",):
+        if mod not in sys.modules:
+            sys.modules[mod] = types.SimpleNamespace(Metric=object)
+    import random
+    import lib.losses.ContrastiveLanguageLoss as RL
+    import models.projection_models as RP
+    out = {}
+    base = dict(ignore_label=-1, num_negative_samples=3, contrast_neg_thresh=0.6, contrast_pos_thresh=0.0, contrast_neg_weight=1.0,
+                instance_augmentation_color_aug_prob=0.0, scannet_path="/nonexistent", projection_model_path="none",
+                clip_uniform_sampling=True)
+    fx = np.load(os.path.join(HERE, "contrastive_loss.npz"))
+    # ---- (a)
+    for dist in ("cos", "l2"):
+        cfg = types.SimpleNamespace(representation_distance_type=dist, **base)
+        for tag in ("c512", "c96"):
+            crit = RL.ContrastiveLanguageCELoss(cfg, 200)
+            F = torch.from_numpy(fx[tag + "_F"]).clone().requires_grad_(True)
+            T, labels = torch.from_numpy(fx[tag + "_T"]), torch.from_numpy(fx[tag + "_labels"])
+            loss, z, loss2 = crit(F, labels, T)
+            loss.backward()
+            out["ce_%s_%s_loss" % (dist, tag)] = loss.detach().reshape(1).numpy()
+            out["ce_%s_%s_gradF" % (dist, tag)] = F.grad.numpy().astype(np.float32)
+    # ---- (b)
+    C, N, K, L, A = 96, 400, 3, 200, 9
+    g = torch.Generator().manual_seed(23)
+    F0 = torch.randn(N, C, generator=g)
+    T3 = torch.randn(L, A, C, generator=g)
+    cat = torch.randint(0, 12, (N,), generator=g)                      # a dozen categories, ~33 rows each
+    cat[torch.rand(N, generator=g) < 0.1] = -1
+    labels0 = torch.stack([cat, torch.zeros_like(cat)], 1)
+    cfg = types.SimpleNamespace(representation_distance_type="cos", instance_augmentation="latent", **base)
+    cfg.instance_augmentation_color_aug_prob = 0.7
+    torch.manual_seed(5)
+    crit = RL.ContrastiveLanguageLoss(cfg, L, feature_dim=C)
+    crit.num_cores = 1
+    crit.augment_categories = torch.tensor([0, 2, 3, 5, 7, 8, 11])
+    plan_on, plan_attr = np.zeros(L * A, bool), np.zeros(L * A, np.int64)
+    negs = []
+    orig_aug, orig_choice = crit.latent_augmentation, np.random.choice
+
+    def rec_aug(features, labels):
+        c0, a0 = int(labels[0, 0]), int(labels[0, 1])
+        f, l, attr_id = orig_aug(features, labels)
+        plan_on[c0 * A + a0] = attr_id > 0
+        plan_attr[c0 * A + a0] = max(attr_id - 1, 0)
+        return f, l, attr_id
+
+    def rec_choice(cands, size):
+        r = orig_choice(cands, size)
+        negs.append(r.copy())
+        return r
+    crit.latent_augmentation = rec_aug
+    cuda_float = getattr(torch.cuda, "FloatTensor", None)
+    fwd_attr = RP.AttributeFittingModel.forward
+    try:
+        torch.cuda.FloatTensor = torch.FloatTensor                     # fixture generation only: the reference allocates on "cuda"
+        np.random.choice = rec_choice
+        random.seed(3)
+        np.random.seed(4)
+        F = F0.clone()
+        labels = labels0.clone()
+        with torch.no_grad():
+            loss, pos_loss, neg_loss = crit(F, labels, T3)
+    finally:
+        np.random.choice = orig_choice
+        torch.cuda.FloatTensor = cuda_float
+    neg = torch.zeros(N, K, dtype=torch.long)
+    uts = [int(c) for c in torch.unique(cat) if int(c) != -1]
+    assert len(uts) == len(negs)
+    for c, r in zip(uts, negs):
+        neg[cat == c] = torch.from_numpy(r)
+    sd = crit.projection_model.state_dict()
+    out.update({"lat_F": F0.numpy(), "lat_T": T3.numpy(), "lat_labels": labels0.numpy(), "lat_neg": neg.numpy(),
+                "lat_augment_categories": crit.augment_categories.numpy(), "lat_plan_on": plan_on, "lat_plan_attr": plan_attr,
+                "lat_F_after": F.numpy(), "lat_labels_after": labels.numpy(), "lat_loss": loss.reshape(1).numpy(),
+                "lat_pos_loss": pos_loss.numpy(), "lat_neg_loss": neg_loss.numpy(),
+                "lat_proj_w": torch.stack([sd["attr_linears.%d.weight" % i] for i in range(8)]).numpy(),
+                "lat_proj_b": torch.stack([sd["attr_linears.%d.bias" % i] for i in range(8)]).numpy()})
+    np.savez_compressed(os.path.join(HERE, "contrastive_ce_latent.npz"), **out)
+    print("CE + latent fixture: ce losses", {k: float(v[0]) for k, v in out.items() if k.endswith("_loss") and k.startswith("ce_")},
+          "latent: %d of %d targets augmented, %d rows changed, loss %.5f" % (int(plan_on.sum()), len(uts),
+                                                                              int((F != F0).any(1).sum()), float(loss)))
+
+
 def _loss_utils():
     if "torchmetrics" not in sys.modules:
         sys.modules["torchmetrics"] = types.SimpleNamespace(Metric=object)
@@ -251,6 +345,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "distances":
         distance_fixture()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ce_latent":
+        ce_and_latent_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "losses":
         feature_sim_fixture()
         balancing_fixture()
@@ -258,6 +355,7 @@ if __name__ == "__main__":
     manifest()
     contrastive()
     distance_fixture()
+    ce_and_latent_fixture()
     feature_sim_fixture()
     balancing_fixture()
     forward_fixture("Res16UNet14A", 3, 1500)
