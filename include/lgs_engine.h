@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LGS_ABI_VERSION 10
+#define LGS_ABI_VERSION 11
 
 enum lgs_dtype { LGS_F32 = 0, LGS_BF16 = 1 };
 
@@ -75,13 +75,6 @@ int64_t lgs_debug_dispatch_counts(char *buf, int64_t cap, int reset);
  *   /root/reference/downstream/insseg/lib/pl_Trainer.py:263                                  */
 int lgs_manager_create(int device, lgs_manager **out);
 int lgs_manager_destroy(lgs_manager *mgr);
-/* Options of one manager, set before its maps are requested.  "halo" (0 / 1): 3^3 stride-1 kernel maps of at least
- * HALO_MIN_ROWS positions also get halo tables -- per 256-position tile the list of distinct input rows and the kernel map as
- * 16-bit slots into it -- which the bf16 convolutions of <= 128 channels then use (csrc/lgs_conv_halo.hip: every row is staged
- * once per tile in LDS instead of being gathered once per offset).  The host side sets it for bf16 feature tensors
- * (the call sites are the same SparseTensor constructions as above).  Unknown option -> error.                    */
-int lgs_manager_set_option(lgs_manager *mgr, const char *name, int64_t value);
-
 /* Insert coords[N,4] as the tensor-stride-1 map.  Dedups (first occurrence wins, surviving
  * rows keep input order).  Writes the map key to *key and the unique-row count to *n_unique
  * (host; this call synchronises `stream` once).
@@ -94,6 +87,12 @@ int lgs_manager_insert(lgs_manager *mgr, const int32_t *coords, int64_t n, int64
  * replaces: the output-coordinate generation inside conv(kernel_size=2, stride=2)
  *   /root/reference/models/res16unet.py:49-56,66-73,83-90,100-107                              */
 int lgs_manager_stride2(lgs_manager *mgr, int in_key, void *stream, int *out_key, int64_t *n_out);
+/* Device-side consistency flags of this manager's maps, read back with ONE synchronisation of the manager's map stream
+ * (test / debug infrastructure: the map builders size coarse maps from counts taken at insert time and never synchronise;
+ * a builder that finds its own count disagreeing raises the flag instead of writing past its arrays).  *flags: 0 = consistent,
+ * bit 0 = coordinate out of the key range at insert, bit 1 = a coarse map's row count differs from the insert-time count.
+ * Same call sites as lgs_manager_stride2.                                                                             */
+int lgs_manager_check(lgs_manager *mgr, int *flags);
 
 /* Finer map that `key` was coarsened from (-1 if none); used by transposed convs to land on the
  * cached map (/root/reference/models/res16unet.py:116-124 + me.cat at :237). */

@@ -35,7 +35,7 @@ void set_error(const std::string &msg);
 // ---- tuning table + dispatch counters (lgs_tuning.hip)
 enum Tune {
   T_WW_MIN_ROWS, T_WW_RANGE, T_WGRAD_WIDE, T_BN_FUSED, T_BN_FUSED_MAX_MB, T_BN_FUSED_FWD_MAX_MB, T_BN_FUSED_BLOCKS, T_PS_CUS, T_PS_WIDE3, T_WGRAD_PS,
-  T_MASK_WINDOW, T_CONV_SPLIT, T_SMALL_CFG, T_WIDE_GC64, T_WIDE_DBG, T_WIDE_TRACE, T_ARENA_DBG, T_CONV_WIDE, T_HALO, T_HALO_MIN_ROWS, T_HALO_TRACE, T_MASK_ORDER,
+  T_MASK_WINDOW, T_CONV_SPLIT, T_SMALL_CFG, T_WIDE_GC64, T_WIDE_DBG, T_WIDE_TRACE, T_ARENA_DBG, T_CONV_WIDE, T_MASK_ORDER,
   T_COUNT
 };
 int64_t tune(Tune t);                                                   // current value (environment LGS_<NAME> at start, lgs_tuning_set later)
@@ -70,22 +70,6 @@ struct View {
   int mirror = 0;     // weight index = K-1-s (the 3^3 map read in the dgrad direction)
 };
 
-// HALO tables of a 3^3 stride-1 map (lgs_conv_halo.hip): the map's positions in a second order -- Morton order, re-sorted by
-// neighbourhood mask inside TILES of kHaloT positions only -- with, per tile, the list of DISTINCT input rows its 27 x kHaloT
-// kernel-map entries touch (a 256-position Morton tile of a surface scan touches ~380, p95 ~430) and every entry rewritten as a
-// 16-bit slot into that list.  A convolution stages the tile's rows ONCE in LDS (one LDS-DMA instruction per ~5 rows) instead
-// of asking for a row once per offset it is a neighbour at (k_conv_gather: 713 gather instructions per 256 positions, 45 % of
-// them blocks without a single neighbour; the kernel sat on the CU's vector-memory issue rate).
-constexpr int kHaloT = 256;       // positions per tile
-constexpr int kHaloS = 1024;      // row-list stride per tile (int32 entries); tiles with more distinct rows are flagged (count = -1)
-struct HaloView {
-  View v;                            // the same map in halo position order: nbr / mask64 / out_row as for any View
-  const uint16_t *lnbr = nullptr;    // [27][n_pad] slot of the neighbour row in the tile's list, 0xffff = none
-  const int32_t *urows = nullptr;    // [n_pad / kHaloT][kHaloS] distinct input rows of the tile (first ucount entries)
-  const int32_t *ucount = nullptr;   // [n_pad / kHaloT] number of distinct rows, -1 = more than kHaloS (per-offset staging)
-  bool ok = false;
-};
-
 inline int pad32(int c) { return (c + 31) / 32 * 32; }
 inline int esize(int dtype) { return dtype == LGS_BF16 ? 2 : 4; }
 inline int epl(int dtype) { return dtype == LGS_BF16 ? 8 : 4; }
@@ -113,11 +97,6 @@ int launch_conv_wide(const View &v, const void *in, int cin_real, int in_ld, con
 int64_t wgrad_wide_workspace_bytes(const View &v, int cin, int cout);
 int conv_wgrad_wide(const View &v, const void *in, int cin, int in_ld, const void *gout, int cout, float *gw, void *workspace,
                     hipStream_t s, bool *done);
-// lgs_conv_halo.hip: per-tile distinct-row 3^3 convolution forward / dgrad for <= 128 channels (bf16)
-bool conv_halo_supported(const HaloView &hv, int g_real, int o_real, int K);
-int64_t conv_halo_pack_layout(int g_real, int o_real, int *ncp, int *nbp);   // packed-image chunk / block counts of this shape
-int launch_conv_halo(const HaloView &hv, int mirror, const void *in, int g_real, int in_ld, const void *wp, int ncp, int nbp,
-                     void *out, int o_real, const float *bias, int accum, hipStream_t s);
 // order `stream` after the construction of km's manager's maps (they are built on the manager's own stream)
 int kmap_wait(lgs_kmap *km, hipStream_t stream);
 
@@ -128,5 +107,4 @@ struct lgs_kmap {
   int in_key = -1, out_key = -1, ks = 0, K = 1;
   lgs::View fwd;  // gathers from the in map, writes the out map
   lgs::View bwd;  // gathers from the out map, writes the in map (dgrad / transposed conv)
-  lgs::HaloView halo;  // 3^3 maps of managers with the "halo" option: serves forward and (mirror = 1) dgrad
 };

@@ -161,10 +161,6 @@ struct BnEpi {
   float *partial = nullptr;     // [gridDim.x][2][cout_real]
   const float *pivot = nullptr; // [cout_real] or NULL
   int accum = 0;                // 1: out += result (lgs_conv_dgrad_accumulate: the residual branch's gradient is already in `out`)
-#ifdef LGS_CONV_DBG
-  int dbg = 0;                  // knock-out bits of an EXPERIMENT build (-DLGS_CONV_DBG, results wrong): 1 no MFMA, 2 no gathers, 4 no weight loads
-  unsigned long long *trace = nullptr;   // [4]: shader clocks of workgroup 0 / wave 0: start -> first barrier -> end of the main loop -> end
-#endif
 };
 // four adjacent stored elements -> fp32 (one 8- or 16-byte access)
 __device__ inline void load4(const float *p, float (&v)[4]) { const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
@@ -321,11 +317,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     act = 0;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-#ifdef LGS_CONV_DBG
-      const bool ok = idx_i[rb] >= 0 && !(be.dbg & 2);
-#else
       const bool ok = idx_i[rb] >= 0;
-#endif
       if (__ballot(idx_i[rb] >= 0)) act |= 1u << rb;
       const unsigned base = ok ? (unsigned)idx_i[rb] * row_bytes + (unsigned)(ichunk * 32 + h * 16) * (unsigned)sizeof(T) : kOOB;
 #pragma unroll
@@ -366,9 +358,6 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   auto wissue = [&](u32x4 (&wreg)[WR]) __attribute__((always_inline)) {
     const int kw = v.KS > 1 ? wslot : kw_single;  // 3^3 dgrad mirroring (K-1-k) is folded into the weight packing
     const unsigned sbase = (unsigned)((((int64_t)kw * ncp + wslab * SC) * nbp + nb_wg) * (LD * 64) * 16);
-#ifdef LGS_CONV_DBG
-    if (be.dbg & 4) return;
-#endif
 #pragma unroll
     for (int i = 0; i < WR; ++i) wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[i], sbase, 0);
   };
@@ -382,9 +371,6 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   float sumsq = 0.f;   // EPI = 1: |f|^2 of this lane's channel half of row vx
   auto compute = [&](int buf, int cc, const u32x4 (&F)[RB][LD], uint32_t act) __attribute__((always_inline)) {
     if (act == 0) return;
-#ifdef LGS_CONV_DBG
-    if (be.dbg & 1) return;
-#endif
     if constexpr (EPI == 1) {
 #pragma unroll
       for (int t = 0; t < LD; ++t) sumsq = sq16<T>(F[0][t], sumsq);
@@ -419,11 +405,6 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   // Prologue: the first weight slab and ALL index loads of the tile are in flight together, one barrier publishes
   // both (a slot-by-slot index copy loop was a chain of ~16 dependent global-load latencies at the head of every
   // workgroup -- a quarter of its lifetime -- and the first weight fetch only started behind it).
-#ifdef LGS_CONV_DBG
-  const bool trw = be.trace != nullptr && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && wave == 0;
-  unsigned long long tq0 = 0, tq1 = 0, tq2 = 0;
-  if (trw) tq0 = __builtin_amdgcn_s_memtime();
-#endif
   const bool whave = wadvance();
   if (whave) wissue(wreg);
   // kernel-map rows of the tile: SIXTEEN-byte loads, four consecutive positions of one offset per lane (the table is
@@ -478,9 +459,6 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     if (wnext) { pslab = wslab; wissue(wreg); }
   }
   __syncthreads();   // indices and the first weight slab are visible
-#ifdef LGS_CONV_DBG
-  if (trw) tq1 = __builtin_amdgcn_s_memtime();
-#endif
   const int total = __builtin_popcount(fmask) * nc;  // chunks of this wave
 #pragma unroll
   for (int d = 0; d < D - 1; ++d) {
@@ -526,9 +504,6 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     }
   }
 
-#ifdef LGS_CONV_DBG
-  if (trw) tq2 = __builtin_amdgcn_s_memtime();
-#endif
   if constexpr (EPI == 1) {
     // ---- CLIP-loss epilogue.  The weight LDS is idle now: every wave parks one 32 x 32 block of its similarity tile
     // there at a time (row stride 36 floats) so that a lane can pick the entries of ITS row's label / negatives with
@@ -691,11 +666,6 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
     }
   }
 stats:
-#ifdef LGS_CONV_DBG
-  if (trw && lane == 0) {
-    be.trace[0] = tq1 - tq0; be.trace[1] = tq2 - tq1; be.trace[2] = __builtin_amdgcn_s_memtime() - tq2; be.trace[3] = (unsigned long long)total;
-  }
-#endif
   if constexpr (EPI == 0) {
     if (be.partial != nullptr) {   // kernel-uniform
       // ---- BatchNorm statistics of this workgroup's rows.  Lane (vx, h) holds, per row block, the 16 NCB channels
@@ -853,14 +823,6 @@ inline int64_t split_partial_bytes(int K, int64_t n_out, int o_real) {
 // k_sum_partials or not at all)
 inline BnEpi bn_epi(const BnEpi *bn, bool did_split) {
   BnEpi e = (bn && !did_split) ? *bn : BnEpi();
-#ifdef LGS_CONV_DBG
-  e.dbg = getenv("LGS_CONV_DBG") ? atoi(getenv("LGS_CONV_DBG")) : 0;
-  if (getenv("LGS_CONV_TRACE")) {
-    static unsigned long long *tr = nullptr;
-    if (!tr) (void)hipMalloc(&tr, 4 * sizeof(unsigned long long));
-    e.trace = tr;
-  }
-#endif
   return e;
 }
 
@@ -922,16 +884,6 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
     default: LGS_LAUNCH(1, 1, 2, 2, (kF32 ? 2 : 4), (kF32 ? 4 : 8)); break;
   }
 #undef LGS_LAUNCH
-#ifdef LGS_CONV_DBG
-  if (getenv("LGS_CONV_TRACE")) {
-    BnEpi e = bn_epi(bn, did_split);
-    unsigned long long h[4];
-    (void)hipStreamSynchronize(s);
-    (void)hipMemcpy(h, e.trace, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[k_conv_gather trace] cfg %d rows %lld %d->%d z=%d: prologue %llu  main loop %llu (%llu chunk iterations = %llu cycles each)  epilogue %llu\n",
-            cfg.id, (long long)v.n_out, cin_real, cout_real, did_split ? 3 : 1, h[0], h[1], h[3], h[3] ? h[1] / h[3] : 0ull, h[2]);
-  }
-#endif
   if (did_split) {
     const int64_t n4 = zstride / 4;
     if (n4 > 0) LGS_KLAUNCH((k_sum_partials<T>), (unsigned)((n4 + 255) / 256), 256, 0, s, zpartial, n4, zstride, bias, cout_real, out,
@@ -1143,26 +1095,6 @@ int pack_desc_t(const View &v, int K, int cin_w, int cout_w, int transposed_w, i
   return 0;
 }
 
-// ---- per-tile distinct-row kernel (lgs_conv_halo.hip) for 3^3 maps that carry halo tables: bf16, forward and dgrad
-inline bool halo_takes(const lgs_kmap *km, int transposed, int g_real, int o_real, int dtype, int in_ld) {
-  return km && km->ks == 3 && !transposed && dtype == LGS_BF16 && (in_ld == 0 || (in_ld * 2) % 16 == 0) &&
-         conv_halo_supported(km->halo, g_real, o_real, km->K);
-}
-// op 0 forward / 1 dgrad on the halo view: pack (unless the caller's image is up to date) and launch
-int conv_halo_op(lgs_kmap *km, int op, const void *in, int g_real, const float *weight, int cin_w, int cout_w, int o_real,
-                 const float *bias, void *out, void *workspace, hipStream_t s, int accum, void *packed_ext, int pack_mode, int in_ld) {
-  int ncp = 0, nbp = 0;
-  const int64_t total = conv_halo_pack_layout(g_real, o_real, &ncp, &nbp);
-  LGS_REQUIRE(total > 0, "halo conv: unsupported shape (internal error)");
-  uint4 *wp = reinterpret_cast<uint4 *>(packed_ext ? packed_ext : workspace);
-  if (!packed_ext) pack_mode = 0;
-  if (pack_mode != 2)
-    LGS_KLAUNCH((k_pack_weights<bf16_t>), (unsigned)((total + 255) / 256), 256, 0, s, weight, km->K, cin_w, cout_w, op, op, g_real, o_real,
-                ncp, nbp, wp);
-  LGS_HIP(hipGetLastError());
-  return launch_conv_halo(km->halo, op, in, g_real, in_ld, wp, ncp, nbp, out, o_real, bias, accum, s);
-}
-
 }  // namespace lgs
 
 using namespace lgs;
@@ -1185,7 +1117,6 @@ int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtyp
 
 int lgs_conv_bn_partial_rows(const lgs_kmap *km, int transposed, int cout, int dtype) {
   if (!km) return 0;
-  if (km->ks == 3 && km->halo.ok && dtype == LGS_BF16) return 0;    // the halo kernel has no statistics epilogue (any input width)
   const View &v = transposed ? km->bwd : km->fwd;
   if (dtype == LGS_F32) return bn_partial_rows_t<float>(v, km->K, cout);
   if (dtype == LGS_BF16) return bn_partial_rows_t<bf16_t>(v, km->K, cout);
@@ -1197,14 +1128,6 @@ int lgs_conv_pack_desc(const lgs_kmap *km, int op, int transposed, int cin, int 
   const View &v = op == 0 ? (transposed ? km->bwd : km->fwd) : (transposed ? km->fwd : km->bwd);
   const int mirror = (op == 1 && km->ks == 3) ? 1 : 0;
   const int g = op == 0 ? cin : cout, o = op == 0 ? cout : cin;
-  if (halo_takes(km, transposed, g, o, dtype, 0)) {
-    memset(out, 0, sizeof(*out));
-    out->total = conv_halo_pack_layout(g, o, &out->ncp, &out->nbp);
-    out->bytes = out->total * 16;
-    out->K = km->K; out->cin_w = cin; out->cout_w = cout; out->transposed = op; out->mirror = mirror;
-    out->g_real = g; out->o_real = o; out->dtype = dtype;
-    return 0;
-  }
   if (dtype == LGS_F32) return pack_desc_t<float>(v, km->K, cin, cout, op, mirror, g, o, dtype, out);
   if (dtype == LGS_BF16) return pack_desc_t<bf16_t>(v, km->K, cin, cout, op, mirror, g, o, dtype, out);
   LGS_REQUIRE(false, "lgs_conv_pack_desc: unknown dtype");
@@ -1231,8 +1154,6 @@ int lgs_conv_forward(lgs_kmap *km, int transposed, const void *in, int cin, cons
   bn.partial = bn_partial; bn.pivot = bn_pivot;
   LGS_REQUIRE(!bn_partial || lgs_conv_bn_partial_rows(km, transposed, cout, dtype) > 0,
               "lgs_conv_forward: this launch shape produces no BatchNorm statistics (see lgs_conv_bn_partial_rows)");
-  if (halo_takes(km, transposed, cin, cout, dtype, in_row_stride))
-    return conv_halo_op(km, 0, in, cin, weight, cin, cout, cout, bias, out, workspace, s, 0, packed, pack_mode, in_row_stride);
   if (dtype == LGS_F32) return conv_gather_op<float>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr, packed, pack_mode, in_row_stride);
   if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr, packed, pack_mode, in_row_stride);
   LGS_REQUIRE(false, "lgs_conv_forward: unknown dtype");
@@ -1246,8 +1167,6 @@ int lgs_conv_dgrad(lgs_kmap *km, int transposed, const void *grad_out, int cout,
   View vv = v; vv.mirror = (km->ks == 3) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   if (kmap_wait(km, s)) return 1;
-  if (halo_takes(km, transposed, cout, cin, dtype, 0))
-    return conv_halo_op(km, 1, grad_out, cout, weight, cin, cout, cin, nullptr, grad_in, workspace, s, 0, packed, pack_mode, 0);
   if (dtype == LGS_F32) return conv_gather_op<float>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, nullptr, packed, pack_mode);
   if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, nullptr, packed, pack_mode);
   LGS_REQUIRE(false, "lgs_conv_dgrad: unknown dtype");
@@ -1259,7 +1178,6 @@ int lgs_conv_dgrad_can_accumulate(const lgs_kmap *km, int transposed, int cin, i
   if (!km || (transposed && km->ks == 3) || cin % 4 != 0 || (dtype != LGS_F32 && dtype != LGS_BF16)) return 0;
   const View &v = transposed ? km->fwd : km->bwd;
   if (v.n_pad == 0) return 0;
-  if (halo_takes(km, transposed, cout, cin, dtype, 0)) return 1;
   const int nb_total = pad32(cin) / 32;
   const int id = dtype == LGS_F32 ? gather_cfg<float>(v, nb_total).id : gather_cfg<bf16_t>(v, nb_total).id;
   return id == 17 ? 0 : 1;
@@ -1275,8 +1193,6 @@ int lgs_conv_dgrad_accumulate(lgs_kmap *km, int transposed, const void *grad_out
   View vv = v; vv.mirror = (km->ks == 3) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   if (kmap_wait(km, s)) return 1;
-  if (halo_takes(km, transposed, cout, cin, dtype, 0))
-    return conv_halo_op(km, 1, grad_out, cout, weight, cin, cout, cin, nullptr, grad_in, workspace, s, 1, packed, pack_mode, 0);
   BnEpi acc; acc.accum = 1;
   if (dtype == LGS_F32) return conv_gather_op<float>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, &acc, packed, pack_mode);
   return conv_gather_op<bf16_t>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, &acc, packed, pack_mode);

@@ -115,13 +115,17 @@ __global__ void k_emit_inverse(const int32_t *svals, const int32_t *runid_incl, 
 }
 
 // stride-2: coarse rows are created in Morton order (row == sorted position)
+// nc = the row count the coarse arrays were SIZED for (counted at insert time, no synchronisation): a run index beyond it is
+// never written, and the last thread compares the two counts (d_err bit 1, lgs_manager_check)
 __global__ void k_emit_coarse(const uint64_t *fkeys, const int32_t *head, const int32_t *cidx_incl, int64_t n,
                               uint64_t keep_mask, uint64_t *ckeys, int32_t *ccoords, int32_t *cstart,
-                              int32_t *fine_cidx) {
+                              int32_t *fine_cidx, int64_t nc, int *d_err) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   int32_t q = cidx_incl[p] - 1;
   fine_cidx[p] = q;
+  if (p == n - 1 && (int64_t)q + 1 != nc && d_err) atomicOr(d_err, 2);
+  if (q >= nc) return;
   if (head[p]) {
     uint64_t k = fkeys[p] & keep_mask;
     ckeys[q] = k;
@@ -273,91 +277,6 @@ __global__ void k_permute_map3(const int32_t *nbr_tmp, const uint32_t *pmask, co
   if ((threadIdx.x & 63) == 0) mask64[q >> 6] = m;
 }
 
-// Halo tables (lgs_common.h HaloView): one workgroup per tile of kHaloT positions collects the distinct input rows of its
-// 27 x kHaloT kernel-map entries in an LDS hash set.  The tile's OWN rows (centre offset: position j's row) get slots
-// 0 .. kHaloT-1 in position order -- at every offset most neighbours of a Morton tile are rows of the tile itself, and
-// neighbouring positions then read neighbouring slots (LDS banks) -- the halo rows follow in hash-table order.
-// Deterministic as a SET (the list order of the halo part depends on insertion races; nothing numeric depends on it: a slot only
-// names an LDS staging row).
-__global__ __launch_bounds__(256) void k_build_halo(const int32_t *__restrict__ nbr, int64_t n_pad, uint16_t *__restrict__ lnbr,
-                                                    int32_t *__restrict__ urows, int32_t *__restrict__ ucount) {
-  constexpr int CAP = 4096;                 // hash capacity: >= 2 x the largest list (kHaloS) that is kept
-  __shared__ int32_t hk[CAP];
-  __shared__ uint16_t hs[CAP];
-  __shared__ int cnt, wsum[4];
-  const int tid = threadIdx.x;
-  const int64_t tile = blockIdx.x, pos0 = tile * kHaloT;
-  for (int e = tid; e < CAP; e += 256) hk[e] = -1;
-  if (tid == 0) cnt = 0;
-  __syncthreads();
-  auto hash = [](int32_t r) { return ((unsigned)r * 2654435761u) >> 20; };        // 12 bits
-  // own rows first: slot = position
-  const int32_t own = nbr[(int64_t)13 * n_pad + pos0 + tid];
-  if (own >= 0) {
-    unsigned hh = hash(own) & (CAP - 1);
-    for (;;) {
-      const int32_t old = atomicCAS(&hk[hh], -1, own);
-      if (old == -1) { hs[hh] = (uint16_t)tid; break; }
-      hh = (hh + 1) & (CAP - 1);            // rows of a map are distinct: no equality case
-    }
-  }
-  __syncthreads();
-  for (int e = tid; e < 27 * kHaloT; e += 256) {
-    const int s = e / kHaloT, j = e % kHaloT;
-    if (s == 13) continue;
-    const int32_t r = nbr[(int64_t)s * n_pad + pos0 + j];
-    if (r < 0) continue;
-    unsigned hh = hash(r) & (CAP - 1);
-    for (;;) {
-      if (*(volatile int *)&cnt > kHaloS) break;          // too wide anyway: stop filling the table
-      const int32_t old = atomicCAS(&hk[hh], -1, r);
-      if (old == -1) { hs[hh] = 0xffffu; atomicAdd(&cnt, 1); break; }
-      if (old == r) break;
-      hh = (hh + 1) & (CAP - 1);
-    }
-  }
-  __syncthreads();
-  const int U = kHaloT + cnt;               // own slots are reserved even for padding positions
-  if (U > kHaloS) {                         // workgroup-uniform
-    if (tid == 0) ucount[tile] = -1;
-    return;
-  }
-  // halo rows: slots kHaloT .. in table order; thread t owns entries 16 t .. 16 t + 15
-  int mine = 0;
-#pragma unroll
-  for (int i = 0; i < CAP / 256; ++i) { const int e = tid * (CAP / 256) + i; mine += (hk[e] >= 0 && hs[e] == 0xffffu); }
-  int incl = mine;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(incl, o);
-    if ((tid & 63) >= o) incl += t;
-  }
-  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-  __syncthreads();
-  int base = kHaloT + incl - mine;
-  for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
-  int32_t *ur = urows + tile * kHaloS;
-  ur[tid] = own;                            // (-1 for a padding position: staged as a zero row)
-#pragma unroll
-  for (int i = 0; i < CAP / 256; ++i) {
-    const int e = tid * (CAP / 256) + i;
-    if (hk[e] >= 0 && hs[e] == 0xffffu) { hs[e] = (uint16_t)base; ur[base] = hk[e]; ++base; }
-  }
-  __syncthreads();
-  for (int e = tid; e < 27 * kHaloT; e += 256) {
-    const int s = e / kHaloT, j = e % kHaloT;
-    const int32_t r = nbr[(int64_t)s * n_pad + pos0 + j];
-    uint16_t slot = 0xffffu;
-    if (r >= 0) {
-      unsigned hh = hash(r) & (CAP - 1);
-      while (hk[hh] != r) hh = (hh + 1) & (CAP - 1);
-      slot = hs[hh];
-    }
-    lnbr[(int64_t)s * n_pad + pos0 + j] = slot;
-  }
-  if (tid == 0) ucount[tile] = U;
-}
-
 // 2x2x2 stride-2, coarse-stationary view: nbr8[k][q] = fine row of child k of coarse row q
 __global__ void k_build_map2_coarse(const uint64_t *fkeys, const int32_t *forder, const int32_t *cstart,
                                     int64_t n_c, int64_t nc_pad, int shift, int32_t *nbr8, uint32_t *mask64) {
@@ -492,7 +411,6 @@ struct lgs_manager {
   struct Blk { size_t off, size; bool freed; };
   std::vector<Blk> blks;           // live arena blocks in allocation order (a stack: freed blocks on top are popped)
   size_t pool_live = 0, pool_peak = 0;
-  int opt_halo = 0;                // lgs_manager_set_option("halo"): 3^3 maps also get halo tables (lgs_common.h HaloView)
   int64_t precount[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // rows of the maps at tensor stride 2^(i+1), counted by the insert (-1: unknown)
 };
 
@@ -720,12 +638,6 @@ int lgs_manager_create(int device, lgs_manager **out) {
   return 0;
 }
 
-int lgs_manager_set_option(lgs_manager *m, const char *name, int64_t value) {
-  LGS_REQUIRE(m && name, "lgs_manager_set_option: null argument");
-  if (!strcmp(name, "halo")) { m->opt_halo = value != 0; return 0; }
-  LGS_REQUIRE(false, std::string("lgs_manager_set_option: unknown option '") + name + "'");
-}
-
 int lgs_manager_destroy(lgs_manager *m) {
   if (!m) return 0;
   DeviceGuard guard(m->device);
@@ -856,7 +768,7 @@ int lgs_manager_stride2(lgs_manager *m, int in_key, void *stream, int *out_key, 
       dalloc(m, &c.fine_cidx, n, s))
     return 1;
   LGS_KLAUNCH(k_emit_coarse, nblk(n), 256, 0, s, f.skeys, head, cincl, n, keep, c.skeys, c.coords, c.cstart,
-                     c.fine_cidx);
+                     c.fine_cidx, nc, m->d_err);
   LGS_HIP(hipGetLastError());
   if (dfree_now(m, head, s) || dfree_now(m, cincl, s)) return 1;
   m->maps.push_back(c);
@@ -864,6 +776,18 @@ int lgs_manager_stride2(lgs_manager *m, int in_key, void *stream, int *out_key, 
   m->maps[in_key].coarse_key = ck;
   *out_key = ck; *n_out = nc;
   return publish(m, nullptr, false);
+}
+
+int lgs_manager_check(lgs_manager *m, int *flags) {
+  LGS_REQUIRE(m && flags, "lgs_manager_check: null argument");
+  *flags = 0;
+  if (!m->d_err) return 0;
+  DeviceGuard guard(m->device);
+  int h = 0;
+  LGS_HIP(hipMemcpyAsync(&h, m->d_err, sizeof(int), hipMemcpyDeviceToHost, m->ms));
+  LGS_HIP(hipStreamSynchronize(m->ms));
+  *flags = h;
+  return 0;
 }
 
 int lgs_manager_parent_of(lgs_manager *m, int key, int *fine_key) {
@@ -935,35 +859,6 @@ int lgs_manager_kernel_map(lgs_manager *m, int in_key, int out_key, int ks, void
       LGS_KLAUNCH(k_permute_map3, (unsigned)(ci.n_pad / 256), 256, 0, s, nbr_tmp, pmask, perm, ci.order, ci.n, ci.n_pad,
                          nbr, orow, mask);
       LGS_HIP(hipGetLastError());
-      // halo tables: the same map once more, clustered by neighbourhood mask inside 256-position tiles only (a tile's
-      // distinct-row list must stay small), for managers that asked for them and maps large enough for the halo kernel
-      if (m->opt_halo && tune(T_HALO) != 0 && ci.n_pad >= tune(T_HALO_MIN_ROWS)) {
-        HaloView &hv = km->halo;
-        int32_t *hnbr, *horow, *urows, *ucount; uint32_t *hmask; uint16_t *lnbr;
-        const int64_t nt = ci.n_pad / kHaloT;
-        // (allocated BELOW the temporaries on the arena stack would be better; they are freed right after, and the stack
-        // allocator reclaims them once everything above is gone -- these six stay)
-        if (dalloc(m, &hnbr, 27 * ci.n_pad, s) || dalloc(m, &hmask, ci.n_pad / kGroup, s) || dalloc(m, &horow, ci.n_pad, s) ||
-            dalloc(m, &lnbr, 27 * ci.n_pad, s) || dalloc(m, &urows, nt * kHaloS, s) || dalloc(m, &ucount, nt, s))
-          return 1;
-        LGS_KLAUNCH(k_mask_sort_keys, (unsigned)(ci.n_pad / 256), 256, 0, s, pmask, ci.n, ci.n_pad, kHaloT, (int)tune(T_MASK_ORDER), keys, vals);
-        {
-          size_t tb = 0;
-          const unsigned eb = mask_sort_bits(ci.n_pad, kHaloT);
-          LGS_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, eb, s));
-          void *tmp = nullptr;
-          if (raw_alloc(m, &tmp, tb ? tb : 16, s)) return 1;
-          LGS_HIP(rocprim::radix_sort_pairs(tmp, tb, keys, skeys2, vals, perm, (size_t)ci.n_pad, 0, eb, s));
-          if (dfree_now(m, tmp, s)) return 1;
-        }
-        LGS_KLAUNCH(k_permute_map3, (unsigned)(ci.n_pad / 256), 256, 0, s, nbr_tmp, pmask, perm, ci.order, ci.n, ci.n_pad,
-                    hnbr, horow, hmask);
-        LGS_KLAUNCH(k_build_halo, (unsigned)nt, 256, 0, s, hnbr, ci.n_pad, lnbr, urows, ucount);
-        LGS_HIP(hipGetLastError());
-        hv.v.nbr = hnbr; hv.v.mask64 = hmask; hv.v.out_row = horow; hv.v.n_pad = ci.n_pad; hv.v.n_out = ci.n; hv.v.n_in = ci.n;
-        hv.v.KS = 27; hv.v.K = 27;
-        hv.lnbr = lnbr; hv.urows = urows; hv.ucount = ucount; hv.ok = true;
-      }
       if (dfree_now(m, nbr_tmp, s) || dfree_now(m, pmask, s) || dfree_now(m, keys, s) || dfree_now(m, skeys2, s) ||
           dfree_now(m, vals, s) || dfree_now(m, perm, s))
         return 1;

@@ -43,11 +43,6 @@ const Knob kKnobs[T_COUNT] = {
     {"WIDE_TRACE", 0, "k_conv_wide: print per-phase shader-clock sums of one workgroup (debug instance of the kernel)"},
     {"ARENA_DBG", 0, "print coordinate-manager arena allocations to stderr"},
     {"CONV_WIDE", 1, "0 = >= 256-output-channel layers stay on k_conv_gather's 8-wave tile (id 16) instead of k_conv_wide (A/B)"},
-    {"HALO", 0, "1 = managers of bf16 tensors build halo tables for their big 3^3 maps and bf16 convolutions of <= 128 channels run on the "
-                "per-tile distinct-row kernel k_conv_halo instead of k_conv_gather.  OFF: parity-green but slower at the benchmark's shapes "
-                "(L0 96->96 0.78 vs 0.58 ms; wins only at 32 / 64 channels by 2-9 %, less than the 1.2 ms per step the tables cost)"},
-    {"HALO_MIN_ROWS", 65536, "k_conv_halo is used on maps of at least this many positions"},
-    {"HALO_TRACE", 0, "k_conv_halo: print per-phase shader-clock sums of one workgroup's wave 0 (debug instance, synchronises)"},
     {"MASK_ORDER", 0, "3^3 maps: sort code of the neighbourhood mask inside a window: 0 the mask, 1 corners > edges > faces, 2 faces > edges > corners, 3 popcount-major"},
 };
 std::atomic<int64_t> g_val[T_COUNT];

@@ -402,44 +402,74 @@ class _SyncBNFunction(torch.autograd.Function):
 class EngineComm:
     """The engine's own RCCL communicator for one process group (csrc/lgs_comm.hip): SyncBN's per-layer collectives are issued by
     the engine ON THE COMPUTE STREAM between its kernels instead of through ProcessGroupNCCL (its stream hand-overs and ~60 us of
-    host work per collective).  Created collectively the first time a SyncBN layer of the group runs: rank 0 draws the id, one
-    torch.distributed broadcast shares it.  `LGS_SYNCBN_ENGINE_COMM=0` keeps torch.distributed's collectives."""
+    host work per collective).  Created COLLECTIVELY the first time a SyncBN layer of the group runs: rank 0 draws the id, one
+    torch.distributed broadcast shares it, every rank initialises, and one all-reduce(MIN) of a success flag over the torch group
+    decides for ALL ranks together -- a rank that failed anywhere on the way (no librccl, id, init) still takes part in both
+    collectives, so no rank is left waiting and no rank uses the communicator unless every rank has it (advisor, round 4).
+
+    Default (`LGS_SYNCBN_ENGINE_COMM=-1`, "auto"): used in a world of ONE rank only (the single-GPU measurement of the per-rank
+    path, bench.py dp_path_world1); with more than one rank SyncBN keeps torch.distributed's collectives -- the engine
+    communicator's kernels on the compute stream would be in flight next to ProcessGroupNCCL's bucket all-reduces on its stream,
+    two communicators at once, which this build has never been able to execute with a peer (one GPU per box).  `=1` turns it on
+    for any world (what a first multi-GPU bring-up should A/B), `=0` off."""
     _by_group = {}
 
     def __init__(self, group, device):
         import ctypes
         from . import engine
-        L = engine.lib()
         world, rank = dist.get_world_size(group), dist.get_rank(group)
+        self.h, self.world, self.rank, self._L = None, world, rank, None
+        err = None
         buf = ctypes.create_string_buffer(128)
-        if rank == 0:
-            engine.check(L.lgs_comm_unique_id(buf))
-        box = [bytes(buf.raw)]
+        try:
+            L = self._L = engine.lib()
+            if rank == 0:
+                engine.check(L.lgs_comm_unique_id(buf))
+        except Exception as e:
+            err = e
+        box = [bytes(buf.raw) if err is None else b""]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        h = ctypes.c_void_p(None)
-        idx = device.index if device.index is not None else torch.cuda.current_device()
-        engine.check(L.lgs_comm_create(ctypes.create_string_buffer(box[0], 128), world, rank, idx, ctypes.byref(h)))
-        self.h, self.world, self.rank, self._L = h, world, rank, L
+        if err is None and len(box[0]) == 128:
+            try:
+                h = ctypes.c_void_p(None)
+                idx = device.index if device.index is not None else torch.cuda.current_device()
+                engine.check(L.lgs_comm_create(ctypes.create_string_buffer(box[0], 128), world, rank, idx, ctypes.byref(h)))
+                self.h = h
+            except Exception as e:
+                err = e
+        elif err is None:
+            err = RuntimeError("rank 0 could not draw an RCCL unique id")
+        ok = torch.tensor([1 if err is None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        self.ok = bool(int(ok.item()))
+        self.error = err
+        if not self.ok:
+            self.close()
 
     def close(self):
         if self.h is not None and self.h.value:
             self._L.lgs_comm_destroy(self.h)
-            self.h = None
+        self.h = None
 
     @classmethod
     def get(cls, group, device):
-        """-> EngineComm of this group, or None (off by knob, not an RCCL group, or RCCL could not be reached: said once)"""
+        """-> EngineComm of this group, or None (off by knob, not an RCCL group, or some rank could not create it: said once)"""
         from . import tuning as _tuning
-        key = (id(group) if group is not None else 0, device.index)
+        g = group if group is not None else dist.group.WORLD
+        key = (g, device.index)                    # the group OBJECT (kept alive by the key): id() of a freed group can be reused
         if key in cls._by_group:
             return cls._by_group[key]
         comm = None
-        if _tuning.host("SYNCBN_ENGINE_COMM") and dist.get_backend(group) == "nccl":
-            try:
-                comm = cls(group, device)
-            except Exception as e:      # every rank takes the same branch: the failure modes (no librccl, init error) are not per rank
+        knob = _tuning.host("SYNCBN_ENGINE_COMM")
+        want = knob == 1 or (knob < 0 and dist.get_world_size(group) == 1)
+        if want and dist.get_backend(group) == "nccl":
+            c = cls(group, device)
+            if c.ok:
+                comm = c
+            else:
                 import sys
-                print("[lgs] engine-side RCCL communicator unavailable (%s): SyncBN keeps torch.distributed's collectives" % e, file=sys.stderr)
+                print("[lgs] engine-side RCCL communicator unavailable on at least one rank (this rank: %s): SyncBN keeps "
+                      "torch.distributed's collectives on every rank" % (c.error,), file=sys.stderr)
         cls._by_group[key] = comm
         return comm
 

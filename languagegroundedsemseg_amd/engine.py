@@ -10,7 +10,7 @@ import os
 from . import build as _build
 
 LGS_F32, LGS_BF16 = 0, 1
-ABI_VERSION = 10     # LGS_ABI_VERSION of include/lgs_engine.h
+ABI_VERSION = 11     # LGS_ABI_VERSION of include/lgs_engine.h
 
 
 class PackDesc(ctypes.Structure):
@@ -80,7 +80,7 @@ _lib = None
 EXPORTS = [
     "lgs_abi_version", "lgs_last_error",
     "lgs_tuning_set", "lgs_tuning_get", "lgs_tuning_describe", "lgs_debug_dispatch_counts",
-    "lgs_manager_create", "lgs_manager_set_option", "lgs_manager_destroy", "lgs_manager_insert", "lgs_manager_stride2",
+    "lgs_manager_create", "lgs_manager_destroy", "lgs_manager_insert", "lgs_manager_stride2", "lgs_manager_check",
     "lgs_manager_parent_of", "lgs_manager_map_size", "lgs_manager_get_coords", "lgs_manager_kernel_map",
     "lgs_kmap_export",
     "lgs_conv_workspace_bytes", "lgs_conv_bn_partial_rows", "lgs_conv_forward", "lgs_conv_dgrad", "lgs_conv_wgrad",
@@ -129,9 +129,9 @@ def lib():
         "lgs_tuning_get": [ctypes.c_char_p, pi64],
         "lgs_manager_create": [ci, pvp],
         "lgs_manager_destroy": [vp],
-        "lgs_manager_set_option": [vp, ctypes.c_char_p, i64],
         "lgs_manager_insert": [vp, vp, i64, vp, vp, vp, pi, pi64],
         "lgs_manager_stride2": [vp, ci, vp, pi, pi64],
+        "lgs_manager_check": [vp, pi],
         "lgs_manager_parent_of": [vp, ci, pi],
         "lgs_manager_map_size": [vp, ci, pi64, pi],
         "lgs_manager_get_coords": [vp, ci, vp, vp],

@@ -6,6 +6,7 @@ raises RuntimeError.
 """
 import ctypes
 import os
+import threading
 import weakref
 
 import torch
@@ -403,10 +404,11 @@ class HipManager:
         except Exception:
             pass
 
-    def hint_feature_dtype(self, dtype):
-        """bf16 features: the 3^3 maps of the big levels also get HALO tables (per-tile distinct-row lists + 16-bit slot maps,
-        csrc/lgs_conv_halo.hip), built with the map on the map stream; fp32 (the parity path) runs k_conv_gather and skips them"""
-        engine.check(engine.lib().lgs_manager_set_option(self.h, b"halo", 1 if dtype == torch.bfloat16 else 0))
+    def check(self):
+        """device-side consistency flags of this manager's maps (one synchronisation; tests): 0 = consistent"""
+        f = ctypes.c_int(0)
+        engine.check(engine.lib().lgs_manager_check(self.h, ctypes.byref(f)))
+        return f.value
 
     def insert(self, coords):
         _require_dev(coords, "coordinates")
@@ -587,12 +589,20 @@ class HipBackend:
         return dx, dres, dgamma, dbeta
 
     # ---- a whole BasicBlock per call (csrc/lgs_block.hip): small batches, everything on the compute stream
-    # host staging of lgs_block_fwd / lgs_block_bwd: one buffer per direction (forward runs on the caller's thread, backward on
-    # autograd's; the engine is single-threaded per process otherwise, include/lgs_engine.h)
-    _blk_args = ctypes.create_string_buffer(512)
-    _blk_addr = ctypes.addressof(_blk_args)
-    _blk_args_b = ctypes.create_string_buffer(512)
-    _blk_addr_b = ctypes.addressof(_blk_args_b)
+    # host staging of lgs_block_fwd / lgs_block_bwd: one buffer per direction and THREAD (ctypes releases the GIL during the call,
+    # so a second Python / autograd thread -- multi-device backward, two models driven from two threads -- must not be able to
+    # overwrite the struct the engine is still reading; advisor, round 4)
+    _blk_tls = threading.local()
+
+    @classmethod
+    def _blk_stage(cls, which):
+        """-> (buffer, address) of this thread's staging struct for direction `which` ("f" / "b")"""
+        st = getattr(cls._blk_tls, which, None)
+        if st is None:
+            buf = ctypes.create_string_buffer(512)
+            st = (buf, ctypes.addressof(buf))
+            setattr(cls._blk_tls, which, st)
+        return st
 
     def _block_ws(self, L, kmap3, kmap1, cin, planes, dt, n, device):
         key = ("cblk_ws", cin, planes, dt)
@@ -635,14 +645,14 @@ class HipBackend:
                        float(m.eps), float(m.momentum)]
                 touched += [m.running_mean, m.running_var, m.num_batches_tracked]
             cws = self._block_ws(L, kmap3, kmap1, cin, planes, dt, n, dev).data_ptr()
-            args = self._blk_args
+            args, addr = self._blk_stage("f")
             engine.BLOCK_FWD_PACK.pack_into(
                 args, 0, kmap3.h.value, kmap1.h.value if ds else 0, dt, int(relu_final), cin, planes, n, x.data_ptr(),
                 w1.data_ptr(), w2.data_ptr(), wd.data_ptr() if ds else 0,
                 _ptr(p1) or 0, _ptr(p2) or 0, _ptr(pd) or 0, int(pm1), int(pm2), int(pmd), *bn,
                 b0, b0 + row, b0 + 2 * row, (b0 + 4 * row) if ds else 0, (b0 + 5 * row) if ds else 0, b0 + 3 * row,
                 s0, s0 + srow, (s0 + 2 * srow) if ds else 0, cws, cws)
-            engine.check(L.lgs_block_forward(self._blk_addr, _stream()))
+            engine.check(L.lgs_block_forward(addr, _stream()))
         _written_by_engine(*touched)
         return buf[0], st[0], buf[1], buf[2], st[1], buf[3], (buf[4] if ds else None), (st[2] if ds else None)
 
@@ -713,8 +723,9 @@ class HipBackend:
                 s_fork = _raw_event(self.fork_event(dev), side)
                 e1, e2 = _raw_event(_param_event(pw1), side), _raw_event(_param_event(pw2), side)
                 ed = _raw_event(_param_event(pwd), side) if ds else 0
+            args_b, addr_b = self._blk_stage("b")
             engine.BLOCK_BWD_PACK.pack_into(
-                self._blk_args_b, 0, kmap3.h.value, kmap1.h.value if ds else 0, dt, int(relu_final), cin, planes, int(want_gin), 0,
+                args_b, 0, kmap3.h.value, kmap1.h.value if ds else 0, dt, int(relu_final), cin, planes, int(want_gin), 0,
                 n, 0 if dy_ld == planes else dy_ld, dy.data_ptr(),
                 x.data_ptr(), o1.data_ptr(), y1.data_ptr(), o2.data_ptr(), y2.data_ptr() if relu_final else 0, od.data_ptr() if ds else 0,
                 st1.data_ptr(), st2.data_ptr(), std.data_ptr() if ds else 0,
@@ -725,7 +736,7 @@ class HipBackend:
                 gw1.data_ptr(), gw2.data_ptr(), gwd.data_ptr() if ds else 0,
                 dg1.data_ptr(), db1.data_ptr(), dg2.data_ptr(), db2.data_ptr(), dgd.data_ptr() if ds else 0, dbd.data_ptr() if ds else 0,
                 cws, cws, s_raw, s_ws, s_fork, e1, e2, ed)
-            engine.check(L.lgs_block_backward(self._blk_addr_b, _stream()))
+            engine.check(L.lgs_block_backward(addr_b, _stream()))
             if side is not None:
                 # the side stream reads these after this call returns: their memory may only be reused in ITS order
                 for t in (x, y1, buf):

@@ -250,35 +250,69 @@ def _is3(op):
             and not op.aux[2])
 
 
-def try_block(q, i, n):
-    """q[i] is a recorded convolution about to run.  If q[i:] starts with a complete residual block whose intermediates have no
-    other consumer, run it as one node and return the number of queue entries it covered, else 0."""
-    if not _BLOCK_FUSED or i + 3 >= n:
+WAIT = -1
+
+
+def try_block(q, i, n, final=True):
+    """q[i] is a recorded convolution at the head of the queue.  If q[i:] starts with a complete residual block whose intermediates
+    have no other consumer, run it as one node and return the number of queue entries it covered; 0 = it is not such a block;
+    WAIT (only when not `final`) = it may still become one: calls that complete it -- the second convolution, `out += residual`,
+    the in-place ReLU, the consumer that closes the last norm -- have not been recorded yet."""
+    if not _BLOCK_FUSED:
         return 0
-    c1, n1, c2 = q[i], q[i + 1], q[i + 2]
-    if not (_is3(c1) and n1.kind == _d.BN and n1.inp is c1.out and n1.relu and n1.residual is None and not n1.cat_up
-            and n1.cat_into is None and _is3(c2) and c2.inp is n1.out and c1.uses == 1 and n1.uses == 1):
+    more = 0 if final else WAIT
+    c1 = q[i]
+    if not _is3(c1) or not c1.grad or c1.dropped:
         return 0
+    if i + 1 >= n:
+        return more
+    n1 = q[i + 1]
+    if not (n1.kind == _d.BN and n1.inp is c1.out and n1.residual is None and not n1.cat_up and n1.cat_into is None and c1.uses == 1):
+        return 0
+    if n1.uses == 0:
+        return 0 if n1.dropped else more              # the norm is still open: its ReLU / its consumer are not recorded yet
+    if not n1.relu or n1.uses != 1 or i + 2 >= n:
+        return 0
+    c2 = q[i + 2]
+    if not (_is3(c2) and c2.inp is n1.out):
+        return 0
+    if i + 3 >= n:
+        return more
     x = c1.inp
     nxt = q[i + 3]
     ds = None
     if nxt.kind == _d.BN:
         n2, took = nxt, 4
+        if n2.inp is not c2.out:
+            return 0
+        if n2.residual is None:
+            # norm2 before its `+=` (the downsample branch may be recorded in between): nothing else may have touched it
+            return more if (not n2.relu and n2.uses == 0 and not n2.dropped) else 0
         if n2.residual is not x:
             return 0
-    else:
-        if i + 5 >= n:
-            return 0
-        cd, nd, n2, took = nxt, q[i + 4], q[i + 5], 6
+    elif nxt.kind == _d.CONV:
+        cd = nxt
         md = cd.mod
-        if not (cd.kind == _d.CONV and type(md) is _mod.MinkowskiConvolution and md.kernel_volume == 1 and md.use_mm
-                and cd.inp is x and nd.kind == _d.BN and nd.inp is cd.out and not nd.relu and nd.residual is None
-                and not nd.cat_up and nd.cat_into is None and cd.uses == 1 and nd.uses == 1 and n2.kind == _d.BN
-                and n2.residual is nd.out):
+        if not (type(md) is _mod.MinkowskiConvolution and md.kernel_volume == 1 and md.use_mm and cd.inp is x):
+            return 0
+        if i + 4 >= n:
+            return more
+        nd = q[i + 4]
+        if not (nd.kind == _d.BN and nd.inp is cd.out and not nd.relu and nd.residual is None and not nd.cat_up and nd.cat_into is None
+                and cd.uses == 1):
+            return 0
+        if i + 5 >= n:
+            return more
+        n2, took = q[i + 5], 6
+        if not (n2.kind == _d.BN and n2.residual is nd.out and nd.uses == 1 and n2.inp is c2.out):
             return 0
         ds = (cd.mod, nd.mod)
-    if not (n2.inp is c2.out and c2.uses == 1 and not n2.cat_up and n2.cat_into is None):
+    else:
         return 0
+    if not (c2.uses == 1 and not n2.cat_up and n2.cat_into is None):
+        return 0
+    if n2.uses == 0 and not final and not n2.dropped:
+        return WAIT                                   # its (optional) final ReLU may still be recorded
     ops = q[i:i + took]
     if not all(o.grad for o in ops) or x._op is not None:
         return 0
@@ -303,9 +337,10 @@ def try_block(q, i, n):
         y = _BasicBlockFunction.apply(xf, blk, kmap3, None, blk.conv1.kernel, blk.norm1.bn.weight, blk.norm1.bn.bias,
                                       blk.conv2.kernel, blk.norm2.bn.weight, blk.norm2.bn.bias)
     out = n2.out
-    out._F, out._op = y, None
+    if out is not None:
+        out._F, out._op = y, None
     dead = _d._Dead(_DEAD_MID)
     for o in ops:
-        if o is not n2:
+        if o is not n2 and o.out is not None:
             o.out._op = dead
     return took

@@ -75,15 +75,13 @@ class CoordinateManager:
         self.device = torch.device(device) if device is not None else None
         self._m = None
         self._keys = {}
-        self.feature_dtype = None
         self._pending = []          # recorded, not yet executed operations on tensors of this manager (me/deferred.py)
+        self._draining = self._redrain = False
 
     def _ensure(self, device):
         if self._m is None:
             self.device = torch.device(device)
             self._m = self.backend.new_manager(self.device)
-            if self.feature_dtype is not None and hasattr(self._m, "hint_feature_dtype"):
-                self._m.hint_feature_dtype(self.feature_dtype)
         return self._m
 
     def _key(self, kid):
@@ -156,7 +154,6 @@ class SparseTensor:
             D = coordinates.shape[1] - 1
             if coordinate_manager is None:
                 coordinate_manager = CoordinateManager(D=D, device=features.device)
-                coordinate_manager.feature_dtype = features.dtype     # a hint for the backend's map builder (bf16: halo tables)
             key, (unique_index, inverse) = coordinate_manager.insert_and_map(coordinates, tensor_stride)
             self.unique_index, self.inverse_mapping = unique_index, inverse
             if unique_index.shape[0] != features.shape[0]:
@@ -381,10 +378,13 @@ def cat_now(sparse_tensors, out=None):
 def _cat_features(sparse_tensors):
     if len(sparse_tensors) == 2:
         a, b = (t._cat_slot for t in sparse_tensors)
-        # zero-copy: both halves were written straight into one [N, C1 + C2] buffer by their norms (me.modules)
-        if (a is not None and b is not None and a.buf is b.buf and a.off == 0 and b.off == a.width
-                and a.width + b.width == a.buf.shape[1] and sparse_tensors[0].F.data_ptr() == a.buf.data_ptr()):
-            return _CatViewFunction.apply(sparse_tensors[0].F, sparse_tensors[1].F, a)
+        if a is not None and a.off == 0 and sparse_tensors[0].F.data_ptr() == a.buf.data_ptr():
+            # zero-copy: both halves were written straight into one [N, C1 + C2] buffer by their norms (me.modules) ...
+            if (b is not None and a.buf is b.buf and b.off == a.width and a.width + b.width == a.buf.shape[1]):
+                return _CatViewFunction.apply(sparse_tensors[0].F, sparse_tensors[1].F, a)
+            # ... or the first half was, and the second was copied in beside it when that norm ran
+            if a.partner is sparse_tensors[1] and a.width + sparse_tensors[1].F.shape[1] == a.buf.shape[1]:
+                return _CatViewFunction.apply(sparse_tensors[0].F, sparse_tensors[1].F, a)
     return torch.cat([s.F for s in sparse_tensors], dim=1)
 
 

@@ -18,17 +18,26 @@ residual block and direction (csrc/lgs_block.hip) -- so the ME surface RECORDS i
   * MinkowskiReLU(inplace=True) on the pending result of a norm, and `out += residual` on it, are IN-PLACE operations on a
     value nobody has seen yet: they become the norm's epilogue flags (the `+=` also moves the norm behind the producer of its
     residual -- program order of an in-place update);
-  * reading `.F` (or shape / dtype / ... ) of any pending tensor executes the whole queue in program order.  The executor
-    looks at what is in front of it: [conv3, norm+relu, conv3, (conv1, norm,) norm+residual(+relu)] runs as the whole-block
-    autograd node (me/block.py: lgs_block_forward / lgs_block_backward), a norm whose result meets a later `me.cat` writes
-    into the shared concat buffer (zero-copy cat), everything else runs module by module with the epilogue flags it collected.
+  * a recorded call EXECUTES as soon as no later call can change what it means (`advance`, run whenever a consumer is recorded):
+    a norm once its result has a consumer (ReLU / residual flags are then final), a convolution once it is known whether it
+    opens a residual block, i.e. the queue holds at most the open tail of one block and the GPU works on a layer while the host
+    records the next; reading `.F` (or shape / dtype / ...) of a pending tensor executes whatever is left (`flush`).
+    LGS_DEFER_INCREMENTAL=0 keeps everything queued until such a read.
+  * the executor looks at what is in front of it: [conv3, norm+relu, conv3, (conv1, norm,) norm+residual(+relu)] runs as the
+    whole-block autograd node (me/block.py: lgs_block_forward / lgs_block_backward); a norm whose only consumer is the
+    `me.cat(up, skip)` recorded right behind it writes straight into the left-hand columns of the concat buffer, the skip half is
+    copied in beside it once, and the cat returns the buffer (one copy of the narrow skip half instead of torch.cat's copy of both;
+    its backward hands out column slices, read in place by the norms' row-stride support); everything else runs module by
+    module with the epilogue flags it collected.
 
 Nothing is re-ordered except the in-place `+=` above, BatchNorm running statistics are updated exactly once per call, module
 forward hooks fire at call time as torch defines them (a hook that reads `.F` simply executes what was recorded so far, i.e.
 hooks force the call-by-call sequence), `torch.no_grad()` / `enable_grad()` are honoured per recorded call, and switching a
-norm between train() and eval() executes what is pending first.  `LGS_DEFER=0` executes every call immediately (the unfused
-sequence: same results, tests/test_gpu_reference_calls.py).
+norm between train() and eval() -- or the backend -- executes what is pending first.  A call whose result is never consumed and
+never read does not run (its norm's running statistics are not updated): values drive execution.  `LGS_DEFER=0` executes every
+call immediately (the unfused sequence: same results, tests/test_gpu_reference_calls.py).
 """
+import sys
 import weakref
 
 import torch
@@ -36,6 +45,7 @@ import torch
 from .. import tuning as _tuning
 
 ENABLED = _tuning.host("DEFER") != 0
+INCREMENTAL = _tuning.host("DEFER_INCREMENTAL") != 0
 
 CONV, BN, CAT = 0, 1, 2
 _LIVE = weakref.WeakSet()       # managers with a non-empty queue
@@ -45,13 +55,37 @@ STATS = {"flushes": 0, "ops": 0, "blocks": 0, "cat_hints": 0}
 
 
 class Op:
-    __slots__ = ("kind", "mod", "inp", "out", "relu", "residual", "cat_up", "cat_into", "grad", "uses", "aux")
+    """one recorded call.  The result tensor is held WEAKLY (it holds the op): when the caller drops a pending result nobody
+    consumed, nothing can read or modify it any more, so the call runs right then (`__call__` is the weak reference's callback)
+    -- a dropped `norm(x)` still updates its running statistics when it is made, as it would executed immediately."""
+    __slots__ = ("kind", "mod", "inp", "_out", "relu", "residual", "cat_up", "cat_into", "grad", "uses", "aux", "dropped", "mgr",
+                 "__weakref__")
 
     def __init__(self, kind, mod, inp, out, aux=None):
-        self.kind, self.mod, self.inp, self.out, self.aux = kind, mod, inp, out, aux
+        self.kind, self.mod, self.inp, self.aux = kind, mod, inp, aux
+        self._out = weakref.ref(out, self)
+        self.mgr = weakref.ref(out._manager)
         self.relu, self.residual, self.cat_up, self.cat_into = False, None, 0, None
         self.grad = torch.is_grad_enabled()
         self.uses = 0            # recorded consumers of `out`
+        self.dropped = False
+
+    @property
+    def out(self):
+        return self._out()
+
+    def __call__(self, _ref):
+        """the pending result was garbage-collected"""
+        self.dropped = True
+        mgr = self.mgr()
+        if mgr is None or not ENABLED or sys.is_finalizing():
+            return
+        q = mgr._pending
+        if q and any(o is self for o in q):
+            try:
+                _drain(mgr, q, False)
+            except Exception as e:       # (an exception cannot leave a weak-reference callback)
+                print("[lgs] a dropped MinkowskiEngine call failed when it was executed: %s: %s" % (type(e).__name__, e), file=sys.stderr)
 
 
 class _Dead:
@@ -85,6 +119,8 @@ def record_conv(mod, inp, resolved):
     op = out._op = Op(CONV, mod, inp, out, resolved)
     _use(inp)
     _push(mgr, op)
+    if INCREMENTAL:
+        advance(mgr)
     return out
 
 
@@ -110,6 +146,8 @@ def record_cat(tensors):
     for t in tensors:
         _use(t)
     _push(mgr, op)
+    if INCREMENTAL:
+        advance(mgr)
     return out
 
 
@@ -155,21 +193,53 @@ def materialise(t):
 
 
 def flush(mgr):
+    """execute everything recorded on this manager (a value is needed)"""
     q = mgr._pending
     if not q:
         return
-    mgr._pending = []
-    _LIVE.discard(mgr)
     STATS["flushes"] += 1
-    STATS["ops"] += len(q)
+    _drain(mgr, q, True)
+
+
+def advance(mgr):
+    """execute the head of the queue as far as no later call can change what it means (INCREMENTAL): a convolution runs once it is
+    known not to open a residual block (or the block is complete), a norm once its result has a consumer (its ReLU / residual
+    epilogue is then final).  Called whenever a consumer is recorded; the GPU starts on a layer while the host records the next"""
+    q = mgr._pending
+    if q:
+        _drain(mgr, q, False)
+
+
+def _drain(mgr, q, final):
+    if mgr._draining:              # re-entered from a weak-reference callback while an operation of this queue is executing
+        mgr._redrain = True
+        return
+    mgr._draining = True
     try:
-        _run(q)
+        while True:
+            mgr._redrain = False
+            done = _run(q, final)
+            STATS["ops"] += done
+            if done == len(q):
+                del q[:]
+                _LIVE.discard(mgr)
+                break
+            if done:
+                del q[:done]
+            if not mgr._redrain:
+                break
     except BaseException as e:
-        for op in q:
-            if op.out._op is not None and op.out._op.kind >= 0:
-                op.out._op = _Dead("a deferred MinkowskiEngine call recorded before this tensor failed: %s: %s"
-                                   % (type(e).__name__, e), e)
+        failed = list(q)
+        del q[:]
+        _LIVE.discard(mgr)
+        for op in failed:
+            t = op.out
+            if t is not None and t._op is not None and t._op.kind >= 0:
+                t._op = _Dead("a deferred MinkowskiEngine call recorded before this tensor failed: %s: %s"
+                              % (type(e).__name__, e), e)
         raise
+    finally:
+        mgr._draining = False
 
 
 def flush_all():
@@ -181,42 +251,28 @@ def pending_ops(mgr):
     return len(mgr._pending)
 
 
-def _plan_cat_hints(q):
-    """zero-copy `me.cat(up, skip)` (res16unet.py:237,247,257,267): when both inputs are results of norms still in the queue,
-    the skip's norm allocates the [N, C_up + C_skip] buffer and writes the right-hand columns, the up's norm the left-hand
-    ones, and the cat returns the buffer (MinkowskiBatchNorm._cat_slot_for; any condition it cannot honour -> the cat copies).
-    Only for skips whose other consumers read row-strided features in place or copy (convolutions)."""
-    cats = [op for op in q if op.kind == CAT and len(op.inp) == 2]
-    if not cats:
-        return
-    index = {id(op): i for i, op in enumerate(q)}
-    consumers = {}
-    for op in q:
-        ins = op.inp if op.kind == CAT else ((op.inp,) if op.residual is None else (op.inp, op.residual))
-        for t in ins:
-            consumers.setdefault(id(t), []).append(op)
-    for c in cats:
-        up, skip = c.inp
-        pa, pb = up._op, skip._op
-        if pa is None or pb is None or pa.kind != BN or pb.kind != BN or pa is pb:
-            continue
-        if index.get(id(pb), 1 << 30) > index.get(id(pa), -1) or pa.cat_into is not None or pb.cat_up or pa.cat_up or pb.cat_into is not None:
-            continue
-        if len(consumers.get(id(up), ())) != 1:
-            continue
-        if any(u.kind == BN for u in consumers.get(id(skip), ())):
-            continue
-        if not (pa.grad and pb.grad) and (pa.grad or pb.grad):
-            continue
-        pb.cat_up = up._nch()
-        pa.cat_into = skip
-        STATS["cat_hints"] += 1
+def _cat_partner(q, i, n, op):
+    """the `me.cat(up, skip)` (res16unet.py:237,247,257,267) this norm's result goes to as the FIRST input, if that is its only
+    consumer and the skip tensor exists already: the norm then writes straight into the left-hand columns of the [N, C_up +
+    C_skip] concat buffer (lgs_bn_forward's output row stride), the skip half is copied in once, and the cat returns the buffer
+    -- the concat costs one copy of the skip half instead of a copy of both halves (MinkowskiBatchNorm._cat_slot_for; any
+    condition it cannot honour -> the cat copies both)."""
+    if op.uses != 1 or op.cat_into is not None:
+        return None
+    for j in range(i + 1, min(i + 3, n)):
+        c = q[j]
+        if c.kind == CAT and len(c.inp) == 2 and c.inp[0] is op.out:
+            skip = c.inp[1]
+            if skip._op is None and c.grad == op.grad:
+                return c
+            return None
+    return None
 
 
-def _run(q):
+def _run(q, final):
+    """-> number of queue entries executed (all of them when `final`)"""
     from .core import cat_now
     from . import block as _block
-    _plan_cat_hints(q)
     hooks = UNIT_HOOKS
     ambient = torch.is_grad_enabled()
     n, i = len(q), 0
@@ -224,37 +280,53 @@ def _run(q):
         op = q[i]
         if op.grad != ambient:
             with torch.set_grad_enabled(op.grad):
-                i += _step(q, i, n, op, hooks, _block, cat_now, False)
+                took = _step(q, i, n, op, hooks, _block, cat_now, final)
         else:
-            i += _step(q, i, n, op, hooks, _block, cat_now, True)
+            took = _step(q, i, n, op, hooks, _block, cat_now, final)
+        if took <= 0:
+            break
+        i += took
+    return i
 
 
-def _step(q, i, n, op, hooks, _block, cat_now, may_block):
+def _step(q, i, n, op, hooks, _block, cat_now, final):
+    """execute q[i] (or the block it opens) -> entries consumed; 0 = not yet (only when not `final`)"""
     kind = op.kind
     if kind == CONV:
-        if may_block and op.grad and not hooks:
-            took = _block.try_block(q, i, n)
-            if took:
+        if not hooks:
+            took = _block.try_block(q, i, n, final)
+            if took > 0:
                 STATS["blocks"] += 1
                 return took
+            if took < 0:
+                return 0
         nxt = q[i + 1] if i + 1 < n else None
         bn = nxt.mod if (nxt is not None and nxt.kind == BN and nxt.inp is op.out and nxt.grad == op.grad) else None
         if hooks:
             for pre, _ in hooks:
                 pre(op.mod, (op.inp,), {})
-        op.mod._forward_now(op.inp, bn=bn, resolved=op.aux, out=op.out)
+        out = op.out
+        res = op.mod._forward_now(op.inp, bn=bn, resolved=op.aux, out=out)
         if hooks:
             for _, post in hooks:
-                post(op.mod, (op.inp,), {}, op.out)
+                post(op.mod, (op.inp,), {}, res)
     elif kind == BN:
+        if op.uses == 0 and not final and not op.dropped:
+            return 0                       # still open: an in-place ReLU or `+=` may follow
+        cat = _cat_partner(q, i, n, op)
+        if cat is not None:
+            op.cat_into = cat.inp[1]
+            STATS["cat_hints"] += 1
         if hooks:
             kw = {"relu": op.relu, "residual": op.residual, "cat_up": op.cat_up, "cat_into": op.cat_into}
             for pre, _ in hooks:
                 pre(op.mod, (op.inp,), kw)
-        op.mod._forward_now(op.inp, op.relu, op.residual, op.cat_up, op.cat_into, out=op.out)
+        res = op.mod._forward_now(op.inp, op.relu, op.residual, op.cat_up, op.cat_into, out=op.out)
         if hooks:
             for _, post in hooks:
-                post(op.mod, (op.inp,), kw, op.out)
+                post(op.mod, (op.inp,), kw, res)
     else:
-        cat_now(op.inp, out=op.out)
+        out = op.out
+        if out is not None:                # (a dropped concat has no side effect: nothing to do)
+            cat_now(op.inp, out=out)
     return 1

@@ -360,6 +360,8 @@ class _CatSlot:
     """where a norm writes its output for a zero-copy ME.cat: column offset `off` of the [N, C_total] concat buffer `buf`
     (a plain Python object on purpose: autograd must not see the buffer as a tensor input of the norm)"""
 
+    partner = None       # the skip tensor whose features were COPIED into the right-hand columns (half-copy concat)
+
     def __init__(self, buf, off, width):
         self.buf, self.off, self.width = buf, off, width
 
@@ -478,10 +480,23 @@ class MinkowskiBatchNorm(nn.Module):
             return _CatSlot(buf, cat_up, c)
         if cat_into is not None:
             other = cat_into._cat_slot
-            if (other is not None and other.off == c and other.buf.shape[0] == x.shape[0] and other.buf.dtype == x.dtype
-                    and not getattr(other, "taken", False)):
-                other.taken = True
-                return _CatSlot(other.buf, 0, c)
+            if other is not None:
+                if (other.off == c and other.buf.shape[0] == x.shape[0] and other.buf.dtype == x.dtype
+                        and not getattr(other, "taken", False)):
+                    other.taken = True
+                    return _CatSlot(other.buf, 0, c)
+                return None
+            # the skip tensor exists already as an ordinary tensor: this norm writes the left-hand columns of a fresh concat
+            # buffer, the skip half is copied in once (me/deferred.py _cat_partner)
+            if cat_into._op is None and c % al == 0:
+                sf = cat_into._F
+                if (sf.is_cuda and sf.dim() == 2 and sf.shape[0] == x.shape[0] and sf.dtype == x.dtype and sf.shape[1] % al == 0):
+                    buf = torch.empty((x.shape[0], c + sf.shape[1]), dtype=x.dtype, device=x.device)
+                    with torch.no_grad():
+                        buf[:, c:].copy_(sf)
+                    slot = _CatSlot(buf, 0, c)
+                    slot.partner = cat_into
+                    return slot
         return None
 
     def __repr__(self):

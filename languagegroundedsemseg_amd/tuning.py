@@ -14,6 +14,10 @@ HOST_KNOBS = {
     "DEFER": (1, int, "0 = every MinkowskiEngine call executes immediately (the reference's call sequence runs unfused: separate norm, "
                       "ReLU, add and concat-copy kernels) instead of being recorded and run fused when a value is first read "
                       "(me/deferred.py; same results: tests/test_gpu_reference_calls.py)"),
+    "DEFER_INCREMENTAL": (1, int, "1 = recorded calls execute as soon as no later call can change them (a norm once its result is "
+                                  "consumed, a convolution once it is known whether it opens a residual block): the GPU works on a layer "
+                                  "while the host records the next; 0 = nothing executes until a value is read (one scene per step: "
+                                  "the whole forward is then recorded before the first launch, +1 - 2 ms of latency)"),
     "BLOCK_FUSED": (1, int, "0 = BasicBlocks run module by module instead of as one autograd node "
                             "(bit-identical: test_block_fast_path_is_the_op_by_op_path)"),
     "BLOCK_C": (1, int, "0 = a BasicBlock is enqueued call by call instead of through lgs_block_forward / lgs_block_backward "
@@ -27,8 +31,10 @@ HOST_KNOBS = {
                                   "e.g. the 1x1 512->544 dgrad 1.37 instead of 11.6 ms, but the step is the sum of its kernels either way)"),
     "CONV_BN_STATS": ("", str, "'1' / 'big' = BatchNorm statistics from the conv epilogue (measured slower: 31.5 vs 30.9 ms; off)"),
     "DBG_WGRAD": ("", str, "'skip' / 'inline': step-time attribution experiments only ('skip' produces no weight gradients)"),
-    "SYNCBN_ENGINE_COMM": (1, int, "1 = MinkowskiSyncBatchNorm's collectives are issued by the engine on its own RCCL communicator, on the "
-                                   "compute stream (csrc/lgs_comm.hip); 0 = torch.distributed collectives between the split kernels"),
+    "SYNCBN_ENGINE_COMM": (-1, int, "MinkowskiSyncBatchNorm's collectives issued by the engine on its own RCCL communicator, on the compute "
+                                    "stream (csrc/lgs_comm.hip): 1 = always, 0 = never (torch.distributed collectives between the split "
+                                    "kernels), -1 = auto: only in a world of ONE rank (two communicators in flight next to each other have "
+                                    "never been executed with a peer on this build's one-GPU boxes; ddp.EngineComm)"),
     "SET_HW_QUEUES": (0, int, "1 = importing the package sets GPU_MAX_HW_QUEUES=8 before the HIP runtime starts (see configure_hw_queues)"),
 }
 

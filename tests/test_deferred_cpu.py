@@ -20,10 +20,10 @@ from oracle.backend import OracleBackend
 @pytest.fixture(autouse=True)
 def _oracle_backend():
     prev = ME.set_backend(OracleBackend("torch"))
-    was = deferred.ENABLED
-    deferred.ENABLED = True
+    was = deferred.ENABLED, deferred.INCREMENTAL
+    deferred.ENABLED, deferred.INCREMENTAL = True, False      # the whole record stays in the queue until a value is read
     yield
-    deferred.ENABLED = was
+    deferred.ENABLED, deferred.INCREMENTAL = was
     ME.set_backend(prev)
 
 
@@ -80,12 +80,48 @@ def test_deferred_equals_immediate_whole_network(name):
     a, b = run(True), run(False)
     n_units = {"Res16UNet14A": 33 + 32 + 4, "Res16UNet34C": 63 + 62 + 4}[name]       # convs + norms + cats: ReLUs and adds are epilogues
     assert a[4] == n_units and b[4] == 0
-    assert deferred.STATS["cat_hints"] == hints0 + 4                 # all four me.cat(up, skip) pairs were planned as zero-copy
+    assert deferred.STATS["cat_hints"] == hints0 + 4                 # all four me.cat(up, skip): `up` goes straight into the concat buffer
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     for k in a[2]:
         assert torch.equal(a[2][k], b[2][k]), k
     for k in a[3]:
         assert torch.equal(a[3][k], b[3][k]), k
+
+
+@pytest.mark.parametrize("name", ["Res16UNet14A", "Res16UNet34C"])
+def test_incremental_execution_runs_the_head_of_the_queue_and_equals_immediate(name):
+    """INCREMENTAL (the default): a recorded call executes as soon as no later call can change it, so the queue never holds more
+    than the open tail of one residual block; results are those of immediate execution"""
+    c, f = _scene(1500)
+    lab = torch.from_numpy(np.random.default_rng(0).integers(-1, 20, c.shape[0]).astype(np.int64))
+    deferred.INCREMENTAL = True
+    depth = []
+    orig = deferred.advance
+
+    def spy(mgr):
+        orig(mgr)
+        depth.append(len(mgr._pending))
+    deferred.advance = spy
+    try:
+        def run(defer):
+            deferred.ENABLED = defer
+            m = deterministic_init(models.load_model(name)(3, 20, Cfg()), 42).train()
+            logits, out = m(ME.SparseTensor(f, c))
+            loss = torch.nn.functional.cross_entropy(logits.F, lab, ignore_index=-1)
+            loss.backward()
+            return logits.F.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}, {k: b.clone() for k, b in m.named_buffers()}
+        hints0 = deferred.STATS["cat_hints"]
+        a = run(True)
+        assert deferred.STATS["cat_hints"] == hints0 + 4             # the four me.cat(up, skip): `up` written into the concat buffer
+        assert depth and max(depth) <= 6                             # conv, norm, conv, norm, downsample conv, downsample norm
+        b = run(False)
+    finally:
+        deferred.advance = orig
+    assert torch.equal(a[0], b[0])
+    for k in a[1]:
+        assert torch.equal(a[1][k], b[1][k]), k
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
 
 
 def test_inplace_semantics_relu_and_iadd_after_a_consumer_are_not_absorbed():
@@ -149,6 +185,32 @@ def test_train_eval_switch_executes_what_is_pending_first():
     assert out._op is None
     assert torch.allclose(out.F, torch.nn.functional.batch_norm(f, None, None, training=True), atol=1e-5)
     assert int(bn.bn.num_batches_tracked) == 1
+
+
+def test_a_dropped_result_runs_when_it_is_dropped():
+    """`norm(x)` whose result nobody keeps (a statistics-recalibration pass, a hook-free warm-up): nothing can read or modify the
+    pending tensor any more, so the call executes when the tensor is collected -- running statistics move exactly as if the call
+    had executed immediately"""
+    c, f = _scene(ch=8)
+    for incremental in (False, True):
+        deferred.INCREMENTAL = incremental
+        bn = ME.MinkowskiBatchNorm(8, momentum=0.5).train()
+        x = ME.SparseTensor(f * 3 + 1, c)
+        for k in range(2):
+            bn(x)
+            assert int(bn.bn.num_batches_tracked) == k + 1
+        ref = torch.nn.BatchNorm1d(8, momentum=0.5).train()
+        for _ in range(2):
+            ref(f * 3 + 1)
+        assert torch.allclose(bn.bn.running_mean, ref.running_mean, atol=1e-6) and torch.allclose(bn.bn.running_var, ref.running_var, atol=1e-5)
+        assert not x.coordinate_manager._pending
+    # a dropped model output: every norm of the network has updated its statistics once
+    deferred.INCREMENTAL = True
+    cc, ff = _scene(1500)
+    m = deterministic_init(models.load_model("Res16UNet14A")(3, 20, Cfg()), 42).train()
+    m.representation_only(True)
+    m(ME.SparseTensor(ff, cc))
+    assert all(int(b) == 1 for k, b in m.named_buffers() if k.endswith("num_batches_tracked"))
 
 
 def test_failure_inside_the_queue_poisons_later_reads():

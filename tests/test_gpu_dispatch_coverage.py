@@ -82,7 +82,12 @@ def test_every_kernel_the_benchmark_dispatches_is_reached_by_a_parity_test(reque
     suite = {k: v for k, v in conftest.DISPATCHED.items() if k != mine}
     if len(suite) < MIN_SUITE:
         pytest.skip("needs the whole `-m gpu` suite in the same session (%d GPU tests ran before this one, %d required)" % (len(suite), MIN_SUITE))
-    covered = set().union(*suite.values())
+    # a launch site counts as covered only through a test that compared the HIP path with an INDEPENDENT reference: the CPU oracle,
+    # a reference-generated golden fixture (both detected at run time by conftest), or a plain-torch restatement named by the
+    # `parity` marker.  Bit-identity / property tests that compare the HIP path with itself do not cover anything.
+    parity = {k: v for k, v in suite.items() if conftest.PARITY.get(k)}
+    covered = set().union(*parity.values())
+    self_only = set().union(*suite.values()) - covered
     bench_sites = _bench_sites()
     unreached = {}
     for tag, sites in bench_sites.items():
@@ -91,7 +96,14 @@ def test_every_kernel_the_benchmark_dispatches_is_reached_by_a_parity_test(reque
             unreached.setdefault(s, []).append(tag)
     for tag, sites in bench_sites.items():
         print("%-36s %3d launch sites" % (tag, len(sites)))
-    print("parity suite: %d tests, %d launch sites" % (len(suite), len(covered)))
+    print("GPU suite: %d tests, of which %d ran against an independent reference (%s); %d launch sites covered by those" % (
+        len(suite), len(parity), ", ".join("%s: %d" % (a, sum(1 for v in conftest.PARITY.values() if v and a in v)) for a in ("oracle", "golden")),
+        len(covered)))
+    bench_all = set().union(*bench_sites.values())
+    print("launch sites reached ONLY by self-comparison tests: %d, of which the benchmark dispatches %d" % (
+        len(self_only), len(self_only & bench_all)))
+    for s_ in sorted(self_only):
+        print("   self-only%s  %s" % (" [BENCH]" if s_ in bench_all else "        ", s_))
     assert not unreached, "kernel launch sites the benchmark dispatches that NO parity test reaches:\n" + "\n".join(
         "  %s   <- %s" % (s, ", ".join(t)) for s, t in sorted(unreached.items()))
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.parity("reference-generated golden fixtures loaded at module level")]
 DEV = "cuda:0"
 G = os.path.join(os.path.dirname(__file__), "golden")
 FX = np.load(os.path.join(G, "contrastive_loss.npz"))
