@@ -74,7 +74,9 @@ int lgs_block_backward(const lgs_block_bwd *a, void *stream) {
   // norm1 + ReLU: mask recomputed from its input
   if ((rc = lgs_bn_backward(a->o1, nullptr, a->dy1, 0, a->n, c, a->gamma1, a->beta1, a->st1, 2, a->dx1, nullptr, a->dgamma1, a->dbeta1, dt,
                             a->bn_ws, 0, stream))) return rc;
-  if ((rc = wgrad(a->km3, a->x, a->cin, a->dx1, a->gw1, a->x_row_stride, a->ev_w1))) return rc;
+  // (A/B knob BLOCK_WGRAD_LATE: the first convolution's weight gradient is forked AFTER the block's last dgrad instead of beside it)
+  const bool late = lgs::tune(lgs::T_BLOCK_WGRAD_LATE) != 0 && a->wgrad_stream && a->want_gin;
+  if (!late && (rc = wgrad(a->km3, a->x, a->cin, a->dx1, a->gw1, a->x_row_stride, a->ev_w1))) return rc;
   void *acc = a->dres;       // the residual branch's gradient w.r.t. x
   if (a->km1) {
     LGS_REQUIRE(a->od && a->std_ && a->wd && a->dxd && a->gwd && a->gind, "lgs_block_backward: downsample branch tensors missing");
@@ -89,7 +91,9 @@ int lgs_block_backward(const lgs_block_bwd *a, void *stream) {
   if (!a->want_gin) return 0;
   // grad_in = dgrad1(dx1) + (gradient of the residual branch): in the epilogue where the launch shape has an accumulating one
   LGS_REQUIRE(lgs_conv_dgrad_can_accumulate(a->km3, 0, a->cin, c, dt), "lgs_block_backward: this shape needs the call-by-call path (no accumulating dgrad)");
-  return lgs_conv_dgrad_accumulate(a->km3, 0, a->dx1, c, a->w1, a->cin, acc, dt, a->conv_ws, a->pk1, a->pm1, stream);
+  if ((rc = lgs_conv_dgrad_accumulate(a->km3, 0, a->dx1, c, a->w1, a->cin, acc, dt, a->conv_ws, a->pk1, a->pm1, stream))) return rc;
+  if (late) return wgrad(a->km3, a->x, a->cin, a->dx1, a->gw1, a->x_row_stride, a->ev_w1);
+  return 0;
 }
 
 }  // extern "C"

@@ -26,14 +26,32 @@
 namespace lgs {
 
 
+// fp32 STORAGE whose products run on the bf16 matrix pipe (round 5): every fp32 operand is split exactly into three bf16 pieces
+// x = hi + mid + lo (8 + 8 + 8 significant bits, by truncation: each remainder is exact), and x * w is accumulated in fp32 from
+// the six products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid -- what is dropped (mid*lo, lo*mid, lo*lo) is below 2^-24 |x w|.
+// v_mfma_f32_32x32x16_bf16 runs 16 x the flops per cycle of v_mfma_f32_32x32x2_f32: six products are 2.7 x faster on the pipe.
+// The feature operand is split in registers as it streams through (11 VALU instructions per pair of elements, reused by every
+// output-channel block of the wave); the weights are split once, when the packed image is made (three pieces per element).
+struct f32s_t { float v; };
+constexpr int kDtF32Split = 2;      // lgs_pack_desc.dtype of an image packed for f32s_t (internal; tensors are LGS_F32)
 template <typename T> struct Tr;
 template <> struct Tr<float> {
   static constexpr int EPL = 4;  // elements per 16-byte load
   static constexpr int LD = 4;   // 16-byte loads per lane per 32-channel chunk
+  static constexpr int WLD = 4;  // 16-byte weight fragments per lane, chunk and output block
+  static constexpr bool SPLIT = false;
 };
 template <> struct Tr<bf16_t> {
   static constexpr int EPL = 8;
   static constexpr int LD = 2;
+  static constexpr int WLD = 2;
+  static constexpr bool SPLIT = false;
+};
+template <> struct Tr<f32s_t> {
+  static constexpr int EPL = 4;
+  static constexpr int LD = 4;
+  static constexpr int WLD = 6;  // [k-step of 16 channels: 2][piece hi / mid / lo: 3]
+  static constexpr bool SPLIT = true;
 };
 
 
@@ -45,6 +63,30 @@ template <typename T> __device__ inline void mma16(f32x16 &acc, const u32x4 &w, 
 template <> __device__ inline void mma16<bf16_t>(f32x16 &acc, const u32x4 &w, const u32x4 &f) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, f), acc, 0, 0, 0);
 }
+__device__ inline void mma_bf16(f32x16 &acc, const u32x4 &w, const u32x4 &f) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, f), acc, 0, 0, 0);
+}
+// one fp32 value -> its three bf16 pieces as the upper halves of three dwords (hi + mid + lo == x exactly)
+__device__ inline void split3(uint32_t x, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+  hi = x & 0xffff0000u;
+  const float r1 = __uint_as_float(x) - __uint_as_float(hi);
+  mid = __float_as_uint(r1) & 0xffff0000u;
+  lo = __float_as_uint(r1 - __uint_as_float(mid));          // <= 8 significant bits: its lower half is zero
+}
+// eight consecutive fp32 reduction elements (two 16-byte loads) -> three bf16x8 MFMA operands
+__device__ inline void split8(const u32x4 &a, const u32x4 &b, u32x4 &hi, u32x4 &mid, u32x4 &lo) {
+  const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint32_t h[8], m[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) split3(x[i], h[i], m[i], l[i]);
+  // element 2i in the low half, 2i + 1 in the high half of dword i: v_perm_b32 picks the upper halves of both
+#define LGS_PK(v, i) __builtin_amdgcn_perm(v[2 * (i) + 1], v[2 * (i)], 0x07060302u)
+  hi = u32x4{LGS_PK(h, 0), LGS_PK(h, 1), LGS_PK(h, 2), LGS_PK(h, 3)};
+  mid = u32x4{LGS_PK(m, 0), LGS_PK(m, 1), LGS_PK(m, 2), LGS_PK(m, 3)};
+  lo = u32x4{LGS_PK(l, 0), LGS_PK(l, 1), LGS_PK(l, 2), LGS_PK(l, 3)};
+#undef LGS_PK
+}
+template <> __device__ inline void mma16<f32s_t>(f32x16 &acc, const u32x4 &w, const u32x4 &f) { (void)acc; (void)w; (void)f; }   // (unused: see compute)
 template <> __device__ inline void mma16<float>(f32x16 &acc, const u32x4 &w, const u32x4 &f) {
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(f.x), acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(f.y), acc, 0, 0, 0);
@@ -66,7 +108,7 @@ template <> __device__ inline void mma16<float>(f32x16 &acc, const u32x4 &w, con
 template <typename T>
 __device__ inline uint4 pack_one(const float *__restrict__ w, int K, int cin_w, int cout_w, int transposed, int mirror, int g_real,
                                  int o_real, int nc, int nb_total, int64_t idx) {
-  constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
+  constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::WLD;
   int lane = (int)(idx & 63);
   int64_t r = idx >> 6;
   int t = (int)(r % LD); r /= LD;
@@ -76,6 +118,22 @@ __device__ inline uint4 pack_one(const float *__restrict__ w, int K, int cin_w, 
   int ks = (transposed && mirror) ? K - 1 - kd : kd;
   int j = lane & 31, h = lane >> 5;
   int o = nb * 32 + j;
+  if constexpr (Tr<T>::SPLIT) {
+    // fragment t = 3 tt + piece: the eight reduction elements g = c*32 + h*16 + tt*8 + e of k-step tt, as bf16 piece `piece`
+    const int tt = t / 3, piece = t % 3;
+    uint32_t pc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = c * 32 + h * 16 + tt * 8 + e;
+      float x = 0.f;
+      if (g < g_real && o < o_real)
+        x = transposed ? w[((int64_t)ks * cin_w + o) * cout_w + g] : w[((int64_t)ks * cin_w + g) * cout_w + o];
+      uint32_t hi, mid, lo;
+      split3(__float_as_uint(x), hi, mid, lo);
+      pc[e] = piece == 0 ? hi : (piece == 1 ? mid : lo);
+    }
+    return make_uint4((pc[0] >> 16) | pc[1], (pc[2] >> 16) | pc[3], (pc[4] >> 16) | pc[5], (pc[6] >> 16) | pc[7]);
+  }
   float vals[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) {
@@ -101,7 +159,7 @@ template <typename T>
 __global__ void k_pack_weights(const float *__restrict__ w, int K, int cin_w, int cout_w, int transposed, int mirror,
                                int g_real, int o_real, int nc /*padded chunks*/, int nb_total /*padded blocks*/,
                                uint4 *__restrict__ dst) {
-  constexpr int LD = Tr<T>::LD;
+  constexpr int LD = Tr<T>::WLD;
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t total = (int64_t)K * nc * nb_total * LD * 64;
   if (idx >= total) return;
@@ -115,9 +173,11 @@ __global__ void k_pack_weights_batch(const lgs_pack_desc *__restrict__ descs) {
   if (idx >= e.total) return;
   uint4 *dst = reinterpret_cast<uint4 *>(e.packed);
   if (e.dtype == LGS_BF16) dst[idx] = pack_one<bf16_t>(e.weight, e.K, e.cin_w, e.cout_w, e.transposed, e.mirror, e.g_real, e.o_real, e.ncp, e.nbp, idx);
+  else if (e.dtype == kDtF32Split) dst[idx] = pack_one<f32s_t>(e.weight, e.K, e.cin_w, e.cout_w, e.transposed, e.mirror, e.g_real, e.o_real, e.ncp, e.nbp, idx);
   else dst[idx] = pack_one<float>(e.weight, e.K, e.cin_w, e.cout_w, e.transposed, e.mirror, e.g_real, e.o_real, e.ncp, e.nbp, idx);
 }
 
+// (descriptor dtype code of a split-fp32 image: internal to the packed-image descriptors, never a tensor dtype)
 // pad rows [n, c] -> [n, cpad] (zero fill) for channel counts that are not a multiple of the load width
 template <typename T>
 __global__ void k_pad_rows(const T *__restrict__ src, int64_t n, int c, int cpad, T *__restrict__ dst) {
@@ -168,7 +228,9 @@ __device__ inline void load4(const bf16_t *p, float (&v)[4]) {
   const uint2 t = *reinterpret_cast<const uint2 *>(p);
   v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
+__device__ inline void load4(const f32s_t *p, float (&v)[4]) { load4(reinterpret_cast<const float *>(p), v); }
 template <typename T> __device__ inline float stored_value(float x);
+template <> __device__ inline float stored_value<f32s_t>(float x) { return x; }
 template <> __device__ inline float stored_value<float>(float x) { return x; }
 template <> __device__ inline float stored_value<bf16_t>(float x) { return bf16_to_f32(f32_to_bf16(x)); }
 template <typename T> __device__ inline float sq16(const u32x4 &f, float s);
@@ -181,6 +243,10 @@ template <> __device__ inline float sq16<bf16_t>(const u32x4 &f, float s) {
     s = fmaf(hi, hi, fmaf(lo, lo, s));
   }
   return s;
+}
+template <> __device__ inline float sq16<f32s_t>(const u32x4 &f, float s) {
+  const float a = __uint_as_float(f.x), b = __uint_as_float(f.y), c = __uint_as_float(f.z), d = __uint_as_float(f.w);
+  return fmaf(d, d, fmaf(c, c, fmaf(b, b, fmaf(a, a, s))));
 }
 template <> __device__ inline float sq16<float>(const u32x4 &f, float s) {
   const float a = __uint_as_float(f.x), b = __uint_as_float(f.y), c = __uint_as_float(f.z), d = __uint_as_float(f.w);
@@ -204,11 +270,11 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   // and one barrier separates slabs, while the gathered feature fragments stream chunk by chunk through a
   // D-deep register ring (loads issued D-1 chunks = several hundred MFMA cycles ahead of their use) that runs
   // across slab and offset boundaries.
-  constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
+  constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD, WLD = Tr<T>::WLD;
   constexpr int NT = WM * WN * 64;
   constexpr int TM = WM * RB * 32;
   constexpr int WB = WN * NCB;                 // weight blocks per chunk
-  constexpr int WCH = WB * LD * 64;            // uint4 per chunk
+  constexpr int WCH = WB * WLD * 64;           // uint4 per chunk
   constexpr int SLAB = SC * WCH;               // uint4 per slab
   constexpr int WR = (SLAB + NT - 1) / NT;     // staging registers per thread
   __shared__ u32x4 lds[2][SLAB];
@@ -353,11 +419,11 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
   for (int i = 0; i < WR; ++i) {
     const int e = min(tid + i * NT, SLAB - 1);
     const int cw = e / WCH, ee = e - cw * WCH;
-    woff[i] = (unsigned)(cw * nbp * (LD * 64) + ee) * 16u;
+    woff[i] = (unsigned)(cw * nbp * (WLD * 64) + ee) * 16u;
   }
   auto wissue = [&](u32x4 (&wreg)[WR]) __attribute__((always_inline)) {
     const int kw = v.KS > 1 ? wslot : kw_single;  // 3^3 dgrad mirroring (K-1-k) is folded into the weight packing
-    const unsigned sbase = (unsigned)((((int64_t)kw * ncp + wslab * SC) * nbp + nb_wg) * (LD * 64) * 16);
+    const unsigned sbase = (unsigned)((((int64_t)kw * ncp + wslab * SC) * nbp + nb_wg) * (WLD * 64) * 16);
 #pragma unroll
     for (int i = 0; i < WR; ++i) wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[i], sbase, 0);
   };
@@ -375,7 +441,39 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv_gather(View v, const T *__
 #pragma unroll
       for (int t = 0; t < LD; ++t) sumsq = sq16<T>(F[0][t], sumsq);
     }
-    const u32x4 *wl = &lds[buf][cc * WCH + (wn * NCB) * LD * 64 + lane];
+    const u32x4 *wl = &lds[buf][cc * WCH + (wn * NCB) * WLD * 64 + lane];
+    if constexpr (Tr<T>::SPLIT) {
+      // split fp32: per k-step of 16 channels (two of the lane's four loads) the feature fragment becomes three bf16 operands,
+      // reused by all NCB column blocks; the six products go smallest first into the same fp32 accumulator
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        u32x4 wf3[3][NCB];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+          for (int nb = 0; nb < NCB; ++nb) wf3[pc][nb] = wl[(nb * WLD + tt * 3 + pc) * 64];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          if (act & (1u << rb)) {
+            u32x4 fh, fm, fl;
+            split8(F[rb][2 * tt], F[rb][2 * tt + 1], fh, fm, fl);
+#pragma unroll
+            for (int nb = 0; nb < NCB; ++nb) mma_bf16(acc[rb][nb], wf3[2][nb], fh);
+#pragma unroll
+            for (int nb = 0; nb < NCB; ++nb) mma_bf16(acc[rb][nb], wf3[0][nb], fl);
+#pragma unroll
+            for (int nb = 0; nb < NCB; ++nb) mma_bf16(acc[rb][nb], wf3[1][nb], fm);
+#pragma unroll
+            for (int nb = 0; nb < NCB; ++nb) mma_bf16(acc[rb][nb], wf3[1][nb], fh);
+#pragma unroll
+            for (int nb = 0; nb < NCB; ++nb) mma_bf16(acc[rb][nb], wf3[0][nb], fm);
+#pragma unroll
+            for (int nb = 0; nb < NCB; ++nb) mma_bf16(acc[rb][nb], wf3[0][nb], fh);
+          }
+        }
+      }
+      return;
+    }
     // all weight fragments of the chunk are requested up front: the LDS latency of step t+1 hides under the
     // MFMAs of step t (the compiler otherwise waits lgkmcnt(0) in front of every MFMA triple)
     u32x4 wf[LD][NCB];
@@ -832,7 +930,7 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
                   float *out_f32 = nullptr, const float *row_scale = nullptr, float *zpartial = nullptr,
                   const BnEpi *bn = nullptr, int *bn_rows = nullptr, int in_ld = 0) {
   if (v.n_pad == 0) return 0;
-  constexpr int LDc = Tr<T>::LD;
+  constexpr int LDc = Tr<T>::WLD;
   const uint64_t in_bytes64 = (uint64_t)v.n_in * (uint64_t)(in_ld > 0 ? in_ld : cin_real) * sizeof(T);
   const uint64_t w_bytes64 = (uint64_t)K * ncp * nbp * LDc * 64 * 16;
   LGS_REQUIRE(in_bytes64 < 0xfffff000ull && w_bytes64 < 0xfffff000ull,
@@ -873,12 +971,12 @@ int launch_gather(const View &v, const GatherCfg &cfg, const T *in, int cin_real
     case 3: LGS_LAUNCH(2, 4, 4, 1, (kF32 ? 1 : 2), (kF32 ? 2 : 3)); break;
     case 4: LGS_LAUNCH(1, 1, 2, 1, (kF32 ? 2 : 4), (kF32 ? 4 : 8)); break;
     case 6: LGS_LAUNCH(1, 7, 4, 1, (kF32 ? 1 : 2), (kF32 ? 3 : 4)); break;
-    case 7: LGS_LAUNCH(1, 4, 4, 1, 2, 4); break;
-    case 16: LGS_LAUNCH(1, 8, 8, 1, 2, 4); break;
-    case 8: LGS_LAUNCH(1, 2, 4, 1, 4, 6); break;
-    case 9: LGS_LAUNCH(1, 2, 2, 2, 4, 6); break;
-    case 10: LGS_LAUNCH(1, 2, 2, 1, 4, 6); break;
-    case 11: LGS_LAUNCH(1, 4, 2, 1, 4, 6); break;
+    case 7: if constexpr (!kF32) LGS_LAUNCH(1, 4, 4, 1, 2, 4); break;      // ids 7 .. 13, 16: bf16 only (gather_cfg)
+    case 16: if constexpr (!kF32) LGS_LAUNCH(1, 8, 8, 1, 2, 4); break;
+    case 8: if constexpr (!kF32) LGS_LAUNCH(1, 2, 4, 1, 4, 6); break;
+    case 9: if constexpr (!kF32) LGS_LAUNCH(1, 2, 2, 2, 4, 6); break;
+    case 10: if constexpr (!kF32) LGS_LAUNCH(1, 2, 2, 1, 4, 6); break;
+    case 11: if constexpr (!kF32) LGS_LAUNCH(1, 4, 2, 1, 4, 6); break;
     case 12: if constexpr (!kF32) LGS_LAUNCH(1, 2, 4, 1, 8, 6); break;     // as 8 with 8-chunk (256-channel) weight slabs: half the slab barriers
     case 13: if constexpr (!kF32) LGS_LAUNCH(1, 4, 4, 1, 8, 4); break;     // 128 positions x 128 channels, 8-chunk slabs
     default: LGS_LAUNCH(1, 1, 2, 2, (kF32 ? 2 : 4), (kF32 ? 4 : 8)); break;
@@ -908,18 +1006,19 @@ int bn_partial_rows_t(const View &v, int K, int o_real) {
   return split ? 0 : (int)gx;
 }
 
-template <typename T>
+// T = storage type of the tensors, TK = the kernel instance that multiplies them (TK = f32s_t: fp32 tensors, split-bf16 products)
+template <typename T, typename TK = T>
 int conv_gather_op(const View &v, const void *in_v, int g_real, const float *weight, int K, int cin_w, int cout_w,
                    int transposed_w, int o_real, const float *bias, void *out_v, void *workspace, hipStream_t s,
                    int w_o_real = -1, const BnEpi *bn = nullptr, void *packed_ext = nullptr, int pack_mode = 0, int in_ld = 0) {
   if (w_o_real < 0) w_o_real = o_real;
   LGS_REQUIRE(in_ld == 0 || in_ld == g_real || (g_real % Tr<T>::EPL == 0 && o_real % 4 == 0 && in_ld > g_real && (in_ld * (int)sizeof(T)) % 16 == 0),
               "sparse conv: a strided input needs 16-byte aligned rows and channel counts on the 16-byte grid");
-  constexpr int EPL = Tr<T>::EPL, LD = Tr<T>::LD;
+  constexpr int EPL = Tr<T>::EPL, LD = Tr<TK>::WLD;
   const int g_pad = pad32(g_real), nc = g_pad / 32, nb_total = pad32(o_real) / 32;
   char *ws = reinterpret_cast<char *>(workspace);
   uint4 *wp = reinterpret_cast<uint4 *>(ws);
-  const GatherCfg cfg = gather_cfg<T>(v, nb_total);
+  const GatherCfg cfg = gather_cfg<TK>(v, nb_total);
   const int ncp = (nc + cfg.sc - 1) / cfg.sc * cfg.sc, nbp = (nb_total + cfg.wb - 1) / cfg.wb * cfg.wb;
   int64_t wbytes = align256((int64_t)K * (nc + 3) * (nb_total + 3) * LD * 64 * 16);
   if (o_real % 4 != 0) {
@@ -936,7 +1035,7 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
       LGS_HIP(hipMemcpyAsync(bp, bias, sizeof(float) * o_real, hipMemcpyDeviceToDevice, s));
       bias4 = bp;
     }
-    int rc = conv_gather_op<T>(v, in_v, g_real, weight, K, cin_w, cout_w, transposed_w, o4, bias4, tmp, workspace, s, o_real);
+    int rc = conv_gather_op<T, TK>(v, in_v, g_real, weight, K, cin_w, cout_w, transposed_w, o4, bias4, tmp, workspace, s, o_real);
     if (rc) return rc;
     int64_t tot = v.n_out * (int64_t)o_real;
     if (tot > 0)
@@ -962,7 +1061,7 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
   if (packed_ext && o_real % 4 == 0 && g_real % EPL == 0) wp = reinterpret_cast<uint4 *>(packed_ext);
   else pack_mode = 0;
   if (pack_mode != 2)
-    LGS_KLAUNCH((k_pack_weights<T>), (unsigned)((total + 255) / 256), 256, 0, s, weight, K, cin_w, cout_w, transposed_w,
+    LGS_KLAUNCH((k_pack_weights<TK>), (unsigned)((total + 255) / 256), 256, 0, s, weight, K, cin_w, cout_w, transposed_w,
                        v.mirror, g_real, w_o_real, ncp, nbp, wp);
   LGS_HIP(hipGetLastError());
   // fp32 partial images of the slot split live behind the packed weights and the padded input
@@ -970,10 +1069,10 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
   if (w_o_real == o_real && split_partial_bytes(K, v.n_out, o_real) > 0)
     zpartial = reinterpret_cast<float *>(ws + wbytes + ((g_real % EPL != 0) ? align256(v.n_in * (int64_t)g_pad * (int64_t)sizeof(T)) : 0));
   int rows = 0;
-  int rc = launch_gather<T>(v, cfg, in, g_stride, nc, wp, nb_total, ncp, nbp, K, reinterpret_cast<T *>(out_v), o_real, bias, s,
+  int rc = launch_gather<TK>(v, cfg, reinterpret_cast<const TK *>(in), g_stride, nc, wp, nb_total, ncp, nbp, K, reinterpret_cast<TK *>(out_v), o_real, bias, s,
                             nullptr, nullptr, zpartial, bn, &rows, (in_ld > g_real && g_stride == g_real) ? in_ld : 0);
   if (rc) return rc;
-  LGS_REQUIRE(!(bn && bn->partial) || rows == bn_partial_rows_t<T>(v, K, o_real),
+  LGS_REQUIRE(!(bn && bn->partial) || rows == bn_partial_rows_t<TK>(v, K, o_real),
               "conv forward: BatchNorm statistics rows differ from lgs_conv_bn_partial_rows (internal error)");
   return 0;
 }
@@ -1089,11 +1188,13 @@ int pack_desc_t(const View &v, int K, int cin_w, int cout_w, int transposed_w, i
   d->ncp = (nc + cfg.sc - 1) / cfg.sc * cfg.sc;
   d->nbp = (nb_total + cfg.wb - 1) / cfg.wb * cfg.wb;
   d->K = K; d->cin_w = cin_w; d->cout_w = cout_w; d->transposed = transposed_w; d->mirror = mirror;
-  d->g_real = g_real; d->o_real = o_real; d->dtype = dtype;
-  d->total = (int64_t)K * d->ncp * d->nbp * LD * 64;
+  d->g_real = g_real; d->o_real = o_real; d->dtype = Tr<T>::SPLIT ? kDtF32Split : dtype;
+  d->total = (int64_t)K * d->ncp * d->nbp * Tr<T>::WLD * 64;
   d->bytes = d->total * 16;
   return 0;
 }
+
+inline bool fp32_split_on() { return tune(T_FP32_SPLIT) != 0; }
 
 }  // namespace lgs
 
@@ -1106,7 +1207,8 @@ int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtyp
   const int e = esize(dtype);
   if (op == 2) return lgs::wgrad_workspace_bytes(km, cin, cout, dtype);
   int g = op == 0 ? cin : cout, o = op == 0 ? cout : cin;
-  int64_t bytes = align256((int64_t)km->K * (pad32(g) + 96) * (pad32(o) + 96) * e);
+  // packed weights: fp32 images of the split path hold three bf16 pieces per element (6 instead of 4 bytes)
+  int64_t bytes = align256((int64_t)km->K * (pad32(g) + 96) * (pad32(o) + 96) * (dtype == LGS_F32 ? 6 : e));
   int64_t nmax = km->fwd.n_in > km->bwd.n_in ? km->fwd.n_in : km->bwd.n_in;
   if (g % epl(dtype) != 0) bytes += align256(nmax * pad32(g) * e);
   if (o % 4 != 0) bytes += align256(nmax * (int64_t)((o + 3) / 4 * 4) * e) + align256(4 * (int64_t)((o + 3) / 4 * 4)) + 256;   // scratch image + padded bias
@@ -1128,6 +1230,7 @@ int lgs_conv_pack_desc(const lgs_kmap *km, int op, int transposed, int cin, int 
   const View &v = op == 0 ? (transposed ? km->bwd : km->fwd) : (transposed ? km->fwd : km->bwd);
   const int mirror = (op == 1 && km->ks == 3) ? 1 : 0;
   const int g = op == 0 ? cin : cout, o = op == 0 ? cout : cin;
+  if (dtype == LGS_F32 && fp32_split_on()) return pack_desc_t<f32s_t>(v, km->K, cin, cout, op, mirror, g, o, dtype, out);
   if (dtype == LGS_F32) return pack_desc_t<float>(v, km->K, cin, cout, op, mirror, g, o, dtype, out);
   if (dtype == LGS_BF16) return pack_desc_t<bf16_t>(v, km->K, cin, cout, op, mirror, g, o, dtype, out);
   LGS_REQUIRE(false, "lgs_conv_pack_desc: unknown dtype");
@@ -1154,6 +1257,7 @@ int lgs_conv_forward(lgs_kmap *km, int transposed, const void *in, int cin, cons
   bn.partial = bn_partial; bn.pivot = bn_pivot;
   LGS_REQUIRE(!bn_partial || lgs_conv_bn_partial_rows(km, transposed, cout, dtype) > 0,
               "lgs_conv_forward: this launch shape produces no BatchNorm statistics (see lgs_conv_bn_partial_rows)");
+  if (dtype == LGS_F32 && fp32_split_on()) return conv_gather_op<float, f32s_t>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr, packed, pack_mode, in_row_stride);
   if (dtype == LGS_F32) return conv_gather_op<float>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr, packed, pack_mode, in_row_stride);
   if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, in, cin, weight, km->K, cin, cout, 0, cout, bias, out, workspace, s, -1, bn_partial ? &bn : nullptr, packed, pack_mode, in_row_stride);
   LGS_REQUIRE(false, "lgs_conv_forward: unknown dtype");
@@ -1167,6 +1271,7 @@ int lgs_conv_dgrad(lgs_kmap *km, int transposed, const void *grad_out, int cout,
   View vv = v; vv.mirror = (km->ks == 3) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   if (kmap_wait(km, s)) return 1;
+  if (dtype == LGS_F32 && fp32_split_on()) return conv_gather_op<float, f32s_t>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, nullptr, packed, pack_mode);
   if (dtype == LGS_F32) return conv_gather_op<float>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, nullptr, packed, pack_mode);
   if (dtype == LGS_BF16) return conv_gather_op<bf16_t>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, nullptr, packed, pack_mode);
   LGS_REQUIRE(false, "lgs_conv_dgrad: unknown dtype");
@@ -1194,6 +1299,7 @@ int lgs_conv_dgrad_accumulate(lgs_kmap *km, int transposed, const void *grad_out
   hipStream_t s = (hipStream_t)stream;
   if (kmap_wait(km, s)) return 1;
   BnEpi acc; acc.accum = 1;
+  if (dtype == LGS_F32 && fp32_split_on()) return conv_gather_op<float, f32s_t>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, &acc, packed, pack_mode);
   if (dtype == LGS_F32) return conv_gather_op<float>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, &acc, packed, pack_mode);
   return conv_gather_op<bf16_t>(vv, grad_out, cout, weight, km->K, cin, cout, 1, cin, nullptr, grad_in, workspace, s, -1, &acc, packed, pack_mode);
 }

@@ -695,6 +695,181 @@ __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(4))) void k
   }
 }
 
+// ------------------------------------------------------------------------------------------------ two launches, no barrier
+// Small layers (the coarse levels: a few thousand to ~100 k rows) are latency chains, not bandwidth: three dependent launches
+// per direction, or ONE launch with two hand-rolled grid barriers whose workgroups must all be resident before the first may
+// pass (round 4: 53 us per backward launch in the step, 8 % of the HBM peak; the weight-gradient kernel on the side stream owns
+// CUs for a millisecond at a time).  Here a direction is TWO ordinary launches: the column reduction into <= kFoldParts partial
+// rows, and an apply kernel whose every workgroup first folds those partial rows itself -- the threads of a workgroup that share
+// a channel group split the rows between them (fixed assignment, double accumulation, combined through LDS in lane order: every
+// workgroup computes bit-identical statistics) -- and then streams its rows.  No inter-workgroup synchronisation, no fold
+// launch; the redundant fold reads (workgroups x parts x 2C floats) stay in L2.  Workgroup 0 also writes what the fold kernels
+// write: saved statistics, running statistics, num_batches_tracked / d gamma, d beta.
+constexpr int kFoldParts = 64;      // partial rows (upper bound; knob BN_FOLD_PARTS)
+
+// -> this thread's channel-group totals of the two column sums, as doubles
+template <int W>
+__device__ inline void fold_in_block(const float *__restrict__ scratch, int nparts, int c, int G, int RL, int cg, int rl,
+                                     double (&t0)[W], double (&t1)[W]) {
+  __shared__ double fred[2][kNT][W];
+  double a0[W], a1[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) a0[i] = a1[i] = 0.0;
+  if (rl < RL) {
+    for (int b = rl; b < nparts; b += RL) {
+      const float *row = scratch + (int64_t)b * 2 * c + cg * W;
+#pragma unroll
+      for (int i = 0; i < W; ++i) { a0[i] += (double)row[i]; a1[i] += (double)row[c + i]; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < W; ++i) { fred[0][threadIdx.x][i] = a0[i]; fred[1][threadIdx.x][i] = a1[i]; }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < W; ++i) { t0[i] = 0.0; t1[i] = 0.0; }
+  if (rl < RL) {
+    const int lim = RL < nparts ? RL : nparts;
+    for (int j = 0; j < lim; ++j) {
+#pragma unroll
+      for (int i = 0; i < W; ++i) { t0[i] += fred[0][j * G + cg][i]; t1[i] += fred[1][j * G + cg][i]; }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kNT) void k_bn_apply_fold(const T *__restrict__ x, const T *__restrict__ res, int64_t n, int c,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                       float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                       long long *__restrict__ nbt, float *__restrict__ stats,
+                                                       const float *__restrict__ scratch, int nparts, int relu, T *__restrict__ y,
+                                                       int64_t y_ld) {
+  constexpr int W = Vec<T>::W;
+  const int G = c / W, RL = kNT / G;
+  const int cg = threadIdx.x % G, rl = threadIdx.x / G;
+  double t0[W], t1[W];
+  fold_in_block<W>(scratch, nparts, c, G, RL, cg, rl, t0, t1);
+  if (rl >= RL) return;
+  float piv[W], sc[W], mean[W], bt[W];
+  if (n > 0) Vec<T>::load(x + cg * W, piv);          // the pivot of k_colreduce<T, 0>: row 0
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    const int ch = cg * W + k;
+    const double dm = n > 0 ? t0[k] / (double)n : 0.0;
+    double var = n > 0 ? t1[k] / (double)n - dm * dm : 0.0;
+    if (var < 0.0) var = 0.0;
+    const double m = (n > 0 ? (double)piv[k] : 0.0) + dm;
+    const float mf = (float)m, isf = (float)(1.0 / sqrt(var + (double)eps));
+    mean[k] = mf; sc[k] = isf * gamma[ch]; bt[k] = beta[ch];
+    if (blockIdx.x == 0 && rl == 0) {
+      stats[ch] = mf; stats[c + ch] = isf;
+      if (running_mean) {
+        const double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
+        running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * m);
+        running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+      }
+    }
+  }
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+  const int64_t stride = (int64_t)gridDim.x * RL;
+  for (int64_t r = (int64_t)blockIdx.x * RL + rl; r < n; r += 2 * stride) {
+    const int64_t r2 = r + stride;
+    const bool two = r2 < n;
+    float xa[W], xb[W], ra[W], rb[W];
+    Vec<T>::load(x + r * c + cg * W, xa);
+    if (two) Vec<T>::load(x + r2 * c + cg * W, xb);
+    if (res) { Vec<T>::load(res + r * c + cg * W, ra); if (two) Vec<T>::load(res + r2 * c + cg * W, rb); }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      float o = (xa[k] - mean[k]) * sc[k] + bt[k];   // the exact expression of k_bn_apply (the backward recomputes the mask from it)
+      if (res) o += ra[k];
+      xa[k] = (relu && o < 0.f) ? 0.f : o;
+    }
+    Vec<T>::store(y + r * y_ld + cg * W, xa);
+    if (two) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        float o = (xb[k] - mean[k]) * sc[k] + bt[k];
+        if (res) o += rb[k];
+        xb[k] = (relu && o < 0.f) ? 0.f : o;
+      }
+      Vec<T>::store(y + r2 * y_ld + cg * W, xb);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kNT) void k_bn_bwd_apply_fold(const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ dy,
+                                                           int64_t n, int c, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, const float *__restrict__ stats,
+                                                           const float *__restrict__ scratch, int nparts, float inv_n, int relu,
+                                                           T *__restrict__ dx, T *__restrict__ dres, float *__restrict__ dgamma,
+                                                           float *__restrict__ dbeta, int64_t dy_ld, int64_t y_ld) {
+  constexpr int W = Vec<T>::W;
+  const int G = c / W, RL = kNT / G;
+  const int cg = threadIdx.x % G, rl = threadIdx.x / G;
+  double t0[W], t1[W];
+  fold_in_block<W>(scratch, nparts, c, G, RL, cg, rl, t0, t1);
+  if (rl >= RL) return;
+  float mean[W], istd[W], sc[W], bt[W], gi[W], m1[W], m2[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    const int ch = cg * W + k;
+    const float s = (float)t0[k], ss = (float)t1[k];      // what k_fold_bwd stores (and k_bn_bwd_apply then reads)
+    if (blockIdx.x == 0 && rl == 0) { dbeta[ch] = s; dgamma[ch] = ss; }
+    mean[k] = stats[ch]; istd[k] = stats[c + ch];
+    sc[k] = istd[k] * (relu == 2 ? gamma[ch] : 0.f);
+    bt[k] = relu == 2 ? beta[ch] : 0.f;
+    gi[k] = gamma[ch] * istd[k];
+    m1[k] = s * inv_n; m2[k] = ss * inv_n;
+  }
+  const int64_t stride = (int64_t)gridDim.x * RL;
+  for (int64_t r = (int64_t)blockIdx.x * RL + rl; r < n; r += stride) {
+    const int64_t o = r * c + cg * W;
+    float xv[W], gv[W];
+    Vec<T>::load(x + o, xv);
+    Vec<T>::load(dy + r * dy_ld + cg * W, gv);
+    if (relu == 1) {
+      float yv[W];
+      Vec<T>::load(y + r * y_ld + cg * W, yv);
+#pragma unroll
+      for (int k = 0; k < W; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
+    } else if (relu == 2) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) gv[k] = ((xv[k] - mean[k]) * sc[k] + bt[k]) > 0.f ? gv[k] : 0.f;  // same expression as k_bn_apply
+    }
+    if (dres) Vec<T>::store(dres + o, gv);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const float xh = (xv[k] - mean[k]) * istd[k];
+      xv[k] = gi[k] * (gv[k] - m1[k] - xh * m2[k]);
+    }
+    Vec<T>::store(dx + o, xv);
+  }
+}
+
+// partial rows / apply workgroups of the two-launch path (knobs BN_FOLD_PARTS / BN_FOLD_GRID)
+inline bool bn_fold_on(int64_t tensor_bytes) { return tune(T_BN_FOLD) != 0 && tensor_bytes <= (tune(T_BN_FOLD_MAX_MB) << 20); }
+inline int fold_parts(int64_t n, int64_t *rows_per_block) {
+  int64_t cap = tune(T_BN_FOLD_PARTS);
+  if (cap < 1 || cap > kFoldParts) cap = kFoldParts;
+  int64_t nb = (n + 127) / 128;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  int64_t rpb = (n + nb - 1) / nb;
+  if (rpb < 1) rpb = 1;
+  *rows_per_block = rpb;
+  nb = (n + rpb - 1) / rpb;
+  return (int)(nb > 0 ? nb : 1);
+}
+inline int fold_grid(int64_t n, int c, int W) {
+  int64_t cap = tune(T_BN_FOLD_GRID);
+  if (cap < 1) cap = 256;
+  const int64_t total = n * (int64_t)(c / W);
+  int64_t g = (total + 2 * kNT - 1) / (2 * kNT);       // two rows per thread and sweep in the forward kernel
+  if (g > cap) g = cap;
+  return (int)(g < 1 ? 1 : g);
+}
+
 // barrier counters of the fused kernels: a ring of slots per device, zeroed once; a kernel leaves its slot at zero
 constexpr int kCtrSlots = 256;
 inline unsigned *fused_counter() {
@@ -787,6 +962,16 @@ int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const flo
   float *scratch = reinterpret_cast<float *>(workspace);  // caller-owned: no allocator call (and no implicit sync) here
   const T *x = reinterpret_cast<const T *>(xv);
   const int pm = (partials && partial_rows > 0) ? 1 : 0;
+  if (!pm && n > 0 && bn_fold_on(n * (int64_t)c * (int64_t)sizeof(T))) {
+    int64_t rpb;
+    const int parts = fold_parts(n, &rpb);
+    LGS_KLAUNCH((k_colreduce<T, 0>), parts, kNT, 0, s, x, (const T *)nullptr, (const T *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                (const float *)nullptr, n, c, 0, rpb, scratch, (int64_t)c, (int64_t)c);
+    LGS_KLAUNCH((k_bn_apply_fold<T>), fold_grid(n, c, W), kNT, 0, s, x, reinterpret_cast<const T *>(res), n, c, gamma, beta, eps, momentum,
+                rm, rv, nbt, stats, scratch, parts, relu, reinterpret_cast<T *>(yv), y_ld);
+    LGS_HIP(hipGetLastError());
+    return 0;
+  }
   const int fcap = bn_fused_on(n * (int64_t)c * (int64_t)sizeof(T), true) ? fused_cap(reinterpret_cast<const void *>(&k_bn_fwd_fused<T>)) : 0;
   if (fcap > 0) {
     unsigned *ctr = fused_counter();
@@ -828,6 +1013,15 @@ int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, in
   float *scratch = reinterpret_cast<float *>(workspace);
   float *sums = scratch + (size_t)2 * c * nb;
   const T *x = reinterpret_cast<const T *>(xv), *y = reinterpret_cast<const T *>(yv), *dy = reinterpret_cast<const T *>(dyv);
+  if (n > 0 && bn_fold_on(n * (int64_t)c * (int64_t)sizeof(T))) {
+    int64_t prpb;
+    const int parts = fold_parts(n, &prpb);
+    LGS_KLAUNCH((k_colreduce<T, 1>), parts, kNT, 0, s, x, y, dy, stats, gamma, beta, n, c, relu, prpb, scratch, dy_ld, y_ld);
+    LGS_KLAUNCH((k_bn_bwd_apply_fold<T>), fold_grid(n, c, W), kNT, 0, s, x, y, dy, n, c, gamma, beta, stats, scratch, parts, 1.f / (float)n, relu,
+                reinterpret_cast<T *>(dxv), reinterpret_cast<T *>(dresv), dgamma, dbeta, dy_ld, y_ld);
+    LGS_HIP(hipGetLastError());
+    return 0;
+  }
   const int fcap = bn_fused_on(n * (int64_t)c * (int64_t)sizeof(T)) ? fused_cap(reinterpret_cast<const void *>(&k_bn_bwd_fused<T>)) : 0;
   if (fcap > 0) {
     unsigned *ctr = fused_counter();

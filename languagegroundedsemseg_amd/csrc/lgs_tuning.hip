@@ -11,6 +11,8 @@
 // kernel that no test reached because of a size gate).
 #include <atomic>
 #include <mutex>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "lgs_common.h"
@@ -18,38 +20,53 @@
 namespace lgs {
 
 namespace {
-struct Knob { const char *name; int64_t def; const char *doc; };
-// keep in the order of enum Tune (lgs_common.h)
+struct Knob { Tune id; const char *name; int64_t def; const char *doc; };
+// in the order of enum Tune (lgs_common.h): every row names its enumerator, init_knobs() refuses a table whose row i is not knob i
 const Knob kKnobs[T_COUNT] = {
-    {"WW_MIN_ROWS", 200000, "k_wgrad_wide (per-offset GEMM over compacted pair lists) is used for 3^3 weight gradients with >= 256 x 256 "
+    {T_WW_MIN_ROWS, "WW_MIN_ROWS", 200000, "k_wgrad_wide (per-offset GEMM over compacted pair lists) is used for 3^3 weight gradients with >= 256 x 256 "
                             "channels on maps of at least this many positions; below, k_wgrad_ps wins (81 k rows, 256->256: 0.82 vs 0.31 ms)"},
-    {"WW_RANGE", 16384, "positions per k_wgrad_wide workgroup range (multiple of 256; 8192 overflows the partial-tile cap, 65536: 8.6 vs 7.5 ms)"},
-    {"WGRAD_WIDE", 1, "0 = never use k_wgrad_wide (A/B)"},
-    {"BN_FUSED", 1, "0 = BatchNorm always as three launches (column sums, fold, apply) instead of the persistent grid-barrier kernels; "
+    {T_WW_RANGE, "WW_RANGE", 16384, "positions per k_wgrad_wide workgroup range (multiple of 256; 8192 overflows the partial-tile cap, 65536: 8.6 vs 7.5 ms)"},
+    {T_WGRAD_WIDE, "WGRAD_WIDE", 1, "0 = never use k_wgrad_wide (A/B)"},
+    {T_BN_FUSED, "BN_FUSED", 1, "0 = BatchNorm always as three launches (column sums, fold, apply) instead of the persistent grid-barrier kernels; "
                     "required when several processes time-share one GPU"},
-    {"BN_FUSED_MAX_MB", 24, "layers above this size use the three-launch BatchNorm (they are bandwidth-bound; the 4096-workgroup apply streams faster)"},
-    {"BN_FUSED_FWD_MAX_MB", 0, "the same bound for the FORWARD direction alone; 0 = the forward is always three launches.  Round 4: with the host "
+    {T_BN_FUSED_MAX_MB, "BN_FUSED_MAX_MB", 24, "layers above this size use the three-launch BatchNorm (they are bandwidth-bound; the 4096-workgroup apply streams faster)"},
+    {T_BN_FUSED_FWD_MAX_MB, "BN_FUSED_FWD_MAX_MB", 0, "the same bound for the FORWARD direction alone; 0 = the forward is always three launches.  Round 4: with the host "
                                "no longer the bound the one-launch forward loses at every size (8-scene step 27.93 vs 28.15 ms, one scene 10.17 vs "
                                "10.30; stand-alone 20 MB: 22.8 vs 33.0 us), the one-launch BACKWARD still wins (16.4 vs 16.8 ms of backward)"},
-    {"BN_FUSED_BLOCKS", 0, "workgroups of the fused BatchNorm kernels; 0 = min(256, co-resident workgroups of the device)"},
-    {"PS_CUS", 20, "CUs per XCD that k_wgrad_ps fills (of 32): the compute stream keeps CUs of its own next to the CU-owning weight gradient"},
-    {"PS_WIDE3", 1, "k_wgrad_ps: three-block stationary slices for >= 256-channel layers (0 = two-block)"},
-    {"WGRAD_PS", 1, "0 = force the round-1 pair-list weight gradient (k_wgrad_bf16) everywhere (debugging)"},
-    {"MASK_WINDOW", 16384, "3^3 maps: positions per window inside which rows are re-sorted by their 27-bit neighbour mask (1024 .. 65536 swept)"},
-    {"CONV_SPLIT", 1, "0 = no slot split (3 x 9 offsets into fp32 partial images) for under-filled coarse-level 3^3 launches"},
-    {"SMALL_CFG", 0, "k_conv_gather tile for maps < 65536 positions: 0 = automatic (id 8), 5 / 9 / 10 / 11 = the other measured shapes"},
-    {"WIDE_GC64", 1, "k_conv_wide: 64-channel stages per reduction group"},
-    {"WIDE_DBG", 0, "k_conv_wide knock-out bits for time attribution (RESULTS ARE WRONG): 1 no LDS reads / MFMA, 4 no gathers, 8 no weight DMA"},
-    {"WIDE_TRACE", 0, "k_conv_wide: print per-phase shader-clock sums of one workgroup (debug instance of the kernel)"},
-    {"ARENA_DBG", 0, "print coordinate-manager arena allocations to stderr"},
-    {"CONV_WIDE", 1, "0 = >= 256-output-channel layers stay on k_conv_gather's 8-wave tile (id 16) instead of k_conv_wide (A/B)"},
-    {"MASK_ORDER", 0, "3^3 maps: sort code of the neighbourhood mask inside a window: 0 the mask, 1 corners > edges > faces, 2 faces > edges > corners, 3 popcount-major"},
+    {T_BN_FUSED_BLOCKS, "BN_FUSED_BLOCKS", 0, "workgroups of the fused BatchNorm kernels; 0 = min(256, co-resident workgroups of the device)"},
+    {T_PS_CUS, "PS_CUS", 20, "CUs per XCD that k_wgrad_ps fills (of 32): the compute stream keeps CUs of its own next to the CU-owning weight gradient"},
+    {T_PS_WIDE3, "PS_WIDE3", 1, "k_wgrad_ps: three-block stationary slices for >= 256-channel layers (0 = two-block)"},
+    {T_WGRAD_PS, "WGRAD_PS", 1, "0 = force the round-1 pair-list weight gradient (k_wgrad_bf16) everywhere (debugging)"},
+    {T_MASK_WINDOW, "MASK_WINDOW", 16384, "3^3 maps: positions per window inside which rows are re-sorted by their 27-bit neighbour mask (1024 .. 65536 swept)"},
+    {T_CONV_SPLIT, "CONV_SPLIT", 1, "0 = no slot split (3 x 9 offsets into fp32 partial images) for under-filled coarse-level 3^3 launches"},
+    {T_SMALL_CFG, "SMALL_CFG", 0, "k_conv_gather tile for maps < 65536 positions: 0 = automatic (id 8), 5 / 9 / 10 / 11 = the other measured shapes"},
+    {T_WIDE_GC64, "WIDE_GC64", 1, "k_conv_wide: 64-channel stages per reduction group"},
+    {T_WIDE_DBG, "WIDE_DBG", 0, "k_conv_wide knock-out bits for time attribution (RESULTS ARE WRONG): 1 no LDS reads / MFMA, 4 no gathers, 8 no weight DMA"},
+    {T_WIDE_TRACE, "WIDE_TRACE", 0, "k_conv_wide: print per-phase shader-clock sums of one workgroup (debug instance of the kernel)"},
+    {T_ARENA_DBG, "ARENA_DBG", 0, "print coordinate-manager arena allocations to stderr"},
+    {T_CONV_WIDE, "CONV_WIDE", 1, "0 = >= 256-output-channel layers stay on k_conv_gather's 8-wave tile (id 16) instead of k_conv_wide (A/B)"},
+    {T_MASK_ORDER, "MASK_ORDER", 0, "3^3 maps: sort code of the neighbourhood mask inside a window: 0 the mask, 1 corners > edges > faces, 2 faces > edges > corners, 3 popcount-major"},
+    {T_BN_FOLD, "BN_FOLD", 1, "1 = BatchNorm layers up to BN_FOLD_MAX_MB run as TWO launches per direction: column sums into <= BN_FOLD_PARTS partial rows, "
+                   "then an apply kernel whose workgroups fold the partial rows themselves (no fold launch, no grid barrier); 0 = the round-4 "
+                   "policies (grid-barrier kernel backward, three launches forward)"},
+    {T_BN_FOLD_MAX_MB, "BN_FOLD_MAX_MB", 6, "layers above this size keep the round-4 policies.  Stand-alone (tools/dbg/bn_small.py, bf16): 2.6 MB 15.2 / 21.1 us forward / backward against 16.1 / 29.0 (three launches / grid barriers), 5 MB 17.8 / 26.0 against 16.0 / 27.6; at 10 - 20 MB the wider 512-row reduction wins (22 / 37 - 59 against 16 - 23 / 32 - 46)"},
+    {T_BN_FOLD_PARTS, "BN_FOLD_PARTS", 64, "partial rows of the two-launch BatchNorm (<= 64): fewer = a shorter fold in every apply workgroup, more = a wider reduction"},
+    {T_BN_FOLD_GRID, "BN_FOLD_GRID", 256, "apply workgroups of the two-launch BatchNorm (each folds the partial rows redundantly)"},
+    {T_FP32_SPLIT, "FP32_SPLIT", 1, "fp32 tensors: 1 = convolution forward / dgrad multiply on the bf16 matrix pipe with exactly split operands (x = hi + mid + lo, "
+                      "six bf16 products accumulated in fp32: error below 2^-22 |x||w|, 2.7 x the MFMA rate of v_mfma_f32_32x32x2_f32); "
+                      "0 = the exact-fp32 MFMA instance"},
+    {T_BLOCK_WGRAD_LATE, "BLOCK_WGRAD_LATE", 0, "A/B: 1 = lgs_block_backward forks the FIRST convolution's weight gradient after the block's last dgrad instead of "
+                            "beside it (the 96->128 dgrad of block8.0 runs 2.1 x its stand-alone time next to k_wgrad_ps 128->96)"},
 };
 std::atomic<int64_t> g_val[T_COUNT];
 std::once_flag g_once;
 
 void init_knobs() {
   for (int i = 0; i < T_COUNT; ++i) {
+    if ((int)kKnobs[i].id != i) {     // a knob added to the enum and the table in different places (round 5 shipped one for an hour)
+      fprintf(stderr, "lgs_engine: tuning table row %d is %s but enum Tune says otherwise -- fix csrc/lgs_tuning.hip\n", i, kKnobs[i].name);
+      abort();
+    }
     const std::string env = std::string("LGS_") + kKnobs[i].name;
     const char *e = getenv(env.c_str());
     g_val[i].store(e ? atoll(e) : kKnobs[i].def, std::memory_order_relaxed);

@@ -97,6 +97,17 @@ class _Dead:
         self.why, self.cause = why, cause
 
 
+_ST = None          # core.SparseTensor / core.cat_now / block: bound on first use (core imports this module)
+_CAT_NOW = None
+_BLOCK = None
+
+
+def _bind():
+    global _ST, _CAT_NOW, _BLOCK
+    from . import core, block
+    _ST, _CAT_NOW, _BLOCK = core.SparseTensor, core.cat_now, block
+
+
 def _use(t):
     o = t._op
     if o is not None and o.kind >= 0:
@@ -112,7 +123,9 @@ def _push(mgr, op):
 
 # ------------------------------------------------------------------------------------------------ recording
 def record_conv(mod, inp, resolved):
-    from .core import SparseTensor
+    if _ST is None:
+        _bind()
+    SparseTensor = _ST
     mgr = inp._manager
     meta = inp._meta if inp._op is not None else (None, inp._F.dtype, inp._F.device)
     out = SparseTensor._pending(resolved[0], mgr, (mod.out_channels, meta[1], meta[2]))
@@ -125,7 +138,9 @@ def record_conv(mod, inp, resolved):
 
 
 def record_bn(mod, inp):
-    from .core import SparseTensor
+    if _ST is None:
+        _bind()
+    SparseTensor = _ST
     mgr = inp._manager
     meta = inp._meta if inp._op is not None else (inp._F.shape[1], inp._F.dtype, inp._F.device)
     out = SparseTensor._pending(inp.coordinate_map_key, mgr, meta)
@@ -136,7 +151,9 @@ def record_bn(mod, inp):
 
 
 def record_cat(tensors):
-    from .core import SparseTensor
+    if _ST is None:
+        _bind()
+    SparseTensor = _ST
     first = tensors[0]
     mgr = first._manager
     ch = sum(t._nch() for t in tensors)
@@ -271,8 +288,9 @@ def _cat_partner(q, i, n, op):
 
 def _run(q, final):
     """-> number of queue entries executed (all of them when `final`)"""
-    from .core import cat_now
-    from . import block as _block
+    if _ST is None:
+        _bind()
+    cat_now, _block = _CAT_NOW, _BLOCK
     hooks = UNIT_HOOKS
     ambient = torch.is_grad_enabled()
     n, i = len(q), 0

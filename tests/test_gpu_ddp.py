@@ -53,6 +53,7 @@ def _job(rank, world):
     return grads, params
 
 
+@pytest.mark.parity("torch SGD on the full batch")
 def test_two_ranks_equal_single_process_full_batch():
     import MinkowskiEngine as ME
     r0, r1 = run_distributed(_job)

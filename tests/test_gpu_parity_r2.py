@@ -200,6 +200,7 @@ def ref_clip_loss(F, T, labels, neg):
     return F, dp, dn, sim
 
 
+@pytest.mark.parity("the reference formulation restated in torch (float64 where stated)")
 @pytest.mark.parametrize("c,na,k,n", [(512, 200, 3, 257), (96, 200, 3, 1000), (64, 20, 1, 130), (32, 64, 7, 4099),
                                       (128, 100, 2, 511), (256, 224, 3, 129)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -318,6 +319,7 @@ def test_negative_sampling_modes_on_hip_tensors():
 
 
 # ------------------------------------------------------------------------------------------- cross-entropy, odd widths
+@pytest.mark.parity("the reference formulation restated in torch (float64 where stated)")
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("classes", [20, 150, 13])
 def test_cross_entropy_class_counts_off_the_16_byte_grid(classes, dtype, tol):
@@ -342,6 +344,7 @@ def test_cross_entropy_class_counts_off_the_16_byte_grid(classes, dtype, tol):
 
 
 # ------------------------------------------------------------------------------------------- BN statistics from the conv epilogue
+@pytest.mark.parity("the reference formulation restated in torch (float64 where stated)")
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_epilogue_batchnorm_statistics_equal_the_column_reduction(dtype):
     """lgs_conv_forward(bn_partial) + lgs_bn_forward(conv_partials) == lgs_bn_forward reading the output itself: same
@@ -423,6 +426,7 @@ def test_packed_weight_cache_never_serves_stale_weights(optim):
         assert len(get_packed().entries) > 60 and get_packed().epoch >= 3
 
 
+@pytest.mark.parity("the reference formulation restated in torch (float64 where stated)")
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
 def test_eval_mode_batchnorm_on_the_engine_matches_torch(dtype, tol):
     """MinkowskiBatchNorm in eval mode (running statistics) with the fused residual / ReLU tail, forward + backward"""

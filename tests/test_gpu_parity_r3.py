@@ -411,6 +411,7 @@ def test_small_batches_inline_their_weight_gradients(monkeypatch):
         assert torch.equal(side[k], inline[k]), k
 
 
+@pytest.mark.parity("fp64 dense formulation of the anchor gradient")
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("n,c,na,k", [(5000, 96, 200, 3), (3001, 512, 200, 3), (700, 32, 20, 7)])
 def test_learned_anchor_gradient_on_the_fused_loss(dtype, tol, n, c, na, k):

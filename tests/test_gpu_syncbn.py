@@ -40,6 +40,7 @@ def _job(rank, world, dtype_name, relu, use_res):
             int(mod.bn.num_batches_tracked))
 
 
+@pytest.mark.parity("plain torch BatchNorm on the concatenated batch")
 @pytest.mark.parametrize("dtype_name,tol", [("float32", 2e-5), ("bfloat16", 2e-2)])
 @pytest.mark.parametrize("relu,use_res", [(False, False), (True, False), (True, True)])
 def test_fused_sync_bn_two_ranks_match_full_batch(dtype_name, tol, relu, use_res):

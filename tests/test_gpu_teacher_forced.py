@@ -213,13 +213,14 @@ def check(tag, fe, be, ge, tf, n_units):
     report(tag + " forward outputs (HIP layer on oracle input vs oracle output)", fe)
     report(tag + " module-output gradients (HIP consumers on oracle dY vs oracle)", be)
     report(tag + " parameter gradients (oracle X, oracle dY)", ge)
-    print("%s: strided (zero-copy cat) inputs seen by %s; strided gradient slices at %s" % (tag, tf.strided_inputs, tf.strided_grads))
+    print("%s: strided inputs seen by %s; strided gradient slices (halves of a concat gradient) at %s" % (tag, tf.strided_inputs, tf.strided_grads))
     assert len(fe) == n_units and len(be) == n_units, (len(fe), len(be), n_units)
     bad = {k: v for k, v in list(fe.items()) + list(be.items()) + list(ge.items()) if not v <= TOL}
     assert not bad, "teacher-forced deviations above %g: %s" % (TOL, bad)
-    # the in-network layouts really were exercised: the strided 2^3 convs read skip tensors as column slices of the concat
-    # buffers, and the norms behind the transposed convs / the skip producers received gradient slices
-    assert len(tf.strided_inputs) >= 4 and len(tf.strided_grads) >= 4
+    # the in-network layouts really were exercised: the norms behind the transposed convs write into the concat buffers, and they
+    # and the skip producers receive column slices of the concat's gradient (round 5: the skip half of a concat is copied in,
+    # so skip tensors are ordinary contiguous tensors for their other readers)
+    assert len(tf.strided_grads) >= 4
 
 
 class _CELoss:

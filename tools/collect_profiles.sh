@@ -29,6 +29,12 @@ for w in ce clip; do
   python $R/tools/prof_summary.py $DB 6 > $O/kernel_stats_$w.txt 2>&1
   rm -rf $O/prof_$w
 done
+# the same step with every kernel alone on the machine (weight gradients on the compute stream): stand-alone durations per shape
+timeout 900 env LGS_DBG_WGRAD=inline rocprofv3 --kernel-trace --marker-trace --hip-runtime-trace --output-format rocpd -d $O/prof_sa -o x -- python $R/bench.py --workload ce --no-cpu-baseline --no-roofline --no-single-scene --no-secondary --roctx --steps 3 --warmup 3 > $O/prof_sa.log 2>&1
+DB=$(find $O/prof_sa -name "*.db" | head -1)
+python $R/tools/prof_summary.py $DB 6 > $O/kernel_stats_standalone.txt 2>&1
+rm -rf $O/prof_sa
+python $R/tools/instep_table.py $O/kernel_stats_ce.txt $O/kernel_stats_standalone.txt > $O/instep_table.txt 2>&1
 cd $R
 bash tools/run_pmc.sh $TAG/pmc sq1 sq2 tcc1 fetch write > $O/pmc.log 2>&1
 python tools/pmc_summary.py gpurun_out/$TAG/pmc > $O/pmc.txt 2>&1
