@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LGS_ABI_VERSION 11
+#define LGS_ABI_VERSION 12
 
 enum lgs_dtype { LGS_F32 = 0, LGS_BF16 = 1 };
 
@@ -252,6 +252,13 @@ int lgs_bn_backward_apply(const void *x, const void *y, const void *dy, int64_t 
 typedef struct lgs_comm lgs_comm;
 int lgs_comm_unique_id(void *id128);
 int lgs_comm_create(const void *id128, int world, int rank, int device, lgs_comm **out);
+/* Mailbox mode (no RCCL): lgs_comm_create_ipc allocates this rank's mailbox in device memory and returns its 64-byte
+ * hipIpcMemHandle; the ranks exchange the handles out of band (one torch.distributed all-gather) and every rank passes ALL of
+ * them ([world][64] bytes, its own entry ignored) to lgs_comm_ipc_open.  lgs_bn_forward_sync / lgs_bn_backward_sync then exchange
+ * through ONE kernel each (peer-to-peer stores into every rank's mailbox, arrival flags spun on in the kernel) instead of an RCCL
+ * collective.  All ranks of one communicator must issue the same sequence of calls.  Same call sites as above. */
+int lgs_comm_create_ipc(int world, int rank, int device, lgs_comm **out, void *handle64);
+int lgs_comm_ipc_open(lgs_comm *comm, const void *handles64);
 int lgs_comm_destroy(lgs_comm *comm);
 int lgs_comm_world(const lgs_comm *comm);
 int64_t lgs_bn_sync_workspace_bytes(int64_t n, int c, int world);

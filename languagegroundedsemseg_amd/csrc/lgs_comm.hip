@@ -72,10 +72,79 @@ inline int64_t align256(int64_t b) { return (b + 255) / 256 * 256; }
 
 }  // namespace
 
+// ---- device-side mailbox exchange (knob SYNCBN_IPC; round 5).  Every rank owns ONE mailbox in its HBM
+//   float    slot[kMbRing][world][kMbRec]    the record rank r contributed to collective number seq, in slot seq % kMbRing
+//   uint32_t flag[kMbRing][world]            = seq once that record is complete
+// and maps every peer's mailbox through hipIpcGetMemHandle / hipIpcOpenMemHandle.  A SyncBN exchange is then ONE kernel of one
+// workgroup on the compute stream: write my record into every rank's mailbox (peer-to-peer stores), fence, raise my flag there,
+// spin on the flags of MY mailbox until all `world` records of this seq are in, combine.  No RCCL kernel (15 - 20 us each, 124
+// per step), no second communicator next to ProcessGroupNCCL's.  A rank can run at most one collective ahead of the slowest
+// rank (the next one needs everybody's record of this one), so a ring of kMbRing = 4 slots is never overwritten while unread.
+// What one GPU cannot show: that a peer's stores become visible to a SPINNING kernel across xGMI (the mailbox is fine-grained
+// memory when the runtime grants it, flags are system-scope atomics, records are read with system-scope loads); the logic --
+// ring, sequence numbers, order of the combination -- is exercised by two processes sharing one GPU (tests/test_gpu_syncbn.py).
+constexpr int kMbRing = 4, kMbRec = 2 * 2048 + 1, kMbMaxWorld = 16;
+struct Mailbox {
+  float *slot;          // [kMbRing][world][kMbRec]
+  unsigned *flag;       // [kMbRing][world]
+};
+
 struct lgs_comm {
   nccl_comm_t comm = nullptr;
   int world = 0, rank = 0, device = 0;
+  // mailbox mode
+  bool ipc = false;
+  void *mine = nullptr;                   // this rank's mailbox allocation
+  void *peer[kMbMaxWorld] = {nullptr};    // mapped mailboxes of all ranks (peer[rank] == mine)
+  Mailbox *d_boxes = nullptr;             // device array [world]
+  unsigned seq = 0;                       // collectives issued so far (identical on every rank: same model, same order)
 };
+
+namespace {
+inline size_t mb_slot_bytes(int world) { return (size_t)kMbRing * world * kMbRec * sizeof(float); }
+inline size_t mb_bytes(int world) { return mb_slot_bytes(world) + (size_t)kMbRing * world * sizeof(unsigned) + 256; }
+
+__device__ inline void mb_put_and_wait(const Mailbox *boxes, int world, int rank, unsigned seq, const float *rec, int len) {
+  const int ring = (int)(seq % kMbRing);
+  // my record into every rank's mailbox (mine included)
+  for (int p = 0; p < world; ++p) {
+    float *dst = boxes[p].slot + ((size_t)ring * world + rank) * kMbRec;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) __hip_atomic_store(dst + i, rec[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if ((int)threadIdx.x < world)
+    __hip_atomic_store(boxes[threadIdx.x].flag + ring * world + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // everybody's record of THIS seq in my mailbox
+  if ((int)threadIdx.x < world) {
+    const unsigned *f = boxes[rank].flag + ring * world + threadIdx.x;
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+  __threadfence_system();
+}
+__device__ inline float mb_get(const Mailbox *boxes, int world, int rank, unsigned seq, int r, int i) {
+  const float *src = boxes[rank].slot + ((size_t)(seq % kMbRing) * world + r) * kMbRec;
+  return __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// all-gather of the [mean | M2 | count] records: all[r][0 .. 2C] for every rank r, in rank order
+__global__ __launch_bounds__(256) void k_mbox_allgather(const Mailbox *boxes, int world, int rank, unsigned seq, const float *local, int len,
+                                                        float *all) {
+  mb_put_and_wait(boxes, world, rank, seq, local, len);
+  for (int r = 0; r < world; ++r)
+    for (int i = threadIdx.x; i < len; i += blockDim.x) all[(size_t)r * len + i] = mb_get(boxes, world, rank, seq, r, i);
+}
+// all-reduce (sum, fixed rank order: identical bits on every rank) of `len` floats, in place
+__global__ __launch_bounds__(256) void k_mbox_allreduce(const Mailbox *boxes, int world, int rank, unsigned seq, float *sums, int len) {
+  mb_put_and_wait(boxes, world, rank, seq, sums, len);
+  for (int i = threadIdx.x; i < len; i += blockDim.x) {
+    float a = 0.f;
+    for (int r = 0; r < world; ++r) a += mb_get(boxes, world, rank, seq, r, i);
+    sums[i] = a;
+  }
+}
+}  // namespace
 
 extern "C" {
 
@@ -106,9 +175,66 @@ int lgs_comm_create(const void *id128, int world, int rank, int device, lgs_comm
   return 0;
 }
 
+// ---- mailbox mode: create (allocates this rank's mailbox) -> exchange the 64-byte handles out of band -> open the peers'
+int lgs_comm_create_ipc(int world, int rank, int device, lgs_comm **out, void *handle64) {
+  LGS_REQUIRE(out && handle64 && world >= 1 && world <= kMbMaxWorld && rank >= 0 && rank < world, "lgs_comm_create_ipc: bad argument");
+  LGS_HIP(hipSetDevice(device));
+  lgs_comm *c = new lgs_comm();
+  c->world = world; c->rank = rank; c->device = device; c->ipc = true;
+  const size_t bytes = mb_bytes(world);
+  // fine-grained (coherent with peers while a kernel runs) when the runtime grants it for an IPC-exportable allocation
+  hipIpcMemHandle_t h;
+  bool ok = hipExtMallocWithFlags(&c->mine, bytes, hipDeviceMallocFinegrained) == hipSuccess && hipIpcGetMemHandle(&h, c->mine) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    if (c->mine) (void)hipFree(c->mine);
+    c->mine = nullptr;
+    if (hipMalloc(&c->mine, bytes) != hipSuccess || hipIpcGetMemHandle(&h, c->mine) != hipSuccess) {
+      lgs::set_error("lgs_comm_create_ipc: could not allocate / export the mailbox (hipIpcGetMemHandle; HSA_ENABLE_IPC_MODE_LEGACY=0 set?)");
+      if (c->mine) (void)hipFree(c->mine);
+      delete c;
+      return 3;
+    }
+  }
+  LGS_HIP(hipMemset(c->mine, 0, bytes));
+  LGS_HIP(hipDeviceSynchronize());
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C-ABI hands the handle over as 64 bytes");
+  ::memcpy(handle64, &h, 64);
+  c->peer[rank] = c->mine;
+  *out = c;
+  return 0;
+}
+
+int lgs_comm_ipc_open(lgs_comm *c, const void *handles64) {
+  LGS_REQUIRE(c && c->ipc && handles64, "lgs_comm_ipc_open: bad argument");
+  LGS_HIP(hipSetDevice(c->device));
+  Mailbox host[kMbMaxWorld];
+  for (int r = 0; r < c->world; ++r) {
+    if (r != c->rank) {
+      hipIpcMemHandle_t h;
+      ::memcpy(&h, reinterpret_cast<const char *>(handles64) + 64 * r, 64);
+      LGS_HIP(hipIpcOpenMemHandle(&c->peer[r], h, hipIpcMemLazyEnablePeerAccess));
+    }
+    host[r].slot = reinterpret_cast<float *>(c->peer[r]);
+    host[r].flag = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(c->peer[r]) + mb_slot_bytes(c->world));
+  }
+  LGS_HIP(hipMalloc(&c->d_boxes, sizeof(Mailbox) * c->world));
+  LGS_HIP(hipMemcpy(c->d_boxes, host, sizeof(Mailbox) * c->world, hipMemcpyHostToDevice));
+  c->seq = 0;
+  return 0;
+}
+
 int lgs_comm_destroy(lgs_comm *c) {
   if (!c) return 0;
   if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+  if (c->ipc) {
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < c->world; ++r)
+      if (r != c->rank && c->peer[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
+    if (c->d_boxes) (void)hipFree(c->d_boxes);
+    if (c->mine) (void)hipFree(c->mine);
+  }
   delete c;
   return 0;
 }
@@ -125,13 +251,21 @@ int64_t lgs_bn_sync_workspace_bytes(int64_t n, int c, int world) {
 int lgs_bn_forward_sync(lgs_comm *comm, const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps,
                         float momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked, const void *residual,
                         int relu, void *y, float *stats, float *inv_n, int dtype, void *workspace, int64_t y_row_stride, void *stream) {
-  LGS_REQUIRE(comm && comm->comm && x && y && gamma && beta && stats && inv_n && workspace, "lgs_bn_forward_sync: null argument");
+  LGS_REQUIRE(comm && (comm->comm || (comm->ipc && comm->d_boxes)) && x && y && gamma && beta && stats && inv_n && workspace,
+              "lgs_bn_forward_sync: null argument");
   char *ws = reinterpret_cast<char *>(workspace);
   float *local = reinterpret_cast<float *>(ws + align256(lgs_bn_workspace_bytes(n, c)));
   float *all = local + (2 * c + 1);
   int rc;
   if ((rc = lgs_bn_stats(x, n, c, local, dtype, workspace, nullptr, 0, nullptr, stream))) return rc;
-  LGS_NCCL(rccl().AllGather(local, all, (size_t)(2 * c + 1), kNcclFloat32, comm->comm, (hipStream_t)stream));
+  if (comm->ipc) {
+    LGS_REQUIRE(2 * c + 1 <= kMbRec, "lgs_bn_forward_sync: record wider than a mailbox slot");
+    comm->seq += 1;
+    LGS_KLAUNCH(k_mbox_allgather, 1, 256, 0, (hipStream_t)stream, comm->d_boxes, comm->world, comm->rank, comm->seq, local, 2 * c + 1, all);
+    LGS_HIP(hipGetLastError());
+  } else {
+    LGS_NCCL(rccl().AllGather(local, all, (size_t)(2 * c + 1), kNcclFloat32, comm->comm, (hipStream_t)stream));
+  }
   if ((rc = lgs_bn_sync_combine(all, comm->world, c, eps, momentum, running_mean, running_var, num_batches_tracked, stats, inv_n, stream)))
     return rc;
   return lgs_bn_apply(x, n, c, gamma, beta, stats, residual, relu, y, dtype, y_row_stride, stream);
@@ -141,14 +275,21 @@ int lgs_bn_forward_sync(lgs_comm *comm, const void *x, int64_t n, int c, const f
 int lgs_bn_backward_sync(lgs_comm *comm, const void *x, const void *y, const void *dy, int64_t n, int c, const float *gamma,
                          const float *beta, const float *stats, const float *inv_n, int relu, void *dx, void *dresidual, float *dgamma,
                          float *dbeta, int dtype, void *workspace, int64_t dy_row_stride, int64_t y_row_stride, void *stream) {
-  LGS_REQUIRE(comm && comm->comm && x && dy && dx && gamma && stats && inv_n && workspace, "lgs_bn_backward_sync: null argument");
+  LGS_REQUIRE(comm && (comm->comm || (comm->ipc && comm->d_boxes)) && x && dy && dx && gamma && stats && inv_n && workspace,
+              "lgs_bn_backward_sync: null argument");
   char *ws = reinterpret_cast<char *>(workspace);
   float *sums = reinterpret_cast<float *>(ws + align256(lgs_bn_workspace_bytes(n, c)) + align256((int64_t)(comm->world + 1) * (2 * c + 1) * 4));
   int rc;
   if ((rc = lgs_bn_backward_reduce(x, y, dy, n, c, gamma, beta, stats, relu, sums, dgamma, dbeta, dtype, workspace, dy_row_stride, y_row_stride,
                                    stream)))
     return rc;
-  LGS_NCCL(rccl().AllReduce(sums, sums, (size_t)(2 * c), kNcclFloat32, kNcclSum, comm->comm, (hipStream_t)stream));
+  if (comm->ipc) {
+    comm->seq += 1;
+    LGS_KLAUNCH(k_mbox_allreduce, 1, 256, 0, (hipStream_t)stream, comm->d_boxes, comm->world, comm->rank, comm->seq, sums, 2 * c);
+    LGS_HIP(hipGetLastError());
+  } else {
+    LGS_NCCL(rccl().AllReduce(sums, sums, (size_t)(2 * c), kNcclFloat32, kNcclSum, comm->comm, (hipStream_t)stream));
+  }
   return lgs_bn_backward_apply(x, y, dy, n, c, gamma, beta, stats, sums, 0.f, inv_n, relu, dx, dresidual, dtype, dy_row_stride, y_row_stride, stream);
 }
 

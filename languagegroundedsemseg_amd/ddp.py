@@ -414,11 +414,15 @@ class EngineComm:
     for any world (what a first multi-GPU bring-up should A/B), `=0` off."""
     _by_group = {}
 
-    def __init__(self, group, device):
+    def __init__(self, group, device, ipc=False):
         import ctypes
         from . import engine
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         self.h, self.world, self.rank, self._L = None, world, rank, None
+        self.ipc = ipc
+        if ipc:
+            self._init_ipc(group, device, world, rank)
+            return
         err = None
         buf = ctypes.create_string_buffer(128)
         try:
@@ -446,6 +450,37 @@ class EngineComm:
         if not self.ok:
             self.close()
 
+    def _init_ipc(self, group, device, world, rank):
+        """mailbox mode (knob SYNCBN_IPC, csrc/lgs_comm.hip): every rank allocates its mailbox, the 64-byte IPC handles go round in
+        ONE all-gather over the torch group (any backend), every rank maps the others'.  Failure anywhere is agreed on collectively,
+        as for the RCCL communicator."""
+        import ctypes
+        from . import engine
+        err, mine = None, bytes(64)
+        try:
+            L = self._L = engine.lib()
+            h, buf = ctypes.c_void_p(None), ctypes.create_string_buffer(64)
+            idx = device.index if device.index is not None else torch.cuda.current_device()
+            engine.check(L.lgs_comm_create_ipc(world, rank, idx, ctypes.byref(h), buf))
+            self.h, mine = h, bytes(buf.raw)
+        except Exception as e:
+            err = e
+        box = [None] * world
+        dist.all_gather_object(box, mine if err is None else b"", group=group)
+        if err is None and all(isinstance(b, bytes) and len(b) == 64 for b in box):
+            try:
+                engine.check(self._L.lgs_comm_ipc_open(self.h, ctypes.create_string_buffer(b"".join(box), 64 * world)))
+            except Exception as e:
+                err = e
+        elif err is None:
+            err = RuntimeError("a peer could not export its mailbox")
+        ok = torch.tensor([1 if err is None else 0], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        self.ok = bool(int(ok.item()))
+        self.error = err
+        if not self.ok:
+            self.close()
+
     def close(self):
         if self.h is not None and self.h.value:
             self._L.lgs_comm_destroy(self.h)
@@ -462,14 +497,15 @@ class EngineComm:
         comm = None
         knob = _tuning.host("SYNCBN_ENGINE_COMM")
         want = knob == 1 or (knob < 0 and dist.get_world_size(group) == 1)
-        if want and dist.get_backend(group) == "nccl":
-            c = cls(group, device)
+        ipc = _tuning.host("SYNCBN_IPC") != 0
+        if ipc or (want and dist.get_backend(group) == "nccl"):
+            c = cls(group, device, ipc=ipc)
             if c.ok:
                 comm = c
             else:
                 import sys
-                print("[lgs] engine-side RCCL communicator unavailable on at least one rank (this rank: %s): SyncBN keeps "
-                      "torch.distributed's collectives on every rank" % (c.error,), file=sys.stderr)
+                print("[lgs] engine-side %s unavailable on at least one rank (this rank: %s): SyncBN keeps "
+                      "torch.distributed's collectives on every rank" % ("mailbox exchange" if ipc else "RCCL communicator", c.error), file=sys.stderr)
         cls._by_group[key] = comm
         return comm
 

@@ -10,7 +10,7 @@ import os
 from . import build as _build
 
 LGS_F32, LGS_BF16 = 0, 1
-ABI_VERSION = 11     # LGS_ABI_VERSION of include/lgs_engine.h
+ABI_VERSION = 12     # LGS_ABI_VERSION of include/lgs_engine.h
 
 
 class PackDesc(ctypes.Structure):
@@ -94,7 +94,7 @@ EXPORTS = [
     "lgs_clip_anchor_grad_workspace_bytes", "lgs_clip_loss_backward_anchors",
     "lgs_ce_forward_backward",
     "lgs_ce_count_valid",
-    "lgs_comm_unique_id", "lgs_comm_create", "lgs_comm_destroy", "lgs_comm_world", "lgs_bn_sync_workspace_bytes",
+    "lgs_comm_unique_id", "lgs_comm_create", "lgs_comm_create_ipc", "lgs_comm_ipc_open", "lgs_comm_destroy", "lgs_comm_world", "lgs_bn_sync_workspace_bytes",
     "lgs_bn_forward_sync", "lgs_bn_backward_sync",
     "lgs_voxelize", "lgs_label_vote", "lgs_cluster_workspace_bytes", "lgs_cluster", "lgs_sgd_step",
 ]
@@ -162,6 +162,8 @@ def lib():
         "lgs_ce_count_valid": [vp, i64, ci, i64, vp, vp],
         "lgs_comm_unique_id": [vp],
         "lgs_comm_create": [vp, ci, ci, ci, ctypes.POINTER(vp)],
+        "lgs_comm_create_ipc": [ci, ci, ci, ctypes.POINTER(vp), vp],
+        "lgs_comm_ipc_open": [vp, vp],
         "lgs_comm_destroy": [vp],
         "lgs_comm_world": [vp],
         "lgs_bn_forward_sync": [vp, vp, i64, ci, vp, vp, cf, cf, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, i64, vp],

@@ -35,6 +35,10 @@ HOST_KNOBS = {
                                     "stream (csrc/lgs_comm.hip): 1 = always, 0 = never (torch.distributed collectives between the split "
                                     "kernels), -1 = auto: only in a world of ONE rank (two communicators in flight next to each other have "
                                     "never been executed with a peer on this build's one-GPU boxes; ddp.EngineComm)"),
+    "SYNCBN_IPC": (0, int, "1 = MinkowskiSyncBatchNorm exchanges its per-layer records through device-side mailboxes (peers' buffers mapped with "
+                           "hipIpc, ONE kernel per exchange that writes to every rank and spins on arrival flags; csrc/lgs_comm.hip) instead of "
+                           "RCCL collectives.  Off: visibility of peer stores to a spinning kernel across xGMI has never been exercised (one GPU "
+                           "per box); the logic is tested with two processes on one GPU (tests/test_gpu_syncbn.py)"),
     "SET_HW_QUEUES": (0, int, "1 = importing the package sets GPU_MAX_HW_QUEUES=8 before the HIP runtime starts (see configure_hw_queues)"),
 }
 

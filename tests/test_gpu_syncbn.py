@@ -19,7 +19,11 @@ def _data(dtype):
     return full, res, g
 
 
-def _job(rank, world, dtype_name, relu, use_res):
+def _job(rank, world, dtype_name, relu, use_res, ipc=False, layers=1):
+    import os
+    if ipc:
+        os.environ["LGS_SYNCBN_IPC"] = "1"                      # (read when languagegroundedsemseg_amd.tuning.host() is asked)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import MinkowskiEngine as ME
     from languagegroundedsemseg_amd.ddp import sync_batch_norm
     dtype = getattr(torch, dtype_name)
@@ -35,6 +39,28 @@ def _job(rank, world, dtype_name, relu, use_res):
     y = sync_batch_norm(x, mod.bn, residual=r if use_res else None, relu=relu)
     y.backward(g[sl].to(dev).to(dtype))
     torch.cuda.synchronize()
+    used = None
+    if ipc:
+        from languagegroundedsemseg_amd import engine
+        from languagegroundedsemseg_amd.ddp import EngineComm
+        used = [c is not None and c.ipc for c in EngineComm._by_group.values()]
+        sites = engine.dispatch_counts()
+        assert used == [True] and sites.get("k_mbox_allgather", 0) == 1 and sites.get("k_mbox_allreduce", 0) == 1, (used, sites)
+        # more exchanges than the ring has slots, of different widths, the ranks drifting apart in between
+        for i in range(layers):
+            cc = (32, 256, 64, 128, 96, 512, 8)[i % 7]
+            xi = (torch.randn(700 + 300 * rank, cc, device=dev) * (1 + i) + rank).to(dtype)
+            mi = ME.MinkowskiSyncBatchNorm(cc).to(dev)
+            yi = sync_batch_norm(xi.requires_grad_(True), mi.bn, relu=bool(i % 2))
+            if rank == i % 2:
+                torch.cuda.synchronize()                          # one rank waits, the other runs ahead into the next exchange
+            yi.float().square().mean().backward()
+            st = torch.cat([mi.bn.running_mean, mi.bn.running_var]).cpu()
+            box = [None, None]
+            import torch.distributed as dist
+            dist.all_gather_object(box, st)
+            assert torch.equal(box[0], box[1]), "layer %d: the ranks combined different statistics" % i
+        EngineComm.close_all()
     return (y.detach().float().cpu(), x.grad.float().cpu(), r.grad.float().cpu() if use_res else None,
             mod.bn.running_mean.cpu(), mod.bn.running_var.cpu(), mod.bn.weight.grad.cpu(), mod.bn.bias.grad.cpu(),
             int(mod.bn.num_batches_tracked))
@@ -43,9 +69,14 @@ def _job(rank, world, dtype_name, relu, use_res):
 @pytest.mark.parity("plain torch BatchNorm on the concatenated batch")
 @pytest.mark.parametrize("dtype_name,tol", [("float32", 2e-5), ("bfloat16", 2e-2)])
 @pytest.mark.parametrize("relu,use_res", [(False, False), (True, False), (True, True)])
-def test_fused_sync_bn_two_ranks_match_full_batch(dtype_name, tol, relu, use_res):
+@pytest.mark.parametrize("ipc", [False, True], ids=["collectives", "mailbox"])
+def test_fused_sync_bn_two_ranks_match_full_batch(dtype_name, tol, relu, use_res, ipc):
+    """ipc = True: the same exchange through the device-side mailboxes of csrc/lgs_comm.hip (knob SYNCBN_IPC): each rank's
+    buffer mapped into the other process with hipIpc, one kernel per exchange that stores into both mailboxes and spins on
+    the arrival flags -- here with both processes on ONE GPU, which exercises the ring / sequence / combination logic but not the
+    visibility of peer stores across xGMI; followed by nine more exchanges (> ring depth) with the ranks out of step"""
     import functools
-    r0, r1 = run_distributed(functools.partial(_job, dtype_name=dtype_name, relu=relu, use_res=use_res))
+    r0, r1 = run_distributed(functools.partial(_job, dtype_name=dtype_name, relu=relu, use_res=use_res, ipc=ipc, layers=9 if ipc else 0))
     dtype = getattr(torch, dtype_name)
     full, res, g = _data(dtype)
     xf = full.clone().requires_grad_(True)
