@@ -852,7 +852,14 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         out["fp32"] = secondary_block("ce", "Res16UNet34C", torch.float32, coords, feats, labels, device, args, clog, steps=5, warmup=3,
-                                      note="the parity path (fp32 storage, exact-fp32 MFMA): logits within 1e-3 of the oracle")
+                                      note="the parity path (fp32 storage: logits within 1e-3 of the oracle).  Convolution forward / dgrad "
+                                           "multiply on the bf16 matrix pipe with exactly split operands (x = hi + mid + lo, six products, fp32 "
+                                           "accumulate; knob FP32_SPLIT); weight gradients on the exact-fp32 MFMA")
+        from languagegroundedsemseg_amd import engine as _engine
+        with _engine.tuning(FP32_SPLIT=0):
+            ex = secondary_block("ce", "Res16UNet34C", torch.float32, coords, feats, labels, device, args, None, steps=4, warmup=2,
+                                 note="FP32_SPLIT=0: every product on v_mfma_f32_32x32x2_f32 (round 4's fp32 path)")
+        out["fp32"]["exact_mfma"] = {"ms_per_step": ex["ms_per_step"], "value": ex["value"], "unit": "voxels/s", "note": ex["note"]}
         log("fp32 block done")
         out["clip"] = secondary_block("clip", "Res16UNet34D", torch.bfloat16, coords, feats, labels, device, args, clog, steps=5, warmup=3,
                                       note="BASELINE configs[2] (scripts/text_representation_train.sh): Res16UNet34D + fused CLIP text-anchor loss")

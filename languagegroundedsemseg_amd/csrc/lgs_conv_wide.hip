@@ -81,12 +81,10 @@ struct WideIter {
   }
 };
 
-template <bool TRACE>
 __global__ __launch_bounds__(512, 2) void k_conv_wide(View v, const bf16_t *__restrict__ in, int cin_real, int nc64,
                                                        const u32x4 *__restrict__ wp, int nb_total, int ncp, int nbp,
                                                        bf16_t *__restrict__ out, int cout_real, const float *__restrict__ bias,
-                                                       unsigned in_bytes, unsigned w_bytes, int in_ld, int gc64, int ny, int dbg_arg,
-                                                       unsigned long long *trace) {
+                                                       unsigned in_bytes, unsigned w_bytes, int in_ld, int gc64, int ny) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -339,49 +337,28 @@ __global__ __launch_bounds__(512, 2) void k_conv_wide(View v, const bf16_t *__re
     else issue_a(it.slot, __builtin_amdgcn_readlane(stab, it.slot), it.c, 0);
   }
   int buf = 0;
-  // LGS_WIDE_TRACE=1 (debug): shader-clock stamps of one workgroup's waves 0 and 4, summed over the stages:
-  // [0] wait for own DMA  [1] barrier  [2] first half (wm 0: weight DMA + blocks 0, 1;  wm 1: blocks 0, 1)
-  // [3] second half (wm 0: blocks 2, 3;  wm 1: gathers + blocks 2, 3)  [4] stages  [5] active blocks
-  // TRACE is a template parameter: five wave-uniform `if (tr)` tests per stage are ~10 scalar instructions per wave on the CU's
-  // shared scalar unit, which the stage loop is short of (SQ_INSTS_SALU 172 M vs SQ_INSTS_MFMA 69 M per launch)
-  const int dbg = TRACE ? dbg_arg : 0;          // knock-out / trace builds only: the production instance has no such tests
-  const bool tr = TRACE && trace != nullptr && blockIdx.x == 8 * 40 && (wave == 0 || wave == 4);
-  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  // (per-phase shader-clock sums and the knock-out bits of the experiment builds: tools/dbg/conv_wide_instrumentation.patch)
   while (have) {
     const bool more = it.next();                                   // `it` now names stage s+1
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-    if (tr) t0 = __builtin_amdgcn_s_memtime();
     LGS_VMCNT(0);                                                  // this wave's pieces of stage s have landed
-    if (tr) t1 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // everybody's have; buffer buf ^ 1 is no longer read
-    if (tr) t2 = __builtin_amdgcn_s_memtime();
-    const uint32_t m4 = (dbg & 1) ? 0u : (__builtin_amdgcn_readlane(stab, cur_slot) & 15u);
+    const uint32_t m4 = __builtin_amdgcn_readlane(stab, cur_slot) & 15u;
     if (wm == 0) {
-      if (more && !(dbg & 8)) issue_w(__builtin_amdgcn_readlane(wtab, it.slot), it.c, buf ^ 1);
+      if (more) issue_w(__builtin_amdgcn_readlane(wtab, it.slot), it.c, buf ^ 1);
       block0(m4, buf);
       block1(m4);
-      if (tr) t3 = __builtin_amdgcn_s_memtime();
       block2(m4);
       block3(m4);
     } else {
       block0(m4, buf);
       block1(m4);
-      if (tr) t3 = __builtin_amdgcn_s_memtime();
-      if (more && !(dbg & 4)) issue_a(it.slot, __builtin_amdgcn_readlane(stab, it.slot), it.c, buf ^ 1);
+      if (more) issue_a(it.slot, __builtin_amdgcn_readlane(stab, it.slot), it.c, buf ^ 1);
       block2(m4);
       block3(m4);
-    }
-    if (tr) {
-      t4 = __builtin_amdgcn_s_memtime();
-      tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2; tacc[3] += t4 - t3; tacc[4] += 1; tacc[5] += __builtin_popcount(m4);
     }
     cur_slot = it.slot;
     have = more;
     buf ^= 1;
-  }
-  if (tr && lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) trace[(wave >> 2) * 6 + i] = tacc[i];
   }
   LGS_VMCNT(0);
   // the MFMAs are opaque asm: the compiler does not know that the accumulators were just written by the matrix pipe
@@ -442,13 +419,10 @@ int launch_conv_wide(const View &v, const void *in, int cin_real, int in_ld, con
               "sparse conv: a feature or weight tensor of 4 GiB or more is beyond the 32-bit buffer-descriptor path");
   static bool attr_set = false;
   if (!attr_set) {
-    LGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wide<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds));
-    LGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds));
+    LGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wide), hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds));
     attr_set = true;
   }
   const int nc64 = (cin_real + 63) / 64, ny = nbp / 8;
-  // knock-out builds for attribution (results are wrong): 1 = no LDS reads / MFMAs, 4 = no gathers, 8 = no weight DMA
-  const int dbg = (int)tune(T_WIDE_DBG);
   const int gc_env = (int)tune(T_WIDE_GC64);   // tuning knob: 64-channel stages per reduction group
   gc64 = gc_env > 0 ? gc_env : gc64;
   unsigned nwg = (unsigned)(v.n_pad / kWideTM) * (unsigned)ny;
@@ -456,29 +430,10 @@ int launch_conv_wide(const View &v, const void *in, int cin_real, int in_ld, con
     const unsigned ntile = (unsigned)(v.n_pad / kWideTM), g = 8u / (unsigned)ny, per = (ntile + g - 1) / g;
     nwg = per * 8u;
   }
-  const bool want_trace = tune(T_WIDE_TRACE) != 0;      // debug: per-phase shader-clock sums of one workgroup
-  static unsigned long long *trace = nullptr;
-  if (want_trace && !trace) { LGS_HIP(hipMalloc(&trace, 12 * sizeof(unsigned long long))); }
-  if (want_trace) LGS_HIP(hipMemsetAsync(trace, 0, 12 * sizeof(unsigned long long), s));
-  if (want_trace || dbg != 0)
-    LGS_KLAUNCH(k_conv_wide<true>, dim3(nwg), dim3(512), kWideLds, s, v, reinterpret_cast<const bf16_t *>(in), cin_real, nc64,
-                       reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, reinterpret_cast<bf16_t *>(out), cout_real, bias,
-                       (unsigned)in_bytes64, (unsigned)w_bytes64, ld, gc64 > 0 ? gc64 : nc64, ny, dbg, trace);
-  else
-    LGS_KLAUNCH(k_conv_wide<false>, dim3(nwg), dim3(512), kWideLds, s, v, reinterpret_cast<const bf16_t *>(in), cin_real, nc64,
-                       reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, reinterpret_cast<bf16_t *>(out), cout_real, bias,
-                       (unsigned)in_bytes64, (unsigned)w_bytes64, ld, gc64 > 0 ? gc64 : nc64, ny, dbg, trace);
+  LGS_KLAUNCH(k_conv_wide, dim3(nwg), dim3(512), kWideLds, s, v, reinterpret_cast<const bf16_t *>(in), cin_real, nc64,
+              reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, reinterpret_cast<bf16_t *>(out), cout_real, bias,
+              (unsigned)in_bytes64, (unsigned)w_bytes64, ld, gc64 > 0 ? gc64 : nc64, ny);
   LGS_HIP(hipGetLastError());
-  if (want_trace) {
-    unsigned long long h[12];
-    LGS_HIP(hipStreamSynchronize(s));
-    LGS_HIP(hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost));
-    for (int g = 0; g < 2; ++g)
-      if (h[g * 6 + 4])
-        fprintf(stderr, "[k_conv_wide trace] %d->%d wave %d (wm %d): %llu stages, %.2f active blocks; cycles per stage: dma-wait %.0f  barrier %.0f  first half %.0f  second half %.0f\n",
-                cin_real, cout_real, 4 * g, g, h[g * 6 + 4], (double)h[g * 6 + 5] / h[g * 6 + 4], (double)h[g * 6 + 0] / h[g * 6 + 4],
-                (double)h[g * 6 + 1] / h[g * 6 + 4], (double)h[g * 6 + 2] / h[g * 6 + 4], (double)h[g * 6 + 3] / h[g * 6 + 4]);
-  }
   return 0;
 }
 

@@ -872,18 +872,32 @@ inline int fold_grid(int64_t n, int c, int W) {
 
 // barrier counters of the fused kernels: a ring of slots per device, zeroed once; a kernel leaves its slot at zero
 constexpr int kCtrSlots = 256;
-inline unsigned *fused_counter() {
+// `s`: the stream of the launch that asks.  The ring is zeroed ONCE, asynchronously on the first asker's stream; until that memset
+// is known to have completed every asker's stream is ordered behind it through an event -- no host synchronisation anywhere
+// (round 4 blocked the host in hipDeviceSynchronize at the first BatchNorm of a process).
+inline unsigned *fused_counter(hipStream_t s) {
   static unsigned *ring[64] = {nullptr};
+  static hipEvent_t zeroed[64] = {nullptr};
+  static std::atomic<bool> settled[64];
   static std::atomic<unsigned> next[64];
   static std::mutex mu;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  if (!ring[dev]) {
-    unsigned *p = nullptr;
-    if (hipMalloc(&p, kCtrSlots * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, kCtrSlots * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
-    ring[dev] = p;
+  if (!settled[dev].load(std::memory_order_acquire)) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ring[dev]) {
+      unsigned *p = nullptr;
+      if (hipMalloc(&p, kCtrSlots * sizeof(unsigned)) != hipSuccess) return nullptr;
+      if (hipEventCreateWithFlags(&zeroed[dev], hipEventDisableTiming) != hipSuccess ||
+          hipMemsetAsync(p, 0, kCtrSlots * sizeof(unsigned), s) != hipSuccess || hipEventRecord(zeroed[dev], s) != hipSuccess)
+        return nullptr;
+      ring[dev] = p;
+    } else if (hipEventQuery(zeroed[dev]) == hipSuccess) {
+      settled[dev].store(true, std::memory_order_release);
+    } else {
+      (void)hipGetLastError();                                   // hipErrorNotReady is not an error
+      if (hipStreamWaitEvent(s, zeroed[dev], 0) != hipSuccess) return nullptr;
+    }
   }
   return ring[dev] + (next[dev].fetch_add(1) % kCtrSlots);
 }
@@ -974,7 +988,7 @@ int bn_forward_t(const void *xv, int64_t n, int c, const float *gamma, const flo
   }
   const int fcap = bn_fused_on(n * (int64_t)c * (int64_t)sizeof(T), true) ? fused_cap(reinterpret_cast<const void *>(&k_bn_fwd_fused<T>)) : 0;
   if (fcap > 0) {
-    unsigned *ctr = fused_counter();
+    unsigned *ctr = fused_counter(s);
     LGS_REQUIRE(ctr != nullptr, "lgs_bn_forward: could not allocate the grid-barrier counters");
     int64_t rpb;
     const int grid = fused_blocks(n, &rpb, fcap);
@@ -1024,7 +1038,7 @@ int bn_backward_t(const void *xv, const void *yv, const void *dyv, int64_t n, in
   }
   const int fcap = bn_fused_on(n * (int64_t)c * (int64_t)sizeof(T)) ? fused_cap(reinterpret_cast<const void *>(&k_bn_bwd_fused<T>)) : 0;
   if (fcap > 0) {
-    unsigned *ctr = fused_counter();
+    unsigned *ctr = fused_counter(s);
     LGS_REQUIRE(ctr != nullptr, "lgs_bn_backward: could not allocate the grid-barrier counters");
     int64_t frpb;
     const int grid = fused_blocks(n, &frpb, fcap);

@@ -41,8 +41,6 @@ const Knob kKnobs[T_COUNT] = {
     {T_CONV_SPLIT, "CONV_SPLIT", 1, "0 = no slot split (3 x 9 offsets into fp32 partial images) for under-filled coarse-level 3^3 launches"},
     {T_SMALL_CFG, "SMALL_CFG", 0, "k_conv_gather tile for maps < 65536 positions: 0 = automatic (id 8), 5 / 9 / 10 / 11 = the other measured shapes"},
     {T_WIDE_GC64, "WIDE_GC64", 1, "k_conv_wide: 64-channel stages per reduction group"},
-    {T_WIDE_DBG, "WIDE_DBG", 0, "k_conv_wide knock-out bits for time attribution (RESULTS ARE WRONG): 1 no LDS reads / MFMA, 4 no gathers, 8 no weight DMA"},
-    {T_WIDE_TRACE, "WIDE_TRACE", 0, "k_conv_wide: print per-phase shader-clock sums of one workgroup (debug instance of the kernel)"},
     {T_ARENA_DBG, "ARENA_DBG", 0, "print coordinate-manager arena allocations to stderr"},
     {T_CONV_WIDE, "CONV_WIDE", 1, "0 = >= 256-output-channel layers stay on k_conv_gather's 8-wave tile (id 16) instead of k_conv_wide (A/B)"},
     {T_MASK_ORDER, "MASK_ORDER", 0, "3^3 maps: sort code of the neighbourhood mask inside a window: 0 the mask, 1 corners > edges > faces, 2 faces > edges > corners, 3 popcount-major"},

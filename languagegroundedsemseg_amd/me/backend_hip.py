@@ -191,7 +191,7 @@ class PackedWeights:
             km._pdesc[ck] = d
         if d.bytes == 0:
             return None, 0
-        key = (op, int(transposed), dt, d.ncp, d.nbp, d.K, cin, cout)
+        key = (op, int(transposed), dt, d.ncp, d.nbp, d.K, cin, cout, int(d.dtype), int(d.bytes))   # (d.dtype: the image's own layout code)
         ent = cache.get(key)
         if ent is None:
             buf = torch.empty(int(d.bytes), dtype=torch.uint8, device=w32.device)

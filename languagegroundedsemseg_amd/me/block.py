@@ -262,7 +262,7 @@ def try_block(q, i, n, final=True):
         return 0
     more = 0 if final else WAIT
     c1 = q[i]
-    if not _is3(c1) or not c1.grad or c1.dropped:
+    if not c1.bs or c1.dropped:
         return 0
     if i + 1 >= n:
         return more
@@ -274,7 +274,7 @@ def try_block(q, i, n, final=True):
     if not n1.relu or n1.uses != 1 or i + 2 >= n:
         return 0
     c2 = q[i + 2]
-    if not (_is3(c2) and c2.inp is n1.out):
+    if not (c2.kind == _d.CONV and c2.bs and c2.inp is n1.out):
         return 0
     if i + 3 >= n:
         return more

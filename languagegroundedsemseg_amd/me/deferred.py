@@ -58,7 +58,7 @@ class Op:
     """one recorded call.  The result tensor is held WEAKLY (it holds the op): when the caller drops a pending result nobody
     consumed, nothing can read or modify it any more, so the call runs right then (`__call__` is the weak reference's callback)
     -- a dropped `norm(x)` still updates its running statistics when it is made, as it would executed immediately."""
-    __slots__ = ("kind", "mod", "inp", "_out", "relu", "residual", "cat_up", "cat_into", "grad", "uses", "aux", "dropped", "mgr",
+    __slots__ = ("kind", "mod", "inp", "_out", "relu", "residual", "cat_up", "cat_into", "grad", "uses", "aux", "dropped", "mgr", "bs",
                  "__weakref__")
 
     def __init__(self, kind, mod, inp, out, aux=None):
@@ -69,6 +69,7 @@ class Op:
         self.grad = torch.is_grad_enabled()
         self.uses = 0            # recorded consumers of `out`
         self.dropped = False
+        self.bs = False          # a convolution that may open a residual block (3^3, stride 1, plain MinkowskiConvolution, grad mode)
 
     @property
     def out(self):
@@ -130,6 +131,7 @@ def record_conv(mod, inp, resolved):
     meta = inp._meta if inp._op is not None else (None, inp._F.dtype, inp._F.device)
     out = SparseTensor._pending(resolved[0], mgr, (mod.out_channels, meta[1], meta[2]))
     op = out._op = Op(CONV, mod, inp, out, resolved)
+    op.bs = op.grad and mod.kernel_volume == 27 and not resolved[2] and mod.stride[0] == 1 and type(mod) is _BLOCK._mod.MinkowskiConvolution
     _use(inp)
     _push(mgr, op)
     if INCREMENTAL:
@@ -223,8 +225,10 @@ def advance(mgr):
     known not to open a residual block (or the block is complete), a norm once its result has a consumer (its ReLU / residual
     epilogue is then final).  Called whenever a consumer is recorded; the GPU starts on a layer while the host records the next"""
     q = mgr._pending
-    if q:
-        _drain(mgr, q, False)
+    n = len(q)
+    if n == 0 or (n < 4 and q[0].bs and not q[0].dropped):     # a block needs four calls before anything about it can be decided
+        return
+    _drain(mgr, q, False)
 
 
 def _drain(mgr, q, final):
