@@ -203,3 +203,65 @@ def test_fullsize_wide_adjoint_identity_ties_forward_dgrad_wgrad(batch):
     scale = (y.double().norm() * gy.double().norm()).item()
     assert abs(a - b) / scale < 6e-3, (a, b)
     assert abs(a - c) / scale < 6e-3, (a, c)
+
+
+# ------------------------------------------------------------------------------------------- round 5: the dominant launch shape
+# itself, at the benchmark's size, against the ORACLE (not a property): level-0 3^3 96 -> 96 on the 1.2 M-voxel batch -- the launch
+# `roofline` is quoted on.  The oracle's BLAS restatement (gather -> GEMM -> scatter per offset, oracle/backend.py "torch") needs about
+# a minute on the host cores for forward + both gradients of this one layer, which is why the other full-size checks are properties.
+_ORACLE_L0 = {}
+
+
+def _oracle_l0(coords, x_np, w_np, g_np):
+    if "v" not in _ORACLE_L0:
+        from oracle.backend import OracleBackend
+        prev = ME.set_backend(OracleBackend("torch"))
+        try:
+            conv = ME.MinkowskiConvolution(96, 96, kernel_size=3, dimension=3)
+            with torch.no_grad():
+                conv.kernel.copy_(torch.from_numpy(w_np))
+            xf = torch.from_numpy(x_np).clone().requires_grad_(True)
+            xs = ME.SparseTensor(xf, torch.from_numpy(coords))
+            y = conv(xs).F
+            y.backward(torch.from_numpy(g_np))
+            _ORACLE_L0["v"] = (y.detach().numpy(), xf.grad.numpy(), conv.kernel.grad.numpy())
+        finally:
+            ME.set_backend(prev)
+    return _ORACLE_L0["v"]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)], ids=["fp32", "bf16"])
+def test_fullsize_dominant_launch_shape_against_the_oracle(batch, dtype, tol):
+    """conv forward, dgrad and weight gradient of 3^3 96 -> 96 on all 1 205 389 voxels (13.7 M pairs) vs the oracle: relative L2 of
+    each tensor (fp32: the split-operand path on the bf16 matrix pipe; bf16: inputs rounded to bf16 first, so only the kernels'
+    own accumulation / output rounding is compared).  Row order: level-0 rows are the caller's rows on both sides."""
+    coords = batch
+    n = coords.shape[0]
+    rng = np.random.default_rng(5)
+    x_np = rng.standard_normal((n, 96), dtype=np.float32)
+    g_np = rng.standard_normal((n, 96), dtype=np.float32)
+    w_np = (rng.standard_normal((27, 96, 96), dtype=np.float32) / np.sqrt(27 * 96)).astype(np.float32)
+    if dtype == torch.bfloat16:       # both sides see bf16-representable inputs
+        x_np = torch.from_numpy(x_np).bfloat16().float().numpy()
+        g_np = torch.from_numpy(g_np).bfloat16().float().numpy()
+        key = "bf16"
+    else:
+        key = "fp32"
+    if _ORACLE_L0.get("key") != key:
+        _ORACLE_L0.clear()
+        _ORACLE_L0["key"] = key
+    oy, ogx, ogw = _oracle_l0(coords, x_np, w_np, g_np)
+    conv = ME.MinkowskiConvolution(96, 96, kernel_size=3, dimension=3).to(DEV)
+    with torch.no_grad():
+        conv.kernel.copy_(torch.from_numpy(w_np))
+    xf = torch.from_numpy(x_np).to(DEV).to(dtype).requires_grad_(True)
+    xs = ME.SparseTensor(xf, torch.from_numpy(coords).to(DEV))
+    y = conv(xs).F
+    y.backward(torch.from_numpy(g_np).to(DEV).to(dtype))
+
+    def rel(a, b):
+        a, b = a.detach().double().cpu(), torch.from_numpy(b).double()
+        return float((a - b).norm() / b.norm())
+    e = (rel(y, oy), rel(xf.grad, ogx), rel(conv.kernel.grad, ogw))
+    print("full size 96->96 %s: rel-L2 forward %.2e, dgrad %.2e, wgrad %.2e" % (key, *e))
+    assert max(e) < tol, e
