@@ -55,6 +55,8 @@ const Knob kKnobs[T_COUNT] = {
                       "0 = the exact-fp32 MFMA instance"},
     {T_BLOCK_WGRAD_LATE, "BLOCK_WGRAD_LATE", 0, "A/B: 1 = lgs_block_backward forks the FIRST convolution's weight gradient after the block's last dgrad instead of "
                             "beside it (the 96->128 dgrad of block8.0 runs 2.1 x its stand-alone time next to k_wgrad_ps 128->96)"},
+    {T_WGRAD_F32_LDS, "WGRAD_F32_LDS", 1, "fp32 weight gradients: 1 = rows staged through LDS with 16-byte loads (k_wgrad_f32_lds; bit-identical "
+                                          "partial slabs), 0 = k_wgrad_f32 (one 4-byte load per lane and MFMA operand)"},
 };
 std::atomic<int64_t> g_val[T_COUNT];
 std::once_flag g_once;

@@ -128,6 +128,168 @@ __global__ __launch_bounds__(256) void k_wgrad_f32(View v, const T *__restrict__
   }
 }
 
+// fp32 rows staged through LDS (round 5).  k_wgrad_f32 above feeds v_mfma_f32_32x32x2_f32 with one 4-byte load per lane and
+// operand: 16 wave-wide load instructions per 12 MFMAs and wave, ~6 per pair at 96 x 96 channels -- the fp32 training step spent
+// 75 ms per step in it (profiles/r05_bench.json, fp32.roofline.discovery_step.wgrad), all of it on the CU's vector-memory
+// instruction rate.  Here the workgroup brings the rows of 32 compacted pairs into LDS with 16-byte loads (input rows: the 128
+// channels of the workgroup's four waves, gradient rows: the NCB x 32 channels of its column tile; every byte once per workgroup
+// instead of once per wave), the next 32 pairs are in flight in registers while the current ones are multiplied, and the MFMA
+// operands are 4-byte LDS reads (row pitch + 32 floats: the two pair rows of one instruction fall on different banks).  The
+// MFMA sequence -- pairs in compacted order, two per instruction -- is k_wgrad_f32's, so the partial slabs are bit-identical.
+// Rows off the 16-byte grid (the 3-channel input layer, odd head widths) are fetched element by element into the same layout.
+template <int NCB, bool AL>
+__global__ __launch_bounds__(256) void k_wgrad_f32_lds(View v, const float *__restrict__ in, int cin_real, const float *__restrict__ gout,
+                                                       int cout_real, int cin_pad, int cout_pad, int64_t span,
+                                                       float *__restrict__ partial) {
+  constexpr int PB = 32;                       // pairs per staged sub-chunk
+  constexpr int AS = 128 + 32, BS = NCB * 32 + 32;
+  constexpr int NB4 = NCB * 8;                 // float4 pieces per gradient row
+  __shared__ int32_t l_in[kWgChunk], l_out[kWgChunk];
+  __shared__ int32_t l_cnt[4];
+  __shared__ __attribute__((aligned(16))) float sA[PB * AS];
+  __shared__ __attribute__((aligned(16))) float sB[PB * BS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vx = lane & 31, h = lane >> 5;
+  const int k = blockIdx.y;
+  const int n_cot = cout_pad / (32 * NCB);
+  const int cot = blockIdx.z % n_cot, cig = blockIdx.z / n_cot;
+  const int cib = cig * 4 + wave;
+  const bool wave_active = cib * 32 < cin_pad;
+  const int slot = v.KS > 1 ? k : 0;
+  const int ca0 = cig * 128, cb0 = cot * NCB * 32;
+  constexpr bool al_in = AL, al_out = AL;      // AL: both operands' rows are 16-byte aligned (the usual case; a template
+                                               // parameter: as a run-time test the aligned instance ran 1.4 x slower)
+
+  f32x16 acc[NCB];
+#pragma unroll
+  for (int nb = 0; nb < NCB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+  float4 ra[4], rb[NCB];
+  auto fetch = [&](int sub, int total) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 5, c4 = idx & 31;
+      const int pr = sub * PB + r, ch = ca0 + 4 * c4;
+      ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pr < total && ch < cin_real) {
+        const float *row = in + (int64_t)l_in[pr] * cin_real + ch;
+        if constexpr (al_in) ra[u] = *reinterpret_cast<const float4 *>(row);
+        else {                                  // rows off the 16-byte grid (the 3-channel input layer, odd head widths)
+          ra[u].x = row[0];
+          if (ch + 1 < cin_real) ra[u].y = row[1];
+          if (ch + 2 < cin_real) ra[u].z = row[2];
+          if (ch + 3 < cin_real) ra[u].w = row[3];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NCB; ++u) {
+      const int idx = tid + 256 * u, r = idx / NB4, c4 = idx % NB4;
+      const int pr = sub * PB + r, ch = cb0 + 4 * c4;
+      rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pr < total && ch < cout_real) {
+        const float *row = gout + (int64_t)l_out[pr] * cout_real + ch;
+        if constexpr (al_out) rb[u] = *reinterpret_cast<const float4 *>(row);
+        else {
+          rb[u].x = row[0];
+          if (ch + 1 < cout_real) rb[u].y = row[1];
+          if (ch + 2 < cout_real) rb[u].z = row[2];
+          if (ch + 3 < cout_real) rb[u].w = row[3];
+        }
+      }
+    }
+  };
+  auto stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 5, c4 = idx & 31;
+      *reinterpret_cast<float4 *>(sA + r * AS + 4 * c4) = ra[u];
+    }
+#pragma unroll
+    for (int u = 0; u < NCB; ++u) {
+      const int idx = tid + 256 * u, r = idx / NB4, c4 = idx % NB4;
+      *reinterpret_cast<float4 *>(sB + r * BS + 4 * c4) = rb[u];
+    }
+  };
+
+  const int64_t p_begin = (int64_t)blockIdx.x * span;
+  const int64_t p_end = min(p_begin + span, v.n_pad);
+  for (int64_t base = p_begin; base < p_end; base += kWgChunk) {
+    // ---- compact valid pairs of this chunk (two positions per thread, fixed wave order): as k_wgrad_f32
+    int32_t my_in[2], my_out[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int64_t p = base + wave * 128 + u * 64 + lane;
+      int32_t i = -1, o = -1;
+      if (p < p_end) {
+        bool grp_ok = true;
+        if (v.KS > 1) grp_ok = (v.mask64[p >> 6] >> slot) & 1u;
+        else if (v.tile_k) grp_ok = v.tile_k[p >> 6] == k;
+        if (grp_ok) {
+          o = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
+          i = v.nbr ? v.nbr[(int64_t)slot * v.n_pad + p] : (p < v.n_in ? (int32_t)p : -1);
+        }
+      }
+      my_in[u] = (i >= 0 && o >= 0) ? i : -1;
+      my_out[u] = o;
+    }
+    unsigned long long bal0 = __ballot(my_in[0] >= 0), bal1 = __ballot(my_in[1] >= 0);
+    int c0 = (int)__builtin_popcountll(bal0), c1 = (int)__builtin_popcountll(bal1);
+    if (lane == 0) l_cnt[wave] = c0 + c1;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      int c = l_cnt[w];
+      if (w < wave) wbase += c;
+      total += c;
+    }
+    if (my_in[0] >= 0) {
+      int at = wbase + (int)__builtin_popcountll(bal0 & ((1ull << lane) - 1ull));
+      l_in[at] = my_in[0]; l_out[at] = my_out[0];
+    }
+    if (my_in[1] >= 0) {
+      int at = wbase + c0 + (int)__builtin_popcountll(bal1 & ((1ull << lane) - 1ull));
+      l_in[at] = my_in[1]; l_out[at] = my_out[1];
+    }
+    __syncthreads();
+    const int nsub = (total + PB - 1) / PB;
+    if (nsub > 0) fetch(0, total);
+    for (int sub = 0; sub < nsub; ++sub) {
+      stage();
+      __syncthreads();
+      if (sub + 1 < nsub) fetch(sub + 1, total);             // in flight while this sub-chunk is multiplied
+      if (wave_active) {
+        const int np = min(PB, total - sub * PB);
+        const float *pa = sA + h * AS + wave * 32 + vx;
+        const float *pb = sB + h * BS + vx;
+        for (int pp = 0; pp < np; pp += 2) {
+          const float a = pa[pp * AS];
+          float b[NCB];
+#pragma unroll
+          for (int nb = 0; nb < NCB; ++nb) b[nb] = pb[pp * BS + nb * 32];
+#pragma unroll
+          for (int nb = 0; nb < NCB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[nb], acc[nb], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (!wave_active) return;
+  float *dst = partial + (((int64_t)blockIdx.x * v.K + k) * cin_pad) * cout_pad;
+#pragma unroll
+  for (int nb = 0; nb < NCB; ++nb) {
+    int co = (cot * NCB + nb) * 32 + vx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int ci = cib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      dst[(int64_t)ci * cout_pad + co] = acc[nb][r];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ bf16 MFMA path
 constexpr int kQ = 1024;       // positions compacted per wave chunk
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -1116,7 +1278,27 @@ int conv_wgrad_f32path(const View &v, const void *in_v, int cin, const void *gou
   int n_cot = p.cout_pad / (32 * p.ncb);
   int n_cig = (p.cin_pad / 32 + 3) / 4;
   dim3 grid((unsigned)p.S, (unsigned)v.K, (unsigned)(n_cot * n_cig));
-  switch (p.ncb) {
+  bool staged = false;
+  if constexpr (sizeof(T) == 4) {
+    if (tune(T_WGRAD_F32_LDS) != 0) {
+      staged = true;
+      const float *fi = reinterpret_cast<const float *>(in), *fg = reinterpret_cast<const float *>(go);
+      const bool al = cin % 4 == 0 && cout % 4 == 0 && (reinterpret_cast<uintptr_t>(fi) & 15u) == 0 && (reinterpret_cast<uintptr_t>(fg) & 15u) == 0;
+#define LGS_WF(N)                                                                                                              \
+  do {                                                                                                                         \
+    if (al) LGS_KLAUNCH((k_wgrad_f32_lds<N, true>), grid, 256, 0, s, v, fi, cin, fg, cout, p.cin_pad, p.cout_pad, p.span, partial); \
+    else LGS_KLAUNCH((k_wgrad_f32_lds<N, false>), grid, 256, 0, s, v, fi, cin, fg, cout, p.cin_pad, p.cout_pad, p.span, partial);   \
+  } while (0)
+      switch (p.ncb) {
+        case 4: LGS_WF(4); break;
+        case 3: LGS_WF(3); break;
+        case 2: LGS_WF(2); break;
+        default: LGS_WF(1); break;
+      }
+#undef LGS_WF
+    }
+  }
+  if (!staged) switch (p.ncb) {
     case 4: LGS_KLAUNCH((k_wgrad_f32<T, 4>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
     case 3: LGS_KLAUNCH((k_wgrad_f32<T, 3>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
     case 2: LGS_KLAUNCH((k_wgrad_f32<T, 2>), grid, 256, 0, s, v, in, cin, go, cout, p.cin_pad, p.cout_pad, p.span, partial); break;

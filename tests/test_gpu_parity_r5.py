@@ -74,3 +74,37 @@ def test_syncbn_record_combination_matches_full_batch_statistics():
         assert torch.allclose(stats[c:].double(), 1.0 / torch.sqrt(var + 1e-5), atol=tol, rtol=1e-4)
         assert abs(float(inv_n) - 1.0 / full.shape[0]) < 1e-12 and int(nbt) == 1
         assert torch.allclose(rm.double(), 0.1 * mean, atol=tol) and torch.allclose(rv.double(), 0.9 + 0.1 * full.var(0, unbiased=True), rtol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,ks", [(96, 96, 3), (32, 64, 2), (128, 96, 3), (96, 200, 1), (256, 256, 3), (36, 20, 3), (3, 32, 3), (96, 3, 1), (30, 7, 3)])
+def test_fp32_weight_gradient_staged_through_lds_is_the_pairwise_kernel_bit_for_bit(cin, cout, ks):
+    """k_wgrad_f32_lds (16-byte row loads into LDS, round 5) issues k_wgrad_f32's MFMA sequence on the same compacted pairs: the
+    gradient must be IDENTICAL, on 3^3, strided 2^3 (forward and transposed use) and 1x1 maps, and match the oracle"""
+    import MinkowskiEngine as ME
+    from helpers import small_scene
+    from languagegroundedsemseg_amd import engine
+    from oracle import oracle as orc
+    coords = small_scene(11, n=6000, extent=40)
+    c = torch.from_numpy(coords).to(DEV)
+    x = ME.SparseTensor(torch.zeros(coords.shape[0], 1, device=DEV), c)
+    mgr, k0 = x.coordinate_manager, x.coordinate_map_key
+    k1 = mgr.stride(k0, 2) if ks == 2 else k0
+    km = mgr.kernel_map_handle(k0, k1, ks)
+    for transposed in ((False, True) if ks == 2 else (False,)):
+        n_in, n_out = km._rows(transposed)
+        g = torch.Generator(device=DEV).manual_seed(3)
+        a = torch.randn(n_in, cin, device=DEV, generator=g)
+        b = torch.randn(n_out, cout, device=DEV, generator=g)
+        engine.dispatch_counts(reset=True)
+        w1 = km.conv_wgrad(a, b, transposed)
+        sites = engine.dispatch_counts(reset=True)
+        assert any(s.startswith("k_wgrad_f32_lds") for s in sites), sites
+        with engine.tuning(WGRAD_F32_LDS=0):
+            w0 = km.conv_wgrad(a, b, transposed)
+        assert torch.equal(w0, w1)
+        kk, ii, oo = (t.cpu().numpy() for t in km.export())
+        if transposed:
+            ii, oo = oo, ii
+        want = orc.conv_wgrad(a.cpu().numpy(), b.cpu().numpy(), (kk, ii, oo), ks ** 3)
+        rel = float(np.linalg.norm(w1.cpu().numpy().reshape(want.shape) - want) / np.linalg.norm(want))
+        assert rel < 2e-5, rel
