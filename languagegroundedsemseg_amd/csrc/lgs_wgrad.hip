@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void k_wgrad_f32(View v, const T *__restrict__
 // instead of once per wave), the next 32 pairs are in flight in registers while the current ones are multiplied, and the MFMA
 // operands are 4-byte LDS reads (row pitch + 32 floats: the two pair rows of one instruction fall on different banks).  The
 // MFMA sequence -- pairs in compacted order, two per instruction -- is k_wgrad_f32's, so the partial slabs are bit-identical.
-// Rows off the 16-byte grid (the 3-channel input layer, odd head widths) are fetched element by element into the same layout.
-template <int NCB, bool AL>
+// Needs rows on the 16-byte grid (the 3-channel input layer and odd head widths keep k_wgrad_f32).
+template <int NCB>
 __global__ __launch_bounds__(256) void k_wgrad_f32_lds(View v, const float *__restrict__ in, int cin_real, const float *__restrict__ gout,
                                                        int cout_real, int cin_pad, int cout_pad, int64_t span,
                                                        float *__restrict__ partial) {
@@ -157,8 +157,6 @@ __global__ __launch_bounds__(256) void k_wgrad_f32_lds(View v, const float *__re
   const bool wave_active = cib * 32 < cin_pad;
   const int slot = v.KS > 1 ? k : 0;
   const int ca0 = cig * 128, cb0 = cot * NCB * 32;
-  constexpr bool al_in = AL, al_out = AL;      // AL: both operands' rows are 16-byte aligned (the usual case; a template
-                                               // parameter: as a run-time test the aligned instance ran 1.4 x slower)
 
   f32x16 acc[NCB];
 #pragma unroll
@@ -173,32 +171,14 @@ __global__ __launch_bounds__(256) void k_wgrad_f32_lds(View v, const float *__re
       const int idx = tid + 256 * u, r = idx >> 5, c4 = idx & 31;
       const int pr = sub * PB + r, ch = ca0 + 4 * c4;
       ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pr < total && ch < cin_real) {
-        const float *row = in + (int64_t)l_in[pr] * cin_real + ch;
-        if constexpr (al_in) ra[u] = *reinterpret_cast<const float4 *>(row);
-        else {                                  // rows off the 16-byte grid (the 3-channel input layer, odd head widths)
-          ra[u].x = row[0];
-          if (ch + 1 < cin_real) ra[u].y = row[1];
-          if (ch + 2 < cin_real) ra[u].z = row[2];
-          if (ch + 3 < cin_real) ra[u].w = row[3];
-        }
-      }
+      if (pr < total && ch < cin_real) ra[u] = *reinterpret_cast<const float4 *>(in + (int64_t)l_in[pr] * cin_real + ch);
     }
 #pragma unroll
     for (int u = 0; u < NCB; ++u) {
       const int idx = tid + 256 * u, r = idx / NB4, c4 = idx % NB4;
       const int pr = sub * PB + r, ch = cb0 + 4 * c4;
       rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pr < total && ch < cout_real) {
-        const float *row = gout + (int64_t)l_out[pr] * cout_real + ch;
-        if constexpr (al_out) rb[u] = *reinterpret_cast<const float4 *>(row);
-        else {
-          rb[u].x = row[0];
-          if (ch + 1 < cout_real) rb[u].y = row[1];
-          if (ch + 2 < cout_real) rb[u].z = row[2];
-          if (ch + 3 < cout_real) rb[u].w = row[3];
-        }
-      }
+      if (pr < total && ch < cout_real) rb[u] = *reinterpret_cast<const float4 *>(gout + (int64_t)l_out[pr] * cout_real + ch);
     }
   };
   auto stage = [&]() __attribute__((always_inline)) {
@@ -262,16 +242,21 @@ __global__ __launch_bounds__(256) void k_wgrad_f32_lds(View v, const float *__re
       __syncthreads();
       if (sub + 1 < nsub) fetch(sub + 1, total);             // in flight while this sub-chunk is multiplied
       if (wave_active) {
-        const int np = min(PB, total - sub * PB);
+        const int np = min(PB, (total - sub * PB + 7) & ~7);     // rows behind `total` are staged as zeros: whole groups of 8 pairs
         const float *pa = sA + h * AS + wave * 32 + vx;
         const float *pb = sB + h * BS + vx;
-        for (int pp = 0; pp < np; pp += 2) {
-          const float a = pa[pp * AS];
-          float b[NCB];
+        for (int p8 = 0; p8 < np; p8 += 8) {
+          float a[4], b[4][NCB];
 #pragma unroll
-          for (int nb = 0; nb < NCB; ++nb) b[nb] = pb[pp * BS + nb * 32];
+          for (int q = 0; q < 4; ++q) {
+            a[q] = pa[(p8 + 2 * q) * AS];
 #pragma unroll
-          for (int nb = 0; nb < NCB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[nb], acc[nb], 0, 0, 0);
+            for (int nb = 0; nb < NCB; ++nb) b[q][nb] = pb[(p8 + 2 * q) * BS + nb * 32];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int nb = 0; nb < NCB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q][nb], acc[nb], 0, 0, 0);
         }
       }
       __syncthreads();
@@ -1280,22 +1265,17 @@ int conv_wgrad_f32path(const View &v, const void *in_v, int cin, const void *gou
   dim3 grid((unsigned)p.S, (unsigned)v.K, (unsigned)(n_cot * n_cig));
   bool staged = false;
   if constexpr (sizeof(T) == 4) {
-    if (tune(T_WGRAD_F32_LDS) != 0) {
+    const float *fi = reinterpret_cast<const float *>(in), *fg = reinterpret_cast<const float *>(go);
+    // rows off the 16-byte grid (the 3-channel input layer: 1.99 vs 1.70 ms staged element by element, odd head widths) keep k_wgrad_f32
+    if (tune(T_WGRAD_F32_LDS) != 0 && cin % 4 == 0 && cout % 4 == 0 && (reinterpret_cast<uintptr_t>(fi) & 15u) == 0 &&
+        (reinterpret_cast<uintptr_t>(fg) & 15u) == 0) {
       staged = true;
-      const float *fi = reinterpret_cast<const float *>(in), *fg = reinterpret_cast<const float *>(go);
-      const bool al = cin % 4 == 0 && cout % 4 == 0 && (reinterpret_cast<uintptr_t>(fi) & 15u) == 0 && (reinterpret_cast<uintptr_t>(fg) & 15u) == 0;
-#define LGS_WF(N)                                                                                                              \
-  do {                                                                                                                         \
-    if (al) LGS_KLAUNCH((k_wgrad_f32_lds<N, true>), grid, 256, 0, s, v, fi, cin, fg, cout, p.cin_pad, p.cout_pad, p.span, partial); \
-    else LGS_KLAUNCH((k_wgrad_f32_lds<N, false>), grid, 256, 0, s, v, fi, cin, fg, cout, p.cin_pad, p.cout_pad, p.span, partial);   \
-  } while (0)
       switch (p.ncb) {
-        case 4: LGS_WF(4); break;
-        case 3: LGS_WF(3); break;
-        case 2: LGS_WF(2); break;
-        default: LGS_WF(1); break;
+        case 4: LGS_KLAUNCH((k_wgrad_f32_lds<4>), grid, 256, 0, s, v, fi, cin, fg, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
+        case 3: LGS_KLAUNCH((k_wgrad_f32_lds<3>), grid, 256, 0, s, v, fi, cin, fg, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
+        case 2: LGS_KLAUNCH((k_wgrad_f32_lds<2>), grid, 256, 0, s, v, fi, cin, fg, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
+        default: LGS_KLAUNCH((k_wgrad_f32_lds<1>), grid, 256, 0, s, v, fi, cin, fg, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
       }
-#undef LGS_WF
     }
   }
   if (!staged) switch (p.ncb) {

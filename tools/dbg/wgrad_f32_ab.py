@@ -14,7 +14,7 @@ n = coords.shape[0]
 x = ME.SparseTensor(torch.zeros(n, 3, device=DEV), c)
 mgr, k0 = x.coordinate_manager, x.coordinate_map_key
 km = mgr.kernel_map_handle(k0, k0, 3)
-for cin, cout in ((96, 96), (128, 96), (32, 32), (96, 200)):
+for cin, cout in ((96, 96), (128, 96), (32, 32), (96, 200), (3, 32)):
     f = torch.randn(n, cin, device=DEV)
     g = torch.randn(n, cout, device=DEV)
     t = {}
