@@ -141,7 +141,7 @@ template <int NCB>
 __global__ __launch_bounds__(256) void k_wgrad_f32_lds(View v, const float *__restrict__ in, int cin_real, const float *__restrict__ gout,
                                                        int cout_real, int cin_pad, int cout_pad, int64_t span,
                                                        float *__restrict__ partial) {
-  constexpr int PB = 32;                       // pairs per staged sub-chunk
+  constexpr int PB = 16;                       // pairs per staged sub-chunk (16 / 32 / 64 at level 0, 96 x 96: 3.1 / 3.5 / 3.7 ms)
   constexpr int AS = 128 + 32, BS = NCB * 32 + 32;
   constexpr int NB4 = NCB * 8;                 // float4 pieces per gradient row
   __shared__ int32_t l_in[kWgChunk], l_out[kWgChunk];
@@ -150,7 +150,9 @@ __global__ __launch_bounds__(256) void k_wgrad_f32_lds(View v, const float *__re
   __shared__ __attribute__((aligned(16))) float sB[PB * BS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vx = lane & 31, h = lane >> 5;
-  const int k = blockIdx.y;
+  // 3^3 maps: the centre offset pairs every position, a corner offset ~15 % of them -- the heavy offsets are dispatched first
+  const int y = blockIdx.y;
+  const int k = v.K == 27 ? (y == 0 ? 13 : (y & 1) ? 13 - (y + 1) / 2 : 13 + y / 2) : y;
   const int n_cot = cout_pad / (32 * NCB);
   const int cot = blockIdx.z % n_cot, cig = blockIdx.z / n_cot;
   const int cib = cig * 4 + wave;
@@ -164,33 +166,34 @@ __global__ __launch_bounds__(256) void k_wgrad_f32_lds(View v, const float *__re
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 
-  float4 ra[4], rb[NCB];
+  constexpr int NA = PB * 32 / 256, NBQ = (PB * NB4 + 255) / 256;
+  float4 ra[NA], rb[NBQ];
   auto fetch = [&](int sub, int total) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NA; ++u) {
       const int idx = tid + 256 * u, r = idx >> 5, c4 = idx & 31;
       const int pr = sub * PB + r, ch = ca0 + 4 * c4;
       ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (pr < total && ch < cin_real) ra[u] = *reinterpret_cast<const float4 *>(in + (int64_t)l_in[pr] * cin_real + ch);
     }
 #pragma unroll
-    for (int u = 0; u < NCB; ++u) {
+    for (int u = 0; u < NBQ; ++u) {
       const int idx = tid + 256 * u, r = idx / NB4, c4 = idx % NB4;
       const int pr = sub * PB + r, ch = cb0 + 4 * c4;
       rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pr < total && ch < cout_real) rb[u] = *reinterpret_cast<const float4 *>(gout + (int64_t)l_out[pr] * cout_real + ch);
+      if (idx < PB * NB4 && pr < total && ch < cout_real) rb[u] = *reinterpret_cast<const float4 *>(gout + (int64_t)l_out[pr] * cout_real + ch);
     }
   };
   auto stage = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NA; ++u) {
       const int idx = tid + 256 * u, r = idx >> 5, c4 = idx & 31;
       *reinterpret_cast<float4 *>(sA + r * AS + 4 * c4) = ra[u];
     }
 #pragma unroll
-    for (int u = 0; u < NCB; ++u) {
+    for (int u = 0; u < NBQ; ++u) {
       const int idx = tid + 256 * u, r = idx / NB4, c4 = idx % NB4;
-      *reinterpret_cast<float4 *>(sB + r * BS + 4 * c4) = rb[u];
+      if (idx < PB * NB4) *reinterpret_cast<float4 *>(sB + r * BS + 4 * c4) = rb[u];
     }
   };
 
@@ -1027,7 +1030,7 @@ inline WgradPlan wgrad_plan(const View &v, int cin, int cout, int dtype) {
     int64_t chunks = (v.n_pad + kWgChunk - 1) / kWgChunk;
     int64_t S = chunks / 4;
     if (S < 1) S = 1;
-    if (S > 64) S = 64;
+    if (S > 128) S = 128;     // (64 until round 5: 27 x 64 workgroups of very unequal work -- the centre offset has ~7 x a corner's pairs -- left a long tail)
     while (S > 1 && S * per > (1ll << 30)) S /= 2;
     int64_t cps = (chunks + S - 1) / S;
     p.span = cps * kWgChunk;
