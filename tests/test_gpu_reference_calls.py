@@ -9,8 +9,8 @@ signatures; tests/test_deferred_cpu.py shows the reference's unchanged files rec
   * the SAME sequence executed call by call (LGS_DEFER=0: unfused norm, nn.ReLU in place on a custom Function's output, add_ in
     place, torch.cat copies) -- whole network forward + backward, i.e. every in-place op is autograd-legal -- against the oracle
     and against the fused execution;
-  * what the executor made of the record: one whole-block node per residual block, four concats whose `up` half was written in
-    place, no elementwise ReLU / add / torch.cat launches."""
+  * what the executor made of the record (deferred.STATS): one whole-block node per residual block, four concats whose `up` half
+    was written in place."""
 import numpy as np
 import pytest
 import torch
