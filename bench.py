@@ -851,7 +851,7 @@ def main():
         del model, ddp, opt
         gc.collect()
         torch.cuda.empty_cache()
-        out["fp32"] = secondary_block("ce", "Res16UNet34C", torch.float32, coords, feats, labels, device, args, clog, steps=5, warmup=3,
+        out["fp32"] = secondary_block("ce", "Res16UNet34C", torch.float32, coords, feats, labels, device, args, clog, steps=6, warmup=5,
                                       note="the parity path (fp32 storage: logits within 1e-3 of the oracle).  Convolution forward / dgrad "
                                            "multiply on the bf16 matrix pipe with exactly split operands (x = hi + mid + lo, six products, fp32 "
                                            "accumulate; knob FP32_SPLIT); weight gradients on the exact-fp32 MFMA")
