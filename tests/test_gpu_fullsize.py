@@ -1,5 +1,7 @@
-"""Full-size checks (BASELINE configs[1]: 8 scenes, ~1.2 M voxels @2cm) through SIZE-INDEPENDENT properties -- the
-oracle would need minutes here, so the HIP path is held against identities any correct sparse convolution satisfies:
+"""Full-size checks (BASELINE configs[1]: 8 scenes, ~1.2 M voxels @2cm).  Round 5: the dominant launch shape (3^3 96 -> 96) and the
+level 0 <-> 1 strided / transposed pair run against the ORACLE itself at this size (bottom of the file, ~2 minutes of host time);
+a whole network would need many minutes, so the rest of the HIP path is held against identities any correct sparse convolution
+satisfies:
 
 * coordinate maps against numpy set arithmetic (dedup, stride-2 coarsening = unique(floor(c / 2) * 2));
 * kernel-map pair counts: offset k and its mirror 26-k have the same number of pairs, the centre has N;
@@ -264,4 +266,24 @@ def test_fullsize_dominant_launch_shape_against_the_oracle(batch, dtype, tol):
         return float((a - b).norm() / b.norm())
     e = (rel(y, oy), rel(xf.grad, ogx), rel(conv.kernel.grad, ogw))
     print("full size 96->96 %s: rel-L2 forward %.2e, dgrad %.2e, wgrad %.2e" % (key, *e))
+    assert max(e) < tol, e
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 2e-2)], ids=["fp32", "bf16"])
+def test_fullsize_strided_and_transposed_convolutions_against_the_oracle(batch, dtype, tol):
+    """the level 0 <-> level 1 pair of the benchmark batch (conv1p1s2 / convtr7p2s2 shapes: 2^3 stride 2 down, transposed 2^3 up,
+    res16unet.py:205,262) on all 1.2 M voxels vs the oracle: output (back on the input's rows), input gradient and both weight
+    gradients; the oracle builds its own coarse map (rows compared by coordinate)"""
+    from test_gpu_engine import run_both, rel_err
+    coords = batch
+    feats = np.random.default_rng(9).standard_normal((coords.shape[0], 32)).astype(np.float32)
+    if dtype == torch.bfloat16:
+        feats = torch.from_numpy(feats).bfloat16().float().numpy()
+
+    def build():
+        return [ME.MinkowskiConvolution(32, 64, kernel_size=2, stride=2, dimension=3),
+                ME.MinkowskiConvolutionTranspose(64, 96, kernel_size=2, stride=2, dimension=3)]
+    (h_out, h_g), (o_out, o_g) = run_both(build, coords, feats, dtype=dtype, oracle_impl="torch")
+    e = [rel_err(h_out, o_out)] + [rel_err(a, b) for a, b in zip(h_g, o_g)]
+    print("full size 2^3 s2 down + transposed up, %s: rel err out %.2e, d input %.2e, dW down %.2e, dW up %.2e" % ((str(dtype),) + tuple(e)))
     assert max(e) < tol, e
