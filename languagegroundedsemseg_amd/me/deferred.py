@@ -33,9 +33,10 @@ residual block and direction (csrc/lgs_block.hip) -- so the ME surface RECORDS i
 Nothing is re-ordered except the in-place `+=` above, BatchNorm running statistics are updated exactly once per call, module
 forward hooks fire at call time as torch defines them (a hook that reads `.F` simply executes what was recorded so far, i.e.
 hooks force the call-by-call sequence), `torch.no_grad()` / `enable_grad()` are honoured per recorded call, and switching a
-norm between train() and eval() -- or the backend -- executes what is pending first.  A call whose result is never consumed and
-never read does not run (its norm's running statistics are not updated): values drive execution.  `LGS_DEFER=0` executes every
-call immediately (the unfused sequence: same results, tests/test_gpu_reference_calls.py).
+norm between train() and eval() -- or the backend -- executes what is pending first.  A pending result that the caller DROPS
+without reading or consuming it executes at that moment (class Op: the result is held weakly and its finaliser drains the queue),
+so a discarded `norm(x)` still updates its running statistics when the call is made.  `LGS_DEFER=0` executes every call
+immediately (the unfused sequence: same results, tests/test_gpu_reference_calls.py).
 """
 import sys
 import weakref
