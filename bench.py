@@ -313,13 +313,13 @@ def pmc_traffic(dom_key, args):
     doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for the default workload they were collected on, null
     otherwise.  It is not measured inside this run (PMC collection needs the profiler)."""
     wide = "K=27 512->512" in dom_key                 # the CLIP workload's dominant shape (k_conv_wide)
-    names = ("r04_pmc_traffic_wide.json",) if wide else ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
-    for name in names:
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            break
-    else:
+    import glob
+    suffix = "_pmc_traffic_wide.json" if wide else "_pmc_traffic.json"
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]" + suffix)), reverse=True)     # newest round first
+    if not found:
         return None, None
+    path = found[0]
+    name = os.path.basename(path)
     if not (args.scenes == 8 and args.voxels == 150000 and args.dtype == "bf16" and ("K=27 96->96" in dom_key or wide)):
         return None, None
     try:
