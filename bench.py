@@ -243,6 +243,15 @@ def train_step(model, ddp, opt, coords, feats, labels, dtype, step_idx, shift=Tr
         off, logits, _ = model(sinput)
         nl, dl = instance_offset_losses(off.F, c[:, 1:], ctx["centers"], ctx["inst"], 0.02)
         loss = fused_cross_entropy(logits.F, labels, ignore_index=-1) + nl + dl
+    elif kind == "ce_balanced":
+        # the fine-tune step as scripts/train_models.sh:37 runs it (--balanced_category_sampling True): CrossEntropyLoss(reduction=
+        # 'none') -> sample_categories_for_balancing -> masked mean over ALL points (pl_BaselineTrainer.py:94,350-356,
+        # lib/losses/utils.py:13-77); split statistics stay on the device (what the trainer's head / common / tail meters consume)
+        from languagegroundedsemseg_amd.losses import sample_categories_for_balancing
+        logits, _ = model(sinput)
+        rows = fused_cross_entropy(logits.F, labels, ignore_index=-1, reduction="none")
+        loss, ctx["split_stats"], _ = sample_categories_for_balancing(rows, labels, ctx["foc"], ctx["head_ratio"], ctx["common_ratio"],
+                                                                       ignore_label=-1, split="stats")
     else:
         logits, _ = model(sinput)
         loss = fused_cross_entropy(logits.F, labels, ignore_index=-1)
@@ -270,41 +279,60 @@ def timed_steps(model, ddp, opt, coords, feats, labels, dtype, steps, warmup, ct
     return dt / steps * 1e3, phase_summary(steps)
 
 
-def cpu_baseline(seconds_budget=30.0, model_name="Res16UNet34C", voxels=150000):
+def cpu_baseline(seconds_budget=30.0, model_name="Res16UNet34C", voxels=150000, voxel=0.02, loss="ce", max_steps=3):
     """Oracle ("port"): MinkowskiEngine-CPU-style gather -> BLAS GEMM -> scatter restated with torch CPU ops, same
-    model, ONE synthetic 2 cm scene of ~150k voxels (BASELINE.md section 2, config 2 -- the scene unit the GPU runs eight
-    of per step), host cores, fwd + loss + bwd.  Bounded: one warm-up step, then timed steps until the budget is spent."""
+    model, ONE synthetic scene (default: 2 cm, ~150k voxels = BASELINE.md section 2, config 2 -- the scene unit the GPU runs eight
+    of per step), host cores, fwd + loss + bwd.  Bounded: one warm-up step, then timed steps until the budget is spent.
+    loss="clip": the text-anchor contrastive loss of configs[2] (dense similarity + gathers on the CPU)."""
     from oracle.backend import OracleBackend
     prev = ME.set_backend(OracleBackend("torch"))
     try:
         cores = min(host_cores(), 16)  # more threads only add OpenMP contention to the small per-offset GEMMs
         torch.set_num_threads(cores)
-        coords, feats, labels = make_batch([0], voxel=0.02, n_target=voxels)
+        coords, feats, labels = make_batch([0], voxel=voxel, n_target=voxels)
         torch.manual_seed(42)
         model = models.load_model(model_name)(3, 200, Cfg()).train()
         c, f, l = torch.from_numpy(coords), torch.from_numpy(feats), torch.from_numpy(labels)
+        crit = anchors = None
+        if loss == "clip":
+            from languagegroundedsemseg_amd.losses import ContrastiveLanguageLoss
+            from languagegroundedsemseg_amd.synthetic import text_anchors
+            model.representation_only(True)
+            crit = ContrastiveLanguageLoss(num_labels=200, num_negative_samples=3)
+            anchors = torch.from_numpy(text_anchors(200, model.PLANES[7]))
 
         def one():
             for p in model.parameters():
                 p.grad = None
             x = ME.SparseTensor(f, c)
-            logits, _ = model(x)
-            loss = torch.nn.functional.cross_entropy(logits.F, l, ignore_index=-1)
-            loss.backward()
+            if crit is not None:
+                out = crit(model(x).F, l, anchors)[0]
+            else:
+                logits, _ = model(x)
+                out = torch.nn.functional.cross_entropy(logits.F, l, ignore_index=-1)
+            out.backward()
         t_all = time.perf_counter()
         one()  # warm-up (builds nothing persistent: maps are per step, as in the reference)
         times = []
-        while len(times) < 3 and (not times or (time.perf_counter() - t_all) < seconds_budget):
+        while len(times) < max_steps and (not times or (time.perf_counter() - t_all) < seconds_budget):
             t0 = time.perf_counter()
             one()
             times.append(time.perf_counter() - t0)
         best = min(times)
         return {"value": coords.shape[0] / best, "unit": "voxels/s", "cores": cores, "kind": "port",
-                "sample": "%s fwd+loss+bwd, 1 synthetic scene @2cm (%d voxels), fp32, best of %d after 1 warm-up (%.1f s of CPU "
+                "sample": "%s fwd+%s loss+bwd, 1 synthetic scene @%gcm (%d voxels), fp32, best of %d after 1 warm-up (%.1f s of CPU "
                           "work); oracle BLAS gather-GEMM-scatter restatement of ME's CPU algorithm (not ME itself)" % (
-                              model_name, coords.shape[0], len(times), time.perf_counter() - t_all)}
+                              model_name, loss, voxel * 100, coords.shape[0], len(times), time.perf_counter() - t_all)}
     finally:
         ME.set_backend(prev)
+
+
+def cpu_baselines_other_configs():
+    """BASELINE.md section 2's other two CPU rows, bounded (details file only; the line's `cpu_baseline` is configs[1]'s):
+    configs[0] Res16UNet14A @5 cm, one scene -- the reference's own CPU-runnable case; configs[2] Res16UNet34D + contrastive
+    text-anchor loss on a 40k-voxel 2 cm scene (a full 150k-voxel scene of the 512-channel decoder is ~1 min per CPU step)."""
+    return {"configs0_res16unet14a_5cm": cpu_baseline(8.0, "Res16UNet14A", voxels=25000, voxel=0.05, max_steps=3),
+            "configs2_res16unet34d_clip_sample": cpu_baseline(20.0, "Res16UNet34D", voxels=40000, voxel=0.02, loss="clip", max_steps=2)}
 
 
 def pmc_traffic(dom_key, args):
@@ -390,6 +418,10 @@ def workload_text(workload, model_name):
     if workload == "ce":
         return ("%s 2cm ScanNet200-shaped synthetic scenes, cross-entropy fine-tune step (configs[1]): SparseTensor build + "
                 "fwd + CE(200) + bwd + grad all-reduce + SGD" % model_name)
+    if workload.startswith("ce_balanced"):
+        return ("%s fine-tune step with --balanced_category_sampling True (scripts/train_models.sh:37): per-point CE + "
+                "sample_categories_for_balancing (%s) + bwd + SGD" % (
+                    model_name, "head / common ratios 0.5" if workload.endswith("sampled") else "ratios -1 = config defaults"))
     if workload == "clip":
         return ("%s 2cm synthetic scenes, CLIP-contrastive pretrain step (configs[2]): SparseTensor build + fwd + text-anchor "
                 "contrastive loss (200 anchors, MFMA contraction) + bwd + grad all-reduce + SGD" % model_name)
@@ -405,6 +437,14 @@ def make_ctx(workload, model_name, coords, device):
         dim = models.load_model(model_name).PLANES[7]
         return {"kind": "clip", "crit": ContrastiveLanguageLoss(num_labels=200, num_negative_samples=3),
                 "anchors": torch.from_numpy(text_anchors(200, dim)).to(device)}
+    if workload in ("ce_balanced", "ce_balanced_sampled"):
+        # ScanNet200's split: 66 head / 68 common / 66 tail categories (lib/datasets/scannet.py:131-141, lib/constants); the synthetic
+        # labels are uniform over the 200 classes, so which ids are "head" does not matter for the timing
+        foc = torch.zeros(200, 3, dtype=torch.bool)
+        foc[:66, 0], foc[66:134, 1], foc[134:, 2] = True, True, True
+        sampled = workload.endswith("sampled")      # config.py:281-282 defaults are -1 / -1 (keep all); `sampled` draws half of head / common
+        return {"kind": "ce_balanced", "foc": foc.to(device), "head_ratio": 0.5 if sampled else -1.0,
+                "common_ratio": 0.5 if sampled else -1.0}
     if workload in ("insseg", "insseg_frozen"):
         g = torch.Generator().manual_seed(0)
         n = coords.shape[0]
@@ -428,34 +468,65 @@ def make_trainer(model_name, dtype, device, world, args, ctx):
     return model, ddp, opt
 
 
-def measure(model, ddp, opt, coords, feats, labels, dtype, steps, warmup, ctx, clog, world, want_roofline, base=0):
-    """`warmup` untimed steps (the last but one is the fully instrumented DISCOVERY step when a ConvLog is given), then
-    exactly `steps` timed steps bracketed by barrier + synchronize on both sides -> dict(dt, loss, disc, step_ms, phases)"""
+def _settled(ms):
+    """warm-up verdict from the per-step compute-stream times of the steps since the last synchronisation: the last two agree
+    within 3 % and neither is more than 5 % above the fastest step seen so far"""
+    if len(ms) < 3:
+        return False
+    a, b = ms[-2], ms[-1]
+    return abs(a - b) <= 0.03 * min(a, b) and max(a, b) <= 1.05 * min(ms[1:])
+
+
+def step_stats(ms):
+    """median / p90 / min / max of the timed steps' compute-stream durations (the headline `value` is the wall-clock mean over
+    exactly K steps, as the contract says; these say whether that mean carries a transient)"""
+    v = sorted(ms)
+    n = len(v)
+    if not n:
+        return None
+    med = v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+    return {"median": med, "p90": v[min(n - 1, int(0.9 * n))], "min": v[0], "max": v[-1]}
+
+
+def measure(model, ddp, opt, coords, feats, labels, dtype, steps, warmup, ctx, clog, world, want_roofline, base=0, settle=12):
+    """`warmup` untimed plain steps, then -- still untimed -- up to `settle` more in rounds of three until two consecutive steps
+    agree within 3 % (a fresh box pays for allocator growth, code-object loading and clock ramps in its first steps: round 5's
+    driver run had six 35 - 56 ms steps inside the timed region); then exactly `steps` timed steps bracketed by barrier +
+    synchronize on both sides.  The fully instrumented DISCOVERY step and the SAMPLING steps of the roofline run AFTER the timed
+    region: nothing before or inside it is bracketed, enqueued call by call or allocated differently from production.
+    -> dict(dt, loss, disc, step_ms, phases, warmup_ms, warmup_extra)"""
     disc = None
     if clog is not None:
         clog.rows, clog.mode, clog.only_key = [], None, None
-    for i in range(warmup):   # un-synchronised, like the timed loop: allocator pools reach their pipelined steady state
-        if i == max(0, warmup - 2) and want_roofline:
-            # DISCOVERY step (inside the warm-up, every rank runs it): every conv launch is bracketed by HIP events to rank
-            # the launch shapes and to evaluate the byte model on the real maps; this stretches the step, so its
-            # durations are only used to pick the dominant shape
-            if clog is not None:
-                clog.mode = "all"
-            train_step(model, ddp, opt, coords, feats, labels, dtype, base + i, ctx=ctx)
-            if clog is not None:
-                fam, wg, top = clog.summarize()
-                disc = dict(fam=fam, wg=wg, top=top, rows=list(clog.rows))
-                clog.rows = []
-                clog.mode = None                # the timed steps are the pure production path: nothing bracketed, no block enqueued call by call
-        else:
-            train_step(model, ddp, opt, coords, feats, labels, dtype, base + i, ctx=ctx)
-    torch.cuda.synchronize()
-    if clog is not None:
-        clog.rows = []
+
+    def plain(n, first):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        ev[0].record()
+        for i in range(n):
+            train_step(model, ddp, opt, coords, feats, labels, dtype, first + i, ctx=ctx)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        return [ev[i].elapsed_time(ev[i + 1]) for i in range(n)]
+
+    warm_ms = plain(warmup, base) if warmup > 0 else []
+    seen, extra = list(warm_ms), 0
+    while settle > 0 and extra < settle and warmup > 0:
+        ok = _settled(seen)
+        if world > 1:      # every rank runs the same number of steps (the steps contain collectives)
+            flag = torch.tensor([0.0 if ok else 1.0], device=coords.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            ok = flag.item() == 0.0
+        if ok:
+            break
+        more = plain(3, base + warmup + extra)
+        warm_ms += more
+        seen = seen + more
+        extra += 3
     if ddp.timing is not None:
         ddp.timing_summary(1)                   # drop the warm-up's collective events
     del _PHASES[:]
-    log("warmup done (%d steps)" % warmup)
+    log("warmup done (%d + %d steps): %s ms" % (warmup, extra, " ".join("%.1f" % m for m in warm_ms)))
+    first = base + warmup + extra
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -463,26 +534,41 @@ def measure(model, ddp, opt, coords, feats, labels, dtype, steps, warmup, ctx, c
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     marks[0].record()
     for i in range(steps):
-        loss = train_step(model, ddp, opt, coords, feats, labels, dtype, base + warmup + i, ctx=ctx)
+        loss = train_step(model, ddp, opt, coords, feats, labels, dtype, first + i, ctx=ctx)
         marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out = {"dt": dt, "loss": loss, "disc": disc, "phases": phase_summary(steps, origin=(marks[0], t0)),
-           "step_ms": [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]}
-    if clog is not None and disc is not None:
-        # SAMPLING pass, after the timed region (advisor, round 4: the headline must not be measured on an instrumented path): a few
-        # more steps in which only the dominant shape's launches are bracketed by HIP events on their stream -- its residual blocks
-        # are enqueued call by call for that (same launches, bit-identical), everything else runs as in the timed steps
-        clog.rows, clog.mode, clog.only_key = [], "only", disc["top"][0][0]
+    out = {"dt": dt, "loss": loss, "disc": None, "phases": phase_summary(steps, origin=(marks[0], t0)),
+           "step_ms": [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)], "warmup_ms": warm_ms, "warmup_extra": extra}
+    if ddp.timing is not None:
+        out["ddp"] = ddp.timing_summary(steps)
+    if want_roofline:
+        # DISCOVERY step (every rank runs it: it contains the step's collectives): every conv launch is bracketed by HIP events to
+        # rank the launch shapes and to evaluate the byte model on the real maps; this stretches the step, so its durations are
+        # only used to pick the dominant shape
+        if clog is not None:
+            clog.rows, clog.mode = [], "all"
+        train_step(model, ddp, opt, coords, feats, labels, dtype, first + steps, ctx=ctx)
+        if clog is not None:
+            fam, wg, top = clog.summarize()
+            disc = dict(fam=fam, wg=wg, top=top, rows=list(clog.rows))
+            # SAMPLING pass: a few more steps in which only the dominant shape's launches are bracketed by HIP events on their
+            # stream -- its residual blocks are enqueued call by call for that (same launches, bit-identical), everything else
+            # runs as in the timed steps
+            clog.rows, clog.mode, clog.only_key = [], "only", top[0][0]
         n_samp = max(2, min(steps, 6))
         for i in range(n_samp):
-            train_step(model, ddp, opt, coords, feats, labels, dtype, base + warmup + steps + i, ctx=ctx)
+            train_step(model, ddp, opt, coords, feats, labels, dtype, first + steps + 1 + i, ctx=ctx)
         torch.cuda.synchronize()
-        clog.mode = None
+        if clog is not None:
+            clog.mode = None
+        out["disc"] = disc
         out["sample_steps"] = n_samp
+        if ddp.timing is not None:
+            ddp.timing_summary(1)
         del _PHASES[:]
     return out
 
@@ -509,11 +595,18 @@ def roofline_report(clog, disc, dtype_name, workload, steps, ms_per_step, n_vox,
     traffic, traffic_src = traffic_pair
     fam_ach = fam["bytes"] / (fam["ms"] * 1e-3) if fam["ms"] > 0 else 0.0
     mfma_peak = 2.5e15 if dtype_name == "bf16" else 157.3e12
-    return {
-        "bound": "hbm",
+    # which roof bounds the dominant launch: its arithmetic intensity on the algorithmic bytes against the ridge point of the dtype
+    # (2.5 PF / 8 TB/s = 312 flop/B for bf16); `achieved / peak / unit / frac` are quoted on THAT roof, both fractions stay in the object
+    ai = flop / alg_bytes if alg_bytes else 0.0
+    mfma_bound = ai > mfma_peak / HBM_PEAK
+    tfl = flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    head = ({"bound": "mfma", "achieved": tfl, "peak": mfma_peak / 1e12, "unit": "TFLOP/s", "frac": tfl * 1e12 / mfma_peak}
+            if mfma_bound else
+            {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK})
+    head.update({
+        "arithmetic_intensity_flop_per_byte": ai, "hbm_GBps_on_alg_bytes": achieved / 1e9, "hbm_frac": achieved / HBM_PEAK,
         "kernel": ("k_conv_wide (2-D blocked wide-channel sparse conv forward/dgrad)" if "512->" in dom_key or "->512" in dom_key
                    else "k_conv_gather (sparse-conv forward/dgrad implicit GEMM)") + ", dominant launch shape: " + dom_key,
-        "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
         "traffic": traffic, "traffic_source": traffic_src,
         # launches of this shape in ONE step (forward + dgrad launches; the 3^3 96->96 shape of Res16UNet34C: 4 forward + 5
         # backward ... counted from the discovery step, the same number DESIGN.md quotes)
@@ -528,8 +621,8 @@ def roofline_report(clog, disc, dtype_name, workload, steps, ms_per_step, n_vox,
                     "launches, bit-identical -- so that Python can bracket them).  The timed steps themselves carry no "
                     "instrumentation" % (len(samp_ms), sample_steps, steps),
         "discovery_step": {
-            "note": "one fully instrumented warm-up step (every conv launch bracketed: the step is stretched, durations "
-                    "rank the shapes and feed the byte model only)",
+            "note": "one fully instrumented step run AFTER the timed region (every conv launch bracketed: the step is stretched, "
+                    "durations rank the shapes and feed the byte model only)",
             "family": {"kernel": "k_conv_gather, all %d launches of the step" % fam["n"], "achieved": fam_ach / 1e9,
                        "frac": fam_ach / HBM_PEAK, "total_ms": fam["ms"], "avg_launch_ms": fam["ms"] / max(fam["n"], 1)},
             "wgrad": {"kernel": "k_wgrad_ps / k_wgrad_bf16 + reduce, all %d launches (side stream)" % wg["n"],
@@ -540,7 +633,8 @@ def roofline_report(clog, disc, dtype_name, workload, steps, ms_per_step, n_vox,
                            for k, g in top[:6]]},
         "step": {"b_alg_bytes": b_alg_step, "b_alg_per_voxel": b_alg_step / n_vox,
                  "frac_of_hbm_peak": b_alg_step / (ms_per_step * 1e-3) / HBM_PEAK},
-    }
+    })
+    return head
 
 
 def secondary_block(workload, model_name, dtype, coords, feats, labels, device, args, clog, steps, warmup, note):
@@ -552,7 +646,7 @@ def secondary_block(workload, model_name, dtype, coords, feats, labels, device, 
     n_vox = int(coords.shape[0])
     ms = res["dt"] / steps * 1e3
     dname = "bf16" if dtype == torch.bfloat16 else "fp32"
-    out = {"workload": workload_text("insseg" if workload.startswith("insseg") and not workload.endswith("frozen") else workload, model_name),
+    out = {"workload": workload_text("insseg" if workload == "insseg" else workload, model_name),
            "note": note, "dtype": dname, "steps": steps, "warmup": warmup, "voxels_per_step": n_vox, "ms_per_step": ms,
            "value": n_vox * steps / res["dt"], "unit": "voxels/s", "final_loss": float(res["loss"].item()), "phases": res["phases"]}
     if clog is not None and res["disc"] is not None:
@@ -602,7 +696,7 @@ def dp_path_block(coords, feats, labels, device, args, dtype, steps=8, warmup=3)
                        "gradient all-reduce) on one GPU with RCCL and a world of ONE rank: every collective is a real RCCL launch, "
                        "only the wire time is missing",
                "ms_per_step": res["dt"] / steps * 1e3, "value": n_vox * steps / res["dt"], "unit": "voxels/s", "steps": steps,
-               "phases": res["phases"], "ddp": ddp.timing_summary(steps), "backend": dist.get_backend(), "allreduce": args.allreduce,
+               "phases": res["phases"], "ddp": res.get("ddp"), "backend": dist.get_backend(), "allreduce": args.allreduce,
                "syncbn_collectives_issued_by": _syncbn_issuer()}
         del model, ddp, opt, res
     finally:
@@ -614,6 +708,98 @@ def dp_path_block(coords, feats, labels, device, args, dtype, steps=8, warmup=3)
     gc.collect()
     torch.cuda.empty_cache()
     return out
+
+
+LINE_LIMIT = 4096      # bytes of the ONE stdout line (round 5's 21 KB line was not parsed by the driver)
+
+
+def _r(x, nd=4):
+    """floats rounded to `nd` significant digits for the stdout line (the details file keeps full precision)"""
+    if isinstance(x, float):
+        return float("%.*g" % (nd, x))
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def headline(full, details_path):
+    """The ONE stdout line: the driver's contract keys + `roofline` + `cpu_baseline` + one number per secondary workload, under
+    LINE_LIMIT bytes.  Everything else (phases, per-rank records, the discovery step, notes) is in the details file and on stderr."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    line = {k: full[k] for k in keep}
+    line["value"] = _r(full["value"], 7)
+    line["ms_per_step"] = _r(full["ms_per_step"], 5)
+    cfg = full["config"]
+    line["config"] = {k: cfg[k] for k in ("workload", "scenes_per_gpu", "voxels_per_gpu", "global_voxels", "parallelism", "sync_bn",
+                                          "allreduce", "storage") if k in cfg}
+    sm = full.get("step_ms")
+    if sm:
+        line["step_ms"] = _r({k: sm[k] for k in ("median", "p90", "min", "max")})
+        line["value_at_median"] = _r(cfg["global_voxels"] / (sm["median"] * 1e-3), 5) if full["n_gpus"] == 1 else None
+    line["warmup_extra"] = full.get("warmup_extra")
+    rf = full.get("roofline")
+    if rf:
+        line["roofline"] = _r({"bound": rf["bound"], "kernel": rf["kernel"], "achieved": rf["achieved"], "peak": rf["peak"],
+                               "unit": rf["unit"], "frac": rf["frac"], "traffic": rf["traffic"],
+                               "alg_bytes_per_launch": rf["alg_bytes_per_launch"], "avg_launch_ms": rf["avg_launch_ms"],
+                               "launches_sampled": rf["launches_sampled"], "hbm_frac": rf["hbm_frac"],
+                               "mfma_frac": rf["mfma_frac_of_peak_on_real_pairs"],
+                               "step_b_alg_bytes": rf["step"]["b_alg_bytes"], "step_frac": rf["step"]["frac_of_hbm_peak"]})
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": cb["sample"][:200]}
+    sec = {}
+    for key, path in (("single_scene_ms", ("single_scene", "ms_per_step")), ("balanced_ce_ms", ("balanced", "ms_per_step")),
+                      ("call_by_call_ms", ("reference_calls", "call_by_call_ms_per_step")), ("fp32_ms", ("fp32", "ms_per_step")),
+                      ("fp32_step_frac", ("fp32", "roofline", "step", "frac_of_hbm_peak")),
+                      ("fp32_exact_mfma_ms", ("fp32", "exact_mfma", "ms_per_step")), ("clip_ms", ("clip", "ms_per_step")),
+                      ("clip_roofline_bound", ("clip", "roofline", "bound")), ("clip_roofline_frac", ("clip", "roofline", "frac")),
+                      ("insseg_ms", ("insseg", "full", "ms_per_step")), ("insseg_frozen_ms", ("insseg", "frozen_trunk", "ms_per_step")),
+                      ("dp_path_world1_ms", ("dp_path_world1", "ms_per_step"))):
+        v = full
+        for k in path:
+            v = v.get(k) if isinstance(v, dict) else None
+            if v is None:
+                break
+        if v is not None:
+            sec[key] = _r(v)
+    if sec:
+        line["secondary"] = sec
+    if full["n_gpus"] > 1:
+        pr = full.get("per_rank") or []
+        line["ranks"] = _r({"ms_per_step": [r["ms_per_step"] for r in pr],
+                            "allreduce_exposed_wait_ms": [(r.get("ddp") or {}).get("allreduce_exposed_wait_ms") for r in pr],
+                            "syncbn_collective_ms": [(r.get("ddp") or {}).get("syncbn_collective_ms") for r in pr],
+                            "comm_create_s": full["rccl_ranks"].get("comm_create_s"), "backend": full["rccl_ranks"].get("backend")})
+    line["details"] = details_path
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:      # never lose the record to its decorations again
+        for k in ("secondary", "ranks", "step_ms", "value_at_median"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) < LINE_LIMIT:
+                break
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
+def write_details(full):
+    """every secondary block of the run -> gpurun_out/bench_full.json (merged back by gpurun; the committed copy of the round's
+    final run is profiles/rNN_bench_full.json) and, as one line, stderr.  Returns the path written (None if the tree is read-only)."""
+    text = json.dumps(full)
+    print("[bench details] " + text, file=sys.stderr, flush=True)
+    path = os.environ.get("LGS_BENCH_DETAILS") or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(text + "\n")
+        return os.path.relpath(path, ROOT)
+    except OSError:
+        return None
 
 
 def _free_port():
@@ -714,9 +900,11 @@ def main():
         os.environ.setdefault("LGS_BN_FUSED", "0")      # initial value of the engine's BN_FUSED knob (csrc/lgs_tuning.hip)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    comm_create_s = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL / tensor sharing)
+        t_pg = time.perf_counter()
         if args.backend == "nccl":
             try:
                 dist.init_process_group("nccl", device_id=device)
@@ -724,6 +912,12 @@ def main():
                 dist.init_process_group("nccl")
         else:
             dist.init_process_group(args.backend)
+        # the first collective brings the communicator up (RCCL builds its rings / trees lazily): time it apart from the steps
+        warm = torch.zeros(1, device=device)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
+        comm_create_s = time.perf_counter() - t_pg
+        log("process group + first collective: %.2f s" % comm_create_s)
     if args.dp_world1:
         if world != 1:
             raise RuntimeError("--dp-world1 is a single-GPU diagnostic (N > 1 runs that path anyway)")
@@ -804,11 +998,14 @@ def main():
                    "timed_steps_instrumented": False},
         "final_loss": final_loss,
         "phases": res["phases"],
+        "step_ms": dict(step_stats(res["step_ms"]), all=res["step_ms"]),
+        "warmup_ms": res["warmup_ms"], "warmup_extra": res["warmup_extra"],
     }
     # one record per rank (also at N = 1, so that the schema of the line does not depend on N): where a step spends its time
     # (compute-stream phases, the part of the bucket all-reduces that backward did not hide, the compute-stream stalls inside
     # SyncBN's small collectives)
-    mine = {"rank": rank, "phases": res["phases"], "ddp": ddp.timing_summary(args.steps), "ms_per_step": res["dt"] / args.steps * 1e3}
+    mine = {"rank": rank, "phases": res["phases"], "ddp": res.get("ddp"), "ms_per_step": res["dt"] / args.steps * 1e3,
+            "step_ms": step_stats(res["step_ms"]), "warmup_extra": res["warmup_extra"]}
     if world > 1:
         allr = [None] * world
         dist.all_gather_object(allr, mine)
@@ -846,6 +1043,13 @@ def main():
         out["reference_calls"] = {"fused_ms_per_step": ms_per_step, "call_by_call_ms_per_step": ub["ms_per_step"],
                                   "call_by_call": ub, "deferred_stats": dict(_deferred.STATS)}
         log("call-by-call block done")
+        out["balanced"] = secondary_block("ce_balanced", "Res16UNet34C", torch.bfloat16, coords, feats, labels, device, args, None, steps=8,
+                                          warmup=3, note="the step scripts/train_models.sh:37 runs: CrossEntropyLoss(reduction='none') + "
+                                                         "sample_categories_for_balancing with the configured ratios (-1 / -1), no host sync")
+        out["balanced"]["sampled"] = secondary_block("ce_balanced_sampled", "Res16UNet34C", torch.bfloat16, coords, feats, labels, device, args,
+                                                     None, steps=8, warmup=3, note="same with head / common ratios 0.5: a draw without "
+                                                                                   "replacement per class on the device")
+        log("balanced block done")
         # the other BASELINE configurations, each a few timed steps on the same 8-scene batch, so that their numbers sit in
         # the driver's record next to the headline instead of in builder-only files
         del model, ddp, opt
@@ -874,11 +1078,17 @@ def main():
         out["dp_path_world1"] = dp_path_block(coords, feats, labels, device, args, dtype)
         log("dp-path block done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(model_name=args.model, voxels=args.voxels)
+        out["cpu_baseline"] = cpu_baseline(model_name=args.model, voxels=args.voxels, loss="clip" if args.workload == "clip" else "ce")
         log("cpu baseline done")
+        if secondary:
+            out["cpu_baseline_other_configs"] = cpu_baselines_other_configs()
+            log("cpu baselines of configs[0] / configs[2] done")
+    out["rccl_ranks"]["comm_create_s"] = comm_create_s
     if rank == 0:
+        details = write_details(out)
+        line = headline(out, details)
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        os.write(json_fd, (line + "\n").encode())
     if world > 1:
         dist.barrier()
     if dist.is_initialized():

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LGS_ABI_VERSION 12
+#define LGS_ABI_VERSION 13
 
 enum lgs_dtype { LGS_F32 = 0, LGS_BF16 = 1 };
 
@@ -410,6 +410,14 @@ int lgs_cluster(const float *xyz, const int32_t *batch_idx, const int32_t *seman
  * wrapper asks for the loss in the forward pass and for the gradient in the backward pass. */
 int lgs_ce_forward_backward(const void *logits, int64_t n, int c, const int64_t *labels, int64_t ignore_index,
                             const float *scale, float *loss_rows, void *dlogits, int dtype, void *stream);
+/* The same pass with a per-row gradient factor (ABI 13): dlogits[n,:] = (softmax - onehot) * (*scale) * row_scale[n].
+ * This is the backward of nn.CrossEntropyLoss(reduction='none') -- what the fine-tune step runs when
+ * --balanced_category_sampling True (/root/reference/scripts/train_models.sh:37, pl_BaselineTrainer.py:94,350-356):
+ * loss_rows IS the reduction='none' output, row_scale the upstream gradient of sample_categories_for_balancing's masked mean
+ * (lib/losses/utils.py:74-77: mask / N).  row_scale may be NULL (= lgs_ce_forward_backward). */
+int lgs_ce_forward_backward_rows(const void *logits, int64_t n, int c, const int64_t *labels, int64_t ignore_index,
+                                 const float *scale, const float *row_scale, float *loss_rows, void *dlogits, int dtype,
+                                 void *stream);
 /* number of rows the loss above counts (label != ignore_index and inside [0, c)) -> *count (DEVICE int32, overwritten): the
  * denominator of the mean reduction (pl_BaselineTrainer.py:350, nn.CrossEntropyLoss(ignore_index) 'mean') without a host
  * sync and without a chain of elementwise / reduction launches over the label tensor. */

@@ -39,7 +39,8 @@ __device__ inline void st_elem(bf16_t *p, float v) { *p = f32_to_bf16(v); }
 template <typename T>
 __global__ __launch_bounds__(256) void k_ce_fwd_bwd(const T *__restrict__ logits, int64_t n, int c, const int64_t *__restrict__ labels,
                                                     int64_t ignore_index, const float *__restrict__ scale_ptr,
-                                                    float *__restrict__ loss_rows, T *__restrict__ dlogits) {
+                                                    const float *__restrict__ row_scale, float *__restrict__ loss_rows,
+                                                    T *__restrict__ dlogits) {
   constexpr int W = LVec<T>::W;
   const int lane = threadIdx.x & 31;  // half-wave per row
   const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
@@ -87,7 +88,8 @@ __global__ __launch_bounds__(256) void k_ce_fwd_bwd(const T *__restrict__ logits
   const float lse = mx + __logf(se);
   if (loss_rows && lane == 0) loss_rows[row] = ignored ? 0.f : (lse - xl);
   if (!dlogits) return;   // loss only (the gradient is produced by a second call in the backward pass)
-  const float scale = ignored ? 0.f : *scale_ptr;
+  // row_scale: per-row upstream gradient of a reduction='none' loss (balanced category sampling: mask / N), times *scale_ptr
+  const float scale = ignored ? 0.f : (row_scale ? *scale_ptr * row_scale[row] : *scale_ptr);
   const float inv = scale / se;
 #pragma unroll
   for (int q = 0; q < kMaxChunks; ++q) {
@@ -137,8 +139,9 @@ __global__ __launch_bounds__(256) void k_ce_count_valid(const int64_t *__restric
 
 using namespace lgs;
 
-extern "C" int lgs_ce_forward_backward(const void *logits, int64_t n, int c, const int64_t *labels, int64_t ignore_index,
-                                       const float *scale, float *loss_rows, void *dlogits, int dtype, void *stream) {
+extern "C" int lgs_ce_forward_backward_rows(const void *logits, int64_t n, int c, const int64_t *labels, int64_t ignore_index,
+                                            const float *scale, const float *row_scale, float *loss_rows, void *dlogits, int dtype,
+                                            void *stream) {
   LGS_REQUIRE(logits && labels && scale && (loss_rows || dlogits), "lgs_ce_forward_backward: null argument");
   const int W = dtype == LGS_BF16 ? 8 : 4;
   LGS_REQUIRE(c >= 1 && (c + W - 1) / W <= 32 * kMaxChunks, "lgs_ce_forward_backward: more classes than one half-wave holds (512 fp32 / 1024 bf16)");
@@ -146,15 +149,20 @@ extern "C" int lgs_ce_forward_backward(const void *logits, int64_t n, int c, con
   hipStream_t s = (hipStream_t)stream;
   const unsigned blocks = (unsigned)((n * 32 + 255) / 256);
   if (dtype == LGS_F32)
-    LGS_KLAUNCH((k_ce_fwd_bwd<float>), blocks, 256, 0, s, (const float *)logits, n, c, labels, ignore_index, scale, loss_rows,
+    LGS_KLAUNCH((k_ce_fwd_bwd<float>), blocks, 256, 0, s, (const float *)logits, n, c, labels, ignore_index, scale, row_scale, loss_rows,
                        (float *)dlogits);
   else if (dtype == LGS_BF16)
-    LGS_KLAUNCH((k_ce_fwd_bwd<bf16_t>), blocks, 256, 0, s, (const bf16_t *)logits, n, c, labels, ignore_index, scale, loss_rows,
+    LGS_KLAUNCH((k_ce_fwd_bwd<bf16_t>), blocks, 256, 0, s, (const bf16_t *)logits, n, c, labels, ignore_index, scale, row_scale, loss_rows,
                        (bf16_t *)dlogits);
   else
     LGS_REQUIRE(false, "lgs_ce_forward_backward: unknown dtype");
   LGS_HIP(hipGetLastError());
   return 0;
+}
+
+int lgs_ce_forward_backward(const void *logits, int64_t n, int c, const int64_t *labels, int64_t ignore_index,
+                            const float *scale, float *loss_rows, void *dlogits, int dtype, void *stream) {
+  return lgs_ce_forward_backward_rows(logits, n, c, labels, ignore_index, scale, nullptr, loss_rows, dlogits, dtype, stream);
 }
 
 int lgs_ce_count_valid(const int64_t *labels, int64_t n, int c, int64_t ignore_index, int32_t *count, void *stream) {

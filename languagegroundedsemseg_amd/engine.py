@@ -10,7 +10,7 @@ import os
 from . import build as _build
 
 LGS_F32, LGS_BF16 = 0, 1
-ABI_VERSION = 12     # LGS_ABI_VERSION of include/lgs_engine.h
+ABI_VERSION = 13     # LGS_ABI_VERSION of include/lgs_engine.h
 
 
 class PackDesc(ctypes.Structure):
@@ -92,7 +92,7 @@ EXPORTS = [
     "lgs_clip_similarity", "lgs_clip_workspace_bytes",
     "lgs_clip_loss_workspace_bytes", "lgs_clip_loss_forward", "lgs_clip_loss_backward",
     "lgs_clip_anchor_grad_workspace_bytes", "lgs_clip_loss_backward_anchors",
-    "lgs_ce_forward_backward",
+    "lgs_ce_forward_backward", "lgs_ce_forward_backward_rows",
     "lgs_ce_count_valid",
     "lgs_comm_unique_id", "lgs_comm_create", "lgs_comm_create_ipc", "lgs_comm_ipc_open", "lgs_comm_destroy", "lgs_comm_world", "lgs_bn_sync_workspace_bytes",
     "lgs_bn_forward_sync", "lgs_bn_backward_sync",
@@ -159,6 +159,7 @@ def lib():
         "lgs_bn_backward_apply": [vp, vp, vp, i64, ci, vp, vp, vp, vp, cf, vp, ci, vp, vp, ci, i64, i64, vp],
         "lgs_clip_similarity": [vp, i64, ci, vp, ci, vp, vp, ci, vp, vp],
         "lgs_ce_forward_backward": [vp, i64, ci, vp, i64, vp, vp, vp, ci, vp],
+        "lgs_ce_forward_backward_rows": [vp, i64, ci, vp, i64, vp, vp, vp, vp, ci, vp],
         "lgs_ce_count_valid": [vp, i64, ci, i64, vp, vp],
         "lgs_comm_unique_id": [vp],
         "lgs_comm_create": [vp, ci, ci, ci, ctypes.POINTER(vp)],
@@ -209,8 +210,13 @@ def check(rc):
 
 
 # ---- tuning table / dispatch counters (include/lgs_engine.h, csrc/lgs_tuning.hip)
+TUNING_EPOCH = 0      # bumped by every tuning_set(): host-side caches of knob-dependent answers (pack descriptors) key on it
+
+
 def tuning_set(name, value):
+    global TUNING_EPOCH
     check(lib().lgs_tuning_set(name.encode(), int(value)))
+    TUNING_EPOCH += 1
 
 
 def tuning_get(name):

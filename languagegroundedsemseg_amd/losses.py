@@ -32,13 +32,37 @@ class _FusedCE(torch.autograd.Function):
         return dlogits, None, None
 
 
-def fused_cross_entropy(logits, labels, ignore_index=-1):
-    """mean softmax cross-entropy over the non-ignored rows; logits may be bf16 or fp32, any class count the kernel's
-    half-wave holds (512 fp32 / 1024 bf16); wider heads go through torch's device op."""
+class _FusedCERows(torch.autograd.Function):
+    """reduction='none': forward = the per-row losses, backward = the same kernel with the upstream per-row gradient as its
+    row factor (lgs_ce_forward_backward_rows) -- no [N, C] softmax is kept between the two."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        ctx.save_for_backward(logits, labels)
+        ctx.ignore_index = ignore_index
+        return get_backend().cross_entropy_rows(logits, labels, ignore_index)
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels = ctx.saved_tensors
+        return get_backend().cross_entropy_rows(logits, labels, ctx.ignore_index, row_grad=g), None, None
+
+
+def fused_cross_entropy(logits, labels, ignore_index=-1, reduction="mean"):
+    """softmax cross-entropy; logits may be bf16 or fp32, any class count the kernel's half-wave holds (512 fp32 / 1024 bf16);
+    wider heads go through torch's device op.
+    reduction='mean': over the non-ignored rows (pl_BaselineTrainer.py:350 with balanced_category_sampling off);
+    reduction='none': per-row losses [N], 0 for ignored rows -- what `self.criterion` returns when the fine-tune script's
+    --balanced_category_sampling True is on (scripts/train_models.sh:37, pl_BaselineTrainer.py:94), the input of
+    sample_categories_for_balancing."""
+    if reduction not in ("mean", "none"):
+        raise ValueError("fused_cross_entropy: reduction must be 'mean' or 'none'")
     backend = get_backend()
     if hasattr(backend, "cross_entropy") and logits.shape[1] <= (1024 if logits.dtype == torch.bfloat16 else 512):
+        if reduction == "none":
+            return _FusedCERows.apply(logits, labels, ignore_index)
         return _FusedCE.apply(logits, labels, ignore_index)
-    return torch.nn.functional.cross_entropy(logits.float(), labels, ignore_index=ignore_index)
+    return torch.nn.functional.cross_entropy(logits.float(), labels, ignore_index=ignore_index, reduction=reduction)
 
 
 class _ClipSimilarity(torch.autograd.Function):
@@ -294,8 +318,10 @@ class ReferenceContrastiveLanguageLoss(ContrastiveLanguageLoss):
         (`random.random() < p`, then `np.random.randint(0, 8)`, :62-70).  Here ONE independent draw per possible (category,
         attribute-slot) pair, on the device, no host loop: -> (augment? [L * A] bool, new attribute [L * A] int64) for A slots."""
         A = self.attributes.shape[0] + 1                                   # slot 0 = the raw category, 1..8 = attributes
-        u = torch.rand(self.num_labels * A, generator=generator, device=device)
-        k = torch.randint(0, self.attributes.shape[0], (self.num_labels * A,), generator=generator, device=device)
+        # draw where the generator lives (a CPU generator cannot feed a device op), then move: 2 x 1800 numbers
+        gdev = generator.device if generator is not None else device
+        u = torch.rand(self.num_labels * A, generator=generator, device=gdev).to(device)
+        k = torch.randint(0, self.attributes.shape[0], (self.num_labels * A,), generator=generator, device=gdev).to(device)
         return u < self.augment_probability, k
 
     def latent_augmentation(self, features, labels, plan=None, generator=None):
@@ -315,7 +341,8 @@ class ReferenceContrastiveLanguageLoss(ContrastiveLanguageLoss):
             in_aug[cats.clamp(0, self.num_labels)] = True
         valid = (cat != self.ignore_label) & (cat >= 0) & (cat < self.num_labels) & (att >= 0) & (att < A)
         pair = torch.where(valid, cat * A + att, torch.zeros_like(cat))
-        do = valid & in_aug[torch.where(valid, cat, torch.full_like(cat, self.num_labels))] & on[pair]
+        in_aug_row = valid & in_aug[torch.where(valid, cat, torch.full_like(cat, self.num_labels))]
+        do = in_aug_row & on[pair]
         k = new_attr[pair]
         idx = do.nonzero().squeeze(1)                                      # (one host sync; the reference loops over classes)
         if self.projection_model.attr_linears[0].weight.device != dev:
@@ -324,7 +351,9 @@ class ReferenceContrastiveLanguageLoss(ContrastiveLanguageLoss):
             proj = self.projection_model.project(features[idx].float(), k[idx])
             features.index_copy_(0, idx, proj.to(features.dtype))
         labels[:, 1] = torch.where(do, k, att).to(labels.dtype)
-        return features, labels, torch.where(do, k + 1, att)
+        # a target of an augment category whose draw said "no" keeps its features and labels, but the reference then sets ut[1] =
+        # attribute_id = 0 (:70,:163-165): its positive anchor is slot 0, the raw category, whatever attribute it carried
+        return features, labels, torch.where(do, k + 1, torch.where(in_aug_row, torch.zeros_like(att), att))
 
     def forward(self, features, labels, anchor_feats, preds=None, neg_indices=None, aug_plan=None):
         if labels.dim() == 2:                                        # (category, attribute) targets, :149-181
@@ -408,36 +437,55 @@ class ReferenceContrastiveLanguageCELoss(ReferenceContrastiveLanguageLoss):
 
 
 def sample_categories_for_balancing(loss, targets, frequency_organized_cats, head_ratio, common_ratio, ignore_label=-1,
-                                    generator=None):
-    """lib/losses/utils.py:13-77 on the device, no host loop / np.random.choice / sync: per-point `loss` [N] is masked so
+                                    generator=None, split="tensors"):
+    """lib/losses/utils.py:13-77 on the device, no host loop / np.random.choice: per-point `loss` [N] is masked so
     that every HEAD class keeps round(head_ratio * count) of its points, every COMMON class round(common_ratio * count)
     (drawn without replacement), TAIL classes keep all; ratio <= 0 keeps everything (:41,:54).
     frequency_organized_cats: bool [num_labels, 3] (head, common, tail), lib/datasets/scannet.py:131-141.
-    -> (masked loss mean over ALL points, (head, common, tail per-point losses, detached), loss_items [N_valid, 3])."""
+    split="tensors" (the reference's return shape):
+        -> (masked loss mean over ALL points, (head, common, tail per-point losses, detached), loss_items [N_valid, 3]);
+        the three variable-length tensors and the row-filtered mask are boolean-index results, i.e. THREE + ONE device->host
+        syncs for their sizes, exactly what the reference's own `loss[loss_items[:, 0]]` costs.
+    split="stats" (the training step: no host sync at all):
+        -> (masked loss mean, stats [3, 2] = (sum of the per-point losses, number of points) of head / common / tail -- what the
+        trainer feeds its meters, `nanmean_t(split_losses[i])` = stats[i, 0] / stats[i, 1] and `.size(0)` = stats[i, 1]
+        (pl_BaselineTrainer.py:353-355) --, loss_items [N, 3] over ALL rows, False on ignored ones)."""
+    if split not in ("tensors", "stats"):
+        raise ValueError("split must be 'tensors' or 'stats'")
     dev = loss.device
     foc = frequency_organized_cats.to(dev).bool()
     valid = targets != ignore_label
     lab = targets.clamp_min(0).long()
     L = foc.shape[0]
     group = torch.where(foc[:, 0], 0, torch.where(foc[:, 1], 1, 2)).to(dev)     # anything not head/common is kept like tail (:58-62)
-    ratio_of_group = torch.tensor([head_ratio if head_ratio > 0 else 1.0, common_ratio if common_ratio > 0 else 1.0, 1.0],
-                                  device=dev, dtype=torch.float64)
+    # per-class keep ratio, built from host scalars with fills only (a torch.tensor([...]) would be a blocking host->device copy)
+    ratio = torch.ones(L, dtype=torch.float64, device=dev)
+    ratio.masked_fill_(group == 0, head_ratio if head_ratio > 0 else 1.0).masked_fill_(group == 1, common_ratio if common_ratio > 0 else 1.0)
     pg = group[lab]
     counts = torch.zeros(L, dtype=torch.long, device=dev).index_add_(0, lab, valid.long())
-    keep_n = torch.round(ratio_of_group[group] * counts.double()).long()         # python round == torch.round: half to even
-    # rank of every point inside its class by a random key = a uniform draw without replacement
-    u = torch.rand(loss.shape[0], device=dev, generator=generator)
-    key = lab.double() + u.double()
-    key = torch.where(valid, key, torch.full_like(key, float(L + 1)))
-    order = torch.argsort(key)
-    start = torch.cumsum(counts, 0) - counts                                     # first sorted position of every class
-    pos = torch.empty_like(order)
-    pos[order] = torch.arange(order.shape[0], device=dev)
-    rank_in_class = pos - start[lab]
-    point_mask = valid & (rank_in_class < keep_n[lab])
+    keep_n = torch.round(ratio * counts.double()).long()                         # python round == torch.round: half to even
+    if head_ratio <= 0 and common_ratio <= 0:
+        # the configured default (config.py:281-282: both ratios -1; scripts/train_models.sh sets neither): every class keeps all
+        # of its points (:45,:56,:60), nothing is drawn
+        point_mask = valid
+    else:
+        # rank of every point inside its class by a random key = a uniform draw without replacement
+        u = torch.rand(loss.shape[0], device=dev, generator=generator)
+        key = lab.double() + u.double()
+        key = torch.where(valid, key, torch.full_like(key, float(L + 1)))
+        order = torch.argsort(key)
+        start = torch.cumsum(counts, 0) - counts                                 # first sorted position of every class
+        pos = torch.empty_like(order)
+        pos[order] = torch.arange(order.shape[0], device=dev)
+        rank_in_class = pos - start[lab]
+        point_mask = valid & (rank_in_class < keep_n[lab])
     loss_items = torch.stack([valid & (pg == 0), valid & (pg == 1), valid & (pg == 2)], 1)
-    head, common, tail = (loss[loss_items[:, i]].detach() for i in range(3))
     masked = loss * point_mask.to(loss.dtype)
+    if split == "stats":
+        w = loss_items.to(torch.float32)                                          # [N, 3]
+        stats = torch.stack([w.t() @ loss.detach().float(), w.sum(0)], 1)         # [3, 2]: sums, counts
+        return masked.mean(), stats, loss_items
+    head, common, tail = (loss[loss_items[:, i]].detach() for i in range(3))
     return masked.mean(), (head, common, tail), loss_items[valid]
 
 

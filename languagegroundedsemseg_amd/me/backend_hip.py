@@ -183,8 +183,11 @@ class PackedWeights:
         """-> (packed buffer or None, pack_mode)"""
         if not self.enabled or cache is None:
             return None, 0
-        ck = (op, transposed, cin, cout, dt)
-        d = km._pdesc.get(ck)          # the layout of a launch shape on this map: asked once per map, layers share maps
+        # the layout of a launch shape on this map: asked once per map (layers share maps) and per state of the tuning table -- the
+        # layout depends on knobs (FP32_SPLIT: 6 instead of 4 bytes per element), and a descriptor cached across engine.tuning(...)
+        # would hand a buffer of the old size / a "valid" image of the old layout to the new kernel (advisor, round 5)
+        ck = (op, transposed, cin, cout, dt, engine.TUNING_EPOCH)
+        d = km._pdesc.get(ck)
         if d is None:
             d = engine.PackDesc()
             engine.check(engine.lib().lgs_conv_pack_desc(km.h, int(op), int(transposed), int(cin), int(cout), int(dt), ctypes.byref(d)))
@@ -972,3 +975,33 @@ class HipBackend:
                                                    _ptr(loss_rows), _ptr(dlogits), dt, _stream()))
         loss = loss_rows[:n].sum() * inv_valid if loss_rows is not None else None
         return loss, dlogits, inv_valid
+
+    def cross_entropy_rows(self, logits, labels, ignore_index, row_grad=None):
+        """nn.CrossEntropyLoss(reduction='none') (pl_BaselineTrainer.py:94 under balanced_category_sampling): row_grad=None ->
+        the per-row losses [N] (0 for ignored rows); row_grad [N] fp32 = the upstream gradient -> d(logits), one pass either way
+        (lgs_ce_forward_backward_rows).  No denominator: the caller's reduction owns it."""
+        _require_dev(logits, "logits")
+        L = engine.lib()
+        logits = logits.contiguous()
+        labels = labels.contiguous().to(torch.int64)
+        n, c = logits.shape
+        with _dev(logits.device):
+            one = self._one(logits.device)
+            if row_grad is None:
+                loss_rows = torch.empty(n, dtype=torch.float32, device=logits.device)
+                engine.check(L.lgs_ce_forward_backward_rows(_ptr(logits), n, c, _ptr(labels), int(ignore_index), _ptr(one), None,
+                                                            _ptr(loss_rows), None, _dtype_code(logits), _stream()))
+                return loss_rows
+            row_grad = row_grad.contiguous().to(torch.float32)
+            dlogits = torch.empty_like(logits)
+            engine.check(L.lgs_ce_forward_backward_rows(_ptr(logits), n, c, _ptr(labels), int(ignore_index), _ptr(one), _ptr(row_grad),
+                                                        None, _ptr(dlogits), _dtype_code(logits), _stream()))
+            return dlogits
+
+    def _one(self, device):
+        """a device-resident 1.0f (the kernels take their scalar factors from device memory)"""
+        cache = self.__dict__.setdefault("_one_cache", {})
+        t = cache.get(device.index)
+        if t is None:
+            t = cache[device.index] = torch.ones((), dtype=torch.float32, device=device)
+        return t

@@ -240,8 +240,9 @@ class BlockView:
         self.downsample, self.final_relu, self.cat_up = downsample, final_relu, cat_up
 
 
-_DEAD_MID = "this tensor was an intermediate of a residual block that ran as ONE fused node (me/block.py), so its value was " \
-            "never formed; set LGS_BLOCK_FUSED=0 (or LGS_DEFER=0) to run the block call by call and keep every intermediate"
+_DEAD_MID = "this tensor was an intermediate of a MinkowskiSyncBatchNorm residual block that ran as ONE fused node (me/block.py), so " \
+            "its value was never formed, and recomputing it would be a collective only this rank enters; set LGS_BLOCK_FUSED=0 (or " \
+            "LGS_DEFER=0) to run the block call by call and keep every intermediate"
 
 
 def _is3(op):
@@ -339,8 +340,25 @@ def try_block(q, i, n, final=True):
     out = n2.out
     if out is not None:
         out._F, out._op = y, None
-    dead = _d._Dead(_DEAD_MID)
+    # the intermediates were never formed.  A caller that kept one gets it recomputed on first read (deferred.LazyBlock); under
+    # MinkowskiSyncBatchNorm the recomputation would be a collective that only the reading rank enters, so there it raises
+    if _sync_group(blk.norm1)[0]:
+        mark = _d._Dead(_DEAD_MID)
+    else:
+        import weakref
+        steps = [(_d.CONV, c1.mod, c1.aux, -1, weakref.ref(c1.out) if c1.out is not None else _none),
+                 (_d.BN, n1.mod, True, 0, weakref.ref(n1.out) if n1.out is not None else _none),
+                 (_d.CONV, c2.mod, c2.aux, 1, weakref.ref(c2.out) if c2.out is not None else _none)]
+        if ds is not None:
+            cd, nd = q[i + 3], q[i + 4]
+            steps += [(_d.CONV, cd.mod, cd.aux, -1, weakref.ref(cd.out) if cd.out is not None else _none),
+                      (_d.BN, nd.mod, False, 3, weakref.ref(nd.out) if nd.out is not None else _none)]
+        mark = _d.LazyBlock(x, steps)
     for o in ops:
         if o is not n2 and o.out is not None:
-            o.out._op = dead
+            o.out._op = mark
     return took
+
+
+def _none():
+    return None

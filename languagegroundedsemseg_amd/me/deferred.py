@@ -24,7 +24,8 @@ residual block and direction (csrc/lgs_block.hip) -- so the ME surface RECORDS i
     records the next; reading `.F` (or shape / dtype / ...) of a pending tensor executes whatever is left (`flush`).
     LGS_DEFER_INCREMENTAL=0 keeps everything queued until such a read.
   * the executor looks at what is in front of it: [conv3, norm+relu, conv3, (conv1, norm,) norm+residual(+relu)] runs as the
-    whole-block autograd node (me/block.py: lgs_block_forward / lgs_block_backward); a norm whose only consumer is the
+    whole-block autograd node (me/block.py: lgs_block_forward / lgs_block_backward; an intermediate of such a block that the
+    caller kept is recomputed when it is read: class LazyBlock); a norm whose only consumer is the
     `me.cat(up, skip)` recorded right behind it writes straight into the left-hand columns of the concat buffer, the skip half is
     copied in beside it once, and the cat returns the buffer (one copy of the narrow skip half instead of torch.cat's copy of both;
     its backward hands out column slices, read in place by the norms' row-stride support); everything else runs module by
@@ -97,6 +98,54 @@ class _Dead:
 
     def __init__(self, why, cause=None):
         self.why, self.cause = why, cause
+
+
+class LazyBlock:
+    """`_op` shared by the intermediates of a residual block that ran as ONE node (me/block.py): conv1's output, norm1's
+    (rectified in place), conv2's, and the downsample branch's two.  Their values were never formed -- the reference's own block
+    rebinds `out` and never looks at them (resnet_block.py:41-57) -- but a caller that KEPT one (a custom block returning norm1's
+    output, a debugger, a feature probe) reads what MinkowskiEngine would have given it: the first read re-runs the block's
+    recorded calls module by module from the block's input, up to the tensor asked for, with autograd on (a second branch from the
+    same input and weights: its gradient adds to the fused node's, as the chain rule has it) and the norms' running statistics
+    put back afterwards (the fused node already counted this batch).  Holds the block input strongly and the intermediates
+    weakly, so a block nobody looks into keeps nothing alive once its wrappers are rebound.
+    steps: [(kind, module, resolved kernel map | relu flag, index of the input step or -1 for the block input, weakref(out))]"""
+    kind = -2
+    __slots__ = ("x", "steps")
+
+    def __init__(self, x, steps):
+        self.x, self.steps = x, steps
+
+    def materialise(self):
+        steps = self.steps
+        need = [False] * len(steps)
+        for j in range(len(steps) - 1, -1, -1):
+            t = steps[j][4]()
+            if (t is not None and t._op is self) or need[j]:
+                need[j] = True
+                if steps[j][3] >= 0:
+                    need[steps[j][3]] = True
+        kept = []
+        for j, (kind, mod, _a, _s, _r) in enumerate(steps):
+            if need[j] and kind == BN and mod.bn.track_running_stats:
+                b = mod.bn
+                kept.append((b, b.running_mean.clone(), b.running_var.clone(), b.num_batches_tracked.clone()))
+        vals = {}
+        try:
+            with torch.enable_grad():
+                for j, (kind, mod, arg, src, ref) in enumerate(steps):
+                    if not need[j]:
+                        continue
+                    t = ref()
+                    if t is not None and t._op is not self:
+                        vals[j] = t                                   # (already has its value)
+                        continue
+                    inp = self.x if src < 0 else vals[src]
+                    vals[j] = mod._forward_now(inp, resolved=arg, out=t) if kind == CONV else mod._forward_now(inp, relu=arg, out=t)
+        finally:
+            with torch.no_grad():
+                for b, rm, rv, nbt in kept:
+                    b.running_mean.copy_(rm); b.running_var.copy_(rv); b.num_batches_tracked.copy_(nbt)
 
 
 _ST = None          # core.SparseTensor / core.cat_now / block: bound on first use (core imports this module)
@@ -203,6 +252,11 @@ def add_residual(t, other):
 # ------------------------------------------------------------------------------------------------ execution
 def materialise(t):
     op = t._op
+    if op.kind == LazyBlock.kind:
+        op.materialise()
+        if t._op is not None:
+            raise RuntimeError("an intermediate of a fused residual block could not be recomputed")
+        return
     if op.kind < 0:
         if op.cause is not None:
             raise RuntimeError(op.why) from op.cause

@@ -5,7 +5,10 @@ modules/resnet_block.py) load unchanged through the `MinkowskiEngine` alias pack
 build's self-contained counterpart (the reference .py files do not travel to the GPU box).  It
 reproduces, and tests/test_models_manifest.py pins against fixtures captured from the reference:
   * the module tree / state-dict keys and shapes (`conv0p1s1.kernel`, `block2.0.downsample.1.bn.weight`, ...)
-    so released checkpoints load (lib/utils.py:17-45),
+    so that a released checkpoint's tensors find their slots by name and shape (lib/utils.py:17-45).  UNTESTED, and not a
+    claim that such a checkpoint reproduces its accuracy here: the order of the K kernel offsets inside `*.kernel [K, Cin, Cout]`
+    (first spatial axis fastest) is recalled from MinkowskiEngine 0.5.4, whose source is not in /root/reference and
+    could not be checked in this build -- no ME, no checkpoint, no network,
   * the dataflow of Res16UNetBase.forward (res16unet.py:196-270) incl. cat order (upsampled, skip),
   * BasicBlock.forward (resnet_block.py:41-57) CALL FOR CALL -- norm(x); relu(x) in place; out += residual; relu; me.cat --
     with standard MinkowskiEngine signatures only: the fusion (norm + residual + ReLU in one kernel, zero-copy cat, one engine

@@ -135,3 +135,10 @@ def test_product_package_never_imports_oracle():
                     src = open(os.path.join(base, f)).read()
                     assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(base, f)
                     assert "from .. import oracle" not in src and "import oracle" not in src.replace("# oracle", "")
+
+
+def test_integration_stub_names_the_current_abi_version():
+    """INTEGRATION.md once said `lgs_abi_version() == 10` two versions after the header had moved on"""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    named = [int(v) for v in re.findall(r"lgs_abi_version\(\) == (\d+)", txt)]
+    assert named and all(v == header_abi_version() for v in named), named

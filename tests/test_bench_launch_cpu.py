@@ -67,3 +67,59 @@ def test_self_launch_propagates_a_rank_failure(tmp_path):
     stub = tmp_path / "bad_rank.py"
     stub.write_text("import sys; sys.exit(3)\n")
     assert bench.self_launch(2, [], script=str(stub)) != 0
+
+
+def _full_record():
+    """the biggest record a default run produces: round 5's committed line (21 KB: every secondary block) plus this round's keys"""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+    full["step_ms"] = {"median": 27.1234567, "p90": 27.9, "min": 26.9, "max": 31.2, "all": [27.1] * 20}
+    full["warmup_ms"], full["warmup_extra"] = [40.0, 28.0, 27.5, 27.2, 27.1], 3
+    rf = full["roofline"]
+    rf.setdefault("hbm_frac", rf["frac"])
+    rf.setdefault("arithmetic_intensity_flop_per_byte", 42.0)
+    full["balanced"] = {"ms_per_step": 27.7, "sampled": {"ms_per_step": 28.3}}
+    full["rccl_ranks"]["comm_create_s"] = None
+    return full
+
+
+def test_stdout_line_stays_under_4_kb_and_round_trips():
+    """round 5's line had grown to 21 KB and the driver recorded `parsed: null`: the ONE stdout line carries the contract keys,
+    `roofline`, `cpu_baseline` and one number per secondary workload; everything else goes to the details file"""
+    import bench
+    full = _full_record()
+    text = bench.headline(full, "gpurun_out/bench_full.json")
+    assert len(text) < 4096 and "\n" not in text
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "details"):
+        assert k in line, k
+    assert line["config"]["workload"].startswith("Res16UNet34C") and "model" not in line["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    assert line["step_ms"]["median"] == 27.12 and line["secondary"]["clip_ms"] > 100
+    assert abs(line["value"] - full["value"]) / full["value"] < 1e-6
+
+
+def test_stdout_line_of_an_eight_rank_run_fits_too():
+    import bench
+    full = _full_record()
+    full["n_gpus"] = 8
+    full["per_rank"] = [dict(full["per_rank"][0], rank=r, ddp={"allreduce_exposed_wait_ms": 0.41234, "syncbn_collective_ms": 1.2345})
+                        for r in range(8)]
+    full["rccl_ranks"].update(comm_create_s=3.21, backend="nccl")
+    text = bench.headline(full, None)
+    assert len(text) < 4096
+    line = json.loads(text)
+    assert len(line["ranks"]["ms_per_step"]) == 8 and line["ranks"]["comm_create_s"] == 3.21
+
+
+def test_warmup_settles_on_two_agreeing_steps():
+    import bench
+    assert not bench._settled([40.0, 29.0])
+    assert not bench._settled([40.0, 35.0, 56.0, 50.0])            # round 5's driver run: still moving
+    assert not bench._settled([29.0, 27.0, 33.0, 33.2])            # agreeing, but well above the fastest step seen
+    assert bench._settled([40.0, 27.3, 27.1, 27.2])
+    s = bench.step_stats([27.0, 27.2, 27.1, 56.0])
+    assert s["median"] == pytest.approx(27.15) and s["max"] == 56.0 and s["min"] == 27.0

@@ -121,20 +121,70 @@ def test_call_by_call_inplace_ops_are_autograd_legal_and_match_torch():
         assert torch.allclose(a[2][k], b[2][k], atol=1e-4, rtol=1e-3), k
 
 
-def test_intermediates_of_a_fused_block_say_so_when_read():
+def test_intermediates_of_a_fused_block_are_recomputed_when_read():
+    """MinkowskiEngine semantics for a caller that keeps what the reference's block rebinds (resnet_block.py:44-46): conv1's output
+    and norm1's (rectified in place) read AFTER the block ran as one fused node have the values -- and carry the gradients -- of the
+    call-by-call execution; the norms' running statistics count the batch once."""
     from languagegroundedsemseg_amd.models import BasicBlock
     coords, feats, _ = _scene(seed=3, n=20000)
     c = torch.from_numpy(coords).to(DEV)
+    f = torch.randn(coords.shape[0], 32, device=DEV)
+    wmid = torch.linspace(-1, 1, 32, device=DEV)
+
+    def run(defer):
+        blk = deterministic_init(BasicBlock(32, 32, D=3), 5).to(DEV).train()
+        x = ME.SparseTensor(f.clone().requires_grad_(True), c)
+
+        def fwd():
+            mid = blk.conv1(x)                   # someone keeps the first convolution's output ...
+            act = blk.norm1(mid)
+            act = blk.relu(act)                  # ... and the rectified norm output
+            out = blk.conv2(act)
+            out = blk.norm2(out)
+            out += x
+            out = blk.relu(out)
+            return mid, act, out
+        n0 = deferred.STATS["blocks"]
+        mid, act, out = _with_defer(defer, fwd)
+        y = out.F
+        assert deferred.STATS["blocks"] == n0 + (1 if defer else 0)
+        stats = [t.clone() for t in (blk.norm1.bn.running_mean, blk.norm1.bn.running_var, blk.norm1.bn.num_batches_tracked)]
+        a, m = act.F, mid.F                      # read in the "wrong" order: act's recomputation fills mid on the way
+        for t, s0 in zip((blk.norm1.bn.running_mean, blk.norm1.bn.running_var, blk.norm1.bn.num_batches_tracked), stats):
+            assert torch.equal(t, s0)            # the recomputation left the statistics alone
+        assert int(blk.norm1.bn.num_batches_tracked) == 1
+        (y.sum() + (m * wmid).sum() + a.square().sum()).backward()
+        return y.detach(), m.detach(), a.detach(), x.F.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}
+
+    fu, cc = run(True), run(False)
+    for i in range(3):
+        assert torch.allclose(fu[i], cc[i], atol=1e-5, rtol=1e-5), i
+    assert float(fu[2].min()) >= 0.0
+    assert torch.allclose(fu[3], cc[3], atol=1e-4, rtol=1e-4)
+    for k in fu[4]:
+        assert torch.allclose(fu[4][k], cc[4][k], atol=2e-4, rtol=1e-3), k
+
+
+def test_a_block_nobody_looks_into_keeps_nothing_alive():
+    """the lazy record holds the block input strongly and the intermediates weakly: once the wrappers are rebound (as the
+    reference's block does) the record and the input's features are released without the cyclic collector"""
+    import gc
+    import weakref
+    from languagegroundedsemseg_amd.models import BasicBlock
+    coords, feats, _ = _scene(seed=3, n=20000)
     blk = deterministic_init(BasicBlock(32, 32, D=3), 5).to(DEV).train()
-    x = ME.SparseTensor(torch.randn(coords.shape[0], 32, device=DEV), c)
-    mid = blk.conv1(x)                   # someone keeps the first convolution's output ...
-    out = blk.norm1(mid)
-    out = blk.relu(out)
-    out = blk.conv2(out)
-    out = blk.norm2(out)
-    out += x
-    out = blk.relu(out)
-    n0 = deferred.STATS["blocks"]
-    assert torch.isfinite(out.F).all() and deferred.STATS["blocks"] == n0 + 1
-    with pytest.raises(RuntimeError, match="fused"):
-        mid.F                            # ... and is told why it has no value (and how to get one)
+    gc.collect()
+    gc.disable()
+    try:
+        x = ME.SparseTensor(torch.randn(coords.shape[0], 32, device=DEV), torch.from_numpy(coords).to(DEV))
+        with torch.no_grad():
+            pass
+        n0 = deferred.STATS["blocks"]
+        out = blk(x)
+        y = out.F
+        assert deferred.STATS["blocks"] == n0 + 1
+        ref = weakref.ref(x._F)
+        del x, out, y
+        assert ref() is None
+    finally:
+        gc.enable()
