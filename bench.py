@@ -468,13 +468,20 @@ def make_trainer(model_name, dtype, device, world, args, ctx):
     return model, ddp, opt
 
 
-def _settled(ms):
-    """warm-up verdict from the per-step compute-stream times of the steps since the last synchronisation: the last two agree
-    within 3 % and neither is more than 5 % above the fastest step seen so far"""
-    if len(ms) < 3:
+SETTLE_ROUND = 4      # steps per warm-up round between two synchronisations
+
+
+def _settled(rounds):
+    """warm-up verdict from the per-step compute-stream times of the warm-up ROUNDS (each a run of steps between two
+    synchronisations).  Inside a round the first step is slow (nothing of it was prepared under the previous step) and the last
+    one fast (no next step builds its maps beside it), so a round is judged by its middle steps: they agree within 3 %, and their
+    mean is within 2 % of the previous round's"""
+    mids = [r[1:-1][-2:] for r in rounds if len(r) >= 4]
+    if len(mids) < 2:
         return False
-    a, b = ms[-2], ms[-1]
-    return abs(a - b) <= 0.03 * min(a, b) and max(a, b) <= 1.05 * min(ms[1:])
+    a, b = mids[-1]
+    m1, m0 = 0.5 * (a + b), sum(mids[-2]) / len(mids[-2])
+    return abs(a - b) <= 0.03 * min(a, b) and abs(m1 - m0) <= 0.02 * m0
 
 
 def step_stats(ms):
@@ -489,8 +496,8 @@ def step_stats(ms):
 
 
 def measure(model, ddp, opt, coords, feats, labels, dtype, steps, warmup, ctx, clog, world, want_roofline, base=0, settle=12):
-    """`warmup` untimed plain steps, then -- still untimed -- up to `settle` more in rounds of three until two consecutive steps
-    agree within 3 % (a fresh box pays for allocator growth, code-object loading and clock ramps in its first steps: round 5's
+    """`warmup` untimed plain steps, then -- still untimed -- up to `settle` more in rounds of four until two consecutive rounds
+    agree (`_settled`) (a fresh box pays for allocator growth, code-object loading and clock ramps in its first steps: round 5's
     driver run had six 35 - 56 ms steps inside the timed region); then exactly `steps` timed steps bracketed by barrier +
     synchronize on both sides.  The fully instrumented DISCOVERY step and the SAMPLING steps of the roofline run AFTER the timed
     region: nothing before or inside it is bracketed, enqueued call by call or allocated differently from production.
@@ -508,20 +515,19 @@ def measure(model, ddp, opt, coords, feats, labels, dtype, steps, warmup, ctx, c
         torch.cuda.synchronize()
         return [ev[i].elapsed_time(ev[i + 1]) for i in range(n)]
 
-    warm_ms = plain(warmup, base) if warmup > 0 else []
-    seen, extra = list(warm_ms), 0
+    rounds = [plain(warmup, base)] if warmup > 0 else []
+    extra = 0
     while settle > 0 and extra < settle and warmup > 0:
-        ok = _settled(seen)
+        ok = _settled(rounds)
         if world > 1:      # every rank runs the same number of steps (the steps contain collectives)
             flag = torch.tensor([0.0 if ok else 1.0], device=coords.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             ok = flag.item() == 0.0
         if ok:
             break
-        more = plain(3, base + warmup + extra)
-        warm_ms += more
-        seen = seen + more
-        extra += 3
+        rounds.append(plain(SETTLE_ROUND, base + warmup + extra))
+        extra += SETTLE_ROUND
+    warm_ms = [m for r in rounds for m in r]
     if ddp.timing is not None:
         ddp.timing_summary(1)                   # drop the warm-up's collective events
     del _PHASES[:]

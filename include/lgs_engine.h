@@ -418,6 +418,13 @@ int lgs_ce_forward_backward(const void *logits, int64_t n, int c, const int64_t 
 int lgs_ce_forward_backward_rows(const void *logits, int64_t n, int c, const int64_t *labels, int64_t ignore_index,
                                  const float *scale, const float *row_scale, float *loss_rows, void *dlogits, int dtype,
                                  void *stream);
+/* head / common / tail statistics of per-point losses (ABI 13): what the trainer's three meters take from
+ * sample_categories_for_balancing (/root/reference/lib/losses/utils.py:69-72, pl_BaselineTrainer.py:353-355) without its
+ * three boolean-index gathers (= three host syncs).  group_of_class[n_classes] in {0,1,2} (anything else: not counted); rows whose
+ * label is ignore_index or outside [0, n_classes) are skipped.  partial[partial_rows][6] (1 <= partial_rows <= 1024, overwritten):
+ * per workgroup (sum, count) x 3 groups -- the caller adds the rows up (deterministic; no float atomics). */
+int lgs_split_stats(const float *loss_rows, const int64_t *labels, int64_t n, const int32_t *group_of_class, int n_classes,
+                    int64_t ignore_index, float *partial, int partial_rows, void *stream);
 /* number of rows the loss above counts (label != ignore_index and inside [0, c)) -> *count (DEVICE int32, overwritten): the
  * denominator of the mean reduction (pl_BaselineTrainer.py:350, nn.CrossEntropyLoss(ignore_index) 'mean') without a host
  * sync and without a chain of elementwise / reduction launches over the label tensor. */

@@ -135,9 +135,57 @@ __global__ __launch_bounds__(256) void k_ce_count_valid(const int64_t *__restric
   if (threadIdx.x == 0 && l_cnt) atomicAdd(count, l_cnt);
 }
 
+// head / common / tail statistics of the per-point losses (lib/losses/utils.py:69-72: loss[loss_items[:, g]] for the trainer's three
+// meters, pl_BaselineTrainer.py:353-355) without the boolean-index gathers: per workgroup the sums and counts of the three groups
+// -> partial[block][6]; the caller adds the <= 1024 rows up (deterministic, no float atomics).  One streaming pass: 12 B per point.
+__global__ __launch_bounds__(256) void k_split_stats(const float *__restrict__ loss, const int64_t *__restrict__ labels, int64_t n,
+                                                     const int32_t *__restrict__ group_of_class, int n_classes, int64_t ignore_index,
+                                                     float *__restrict__ partial) {
+  __shared__ float l_acc[4][6];
+  float sum[3] = {0.f, 0.f, 0.f}, cnt[3] = {0.f, 0.f, 0.f};
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+    const int64_t lab = labels[r];
+    if (lab == ignore_index || lab < 0 || lab >= n_classes) continue;
+    const int g = group_of_class[lab];
+    const float v = loss[r];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      sum[k] += g == k ? v : 0.f;
+      cnt[k] += g == k ? 1.f : 0.f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      sum[k] += __shfl_down(sum[k], o, 64);
+      cnt[k] += __shfl_down(cnt[k], o, 64);
+    }
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { l_acc[wave][2 * k] = sum[k]; l_acc[wave][2 * k + 1] = cnt[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6)
+    partial[(int64_t)blockIdx.x * 6 + threadIdx.x] = l_acc[0][threadIdx.x] + l_acc[1][threadIdx.x] + l_acc[2][threadIdx.x] + l_acc[3][threadIdx.x];
+}
+
 }  // namespace lgs
 
 using namespace lgs;
+
+extern "C" int lgs_split_stats(const float *loss_rows, const int64_t *labels, int64_t n, const int32_t *group_of_class, int n_classes,
+                               int64_t ignore_index, float *partial, int partial_rows, void *stream) {
+  LGS_REQUIRE(partial && group_of_class && n >= 0 && n_classes >= 1 && partial_rows >= 1 && partial_rows <= 1024 &&
+                  ((loss_rows && labels) || n == 0),
+              "lgs_split_stats: bad argument");
+  LGS_KLAUNCH(k_split_stats, (unsigned)partial_rows, 256, 0, (hipStream_t)stream, loss_rows, labels, n, group_of_class, n_classes,
+              ignore_index, partial);
+  LGS_HIP(hipGetLastError());
+  return 0;
+}
 
 extern "C" int lgs_ce_forward_backward_rows(const void *logits, int64_t n, int c, const int64_t *labels, int64_t ignore_index,
                                             const float *scale, const float *row_scale, float *loss_rows, void *dlogits, int dtype,

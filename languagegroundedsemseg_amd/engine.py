@@ -92,7 +92,7 @@ EXPORTS = [
     "lgs_clip_similarity", "lgs_clip_workspace_bytes",
     "lgs_clip_loss_workspace_bytes", "lgs_clip_loss_forward", "lgs_clip_loss_backward",
     "lgs_clip_anchor_grad_workspace_bytes", "lgs_clip_loss_backward_anchors",
-    "lgs_ce_forward_backward", "lgs_ce_forward_backward_rows",
+    "lgs_ce_forward_backward", "lgs_ce_forward_backward_rows", "lgs_split_stats",
     "lgs_ce_count_valid",
     "lgs_comm_unique_id", "lgs_comm_create", "lgs_comm_create_ipc", "lgs_comm_ipc_open", "lgs_comm_destroy", "lgs_comm_world", "lgs_bn_sync_workspace_bytes",
     "lgs_bn_forward_sync", "lgs_bn_backward_sync",
@@ -160,6 +160,7 @@ def lib():
         "lgs_clip_similarity": [vp, i64, ci, vp, ci, vp, vp, ci, vp, vp],
         "lgs_ce_forward_backward": [vp, i64, ci, vp, i64, vp, vp, vp, ci, vp],
         "lgs_ce_forward_backward_rows": [vp, i64, ci, vp, i64, vp, vp, vp, vp, ci, vp],
+        "lgs_split_stats": [vp, vp, i64, vp, ci, i64, vp, ci, vp],
         "lgs_ce_count_valid": [vp, i64, ci, i64, vp, vp],
         "lgs_comm_unique_id": [vp],
         "lgs_comm_create": [vp, ci, ci, ci, ctypes.POINTER(vp)],

@@ -461,32 +461,60 @@ def sample_categories_for_balancing(loss, targets, frequency_organized_cats, hea
     # per-class keep ratio, built from host scalars with fills only (a torch.tensor([...]) would be a blocking host->device copy)
     ratio = torch.ones(L, dtype=torch.float64, device=dev)
     ratio.masked_fill_(group == 0, head_ratio if head_ratio > 0 else 1.0).masked_fill_(group == 1, common_ratio if common_ratio > 0 else 1.0)
-    pg = group[lab]
-    counts = torch.zeros(L, dtype=torch.long, device=dev).index_add_(0, lab, valid.long())
-    keep_n = torch.round(ratio * counts.double()).long()                         # python round == torch.round: half to even
     if head_ratio <= 0 and common_ratio <= 0:
         # the configured default (config.py:281-282: both ratios -1; scripts/train_models.sh sets neither): every class keeps all
         # of its points (:45,:56,:60), nothing is drawn
         point_mask = valid
     else:
-        # rank of every point inside its class by a random key = a uniform draw without replacement
+        # rank of every point inside its class by a random key = a uniform draw without replacement.  Class sizes and first
+        # positions come from the sorted keys (binary searches for the 200 class boundaries), not from 1.2 M atomics on 200 counters
         u = torch.rand(loss.shape[0], device=dev, generator=generator)
         key = lab.double() + u.double()
         key = torch.where(valid, key, torch.full_like(key, float(L + 1)))
-        order = torch.argsort(key)
-        start = torch.cumsum(counts, 0) - counts                                 # first sorted position of every class
+        skey, order = torch.sort(key)
+        bounds = torch.searchsorted(skey, torch.arange(L + 1, device=dev, dtype=torch.float64))
+        start, counts = bounds[:L], bounds[1:] - bounds[:L]                       # first sorted position / size of every class
+        keep_n = torch.round(ratio * counts.double()).long()                     # python round == torch.round: half to even
         pos = torch.empty_like(order)
         pos[order] = torch.arange(order.shape[0], device=dev)
         rank_in_class = pos - start[lab]
         point_mask = valid & (rank_in_class < keep_n[lab])
-    loss_items = torch.stack([valid & (pg == 0), valid & (pg == 1), valid & (pg == 2)], 1)
     masked = loss * point_mask.to(loss.dtype)
+    be = get_backend()
+    if split == "stats" and loss.is_cuda and hasattr(be, "split_stats"):
+        # one streaming pass for the three meters (lgs_split_stats); the [N, 3] membership mask is built only if somebody reads it
+        stats = be.split_stats(loss, targets, group, ignore_label)
+        return masked.mean(), stats, _LazyItems(valid, group, lab)
+    pg = group[lab]
+    loss_items = torch.stack([valid & (pg == 0), valid & (pg == 1), valid & (pg == 2)], 1)
     if split == "stats":
-        w = loss_items.to(torch.float32)                                          # [N, 3]
-        stats = torch.stack([w.t() @ loss.detach().float(), w.sum(0)], 1)         # [3, 2]: sums, counts
+        ld = loss.detach().float()
+        stats = torch.stack([torch.stack([(ld * loss_items[:, i]).sum() for i in range(3)]), loss_items.sum(0).float()], 1)   # [3, 2]
         return masked.mean(), stats, loss_items
     head, common, tail = (loss[loss_items[:, i]].detach() for i in range(3))
     return masked.mean(), (head, common, tail), loss_items[valid]
+
+
+class _LazyItems:
+    """loss_items [N, 3] of split='stats' on the device path, built when it is indexed / converted (the training step never does:
+    its meters take the statistics; the reference's evaluation code indexes predictions with it, pl_BaselineTrainer.py:358-370)"""
+
+    def __init__(self, valid, group, lab):
+        self._parts, self._t = (valid, group, lab), None
+
+    def tensor(self):
+        if self._t is None:
+            valid, group, lab = self._parts
+            pg = group[lab]
+            self._t = torch.stack([valid & (pg == 0), valid & (pg == 1), valid & (pg == 2)], 1)
+            self._parts = None
+        return self._t
+
+    def __getitem__(self, idx):
+        return self.tensor()[idx]
+
+    def __getattr__(self, name):
+        return getattr(self.tensor(), name)
 
 
 def instance_offset_losses(pt_offsets, coords_xyz, centers, instance_ids, voxel_size):

@@ -998,6 +998,21 @@ class HipBackend:
                                                         None, _ptr(dlogits), _dtype_code(logits), _stream()))
             return dlogits
 
+    def split_stats(self, loss_rows, labels, group_of_class, ignore_index):
+        """-> [3, 2] fp32: (sum of loss_rows, number of rows) of the head / common / tail points (lgs_split_stats), no host sync"""
+        _require_dev(loss_rows, "loss_rows")
+        L = engine.lib()
+        loss_rows = loss_rows.detach().contiguous().to(torch.float32)
+        labels = labels.contiguous().to(torch.int64)
+        group_of_class = group_of_class.contiguous().to(torch.int32)
+        n = loss_rows.shape[0]
+        rows = max(1, min(1024, (n + 2047) // 2048))
+        with _dev(loss_rows.device):
+            partial = torch.empty(rows, 6, dtype=torch.float32, device=loss_rows.device)
+            engine.check(L.lgs_split_stats(_ptr(loss_rows), _ptr(labels), n, _ptr(group_of_class), int(group_of_class.shape[0]),
+                                           int(ignore_index), _ptr(partial), rows, _stream()))
+        return partial.sum(0).view(3, 2)
+
     def _one(self, device):
         """a device-resident 1.0f (the kernels take their scalar factors from device memory)"""
         cache = self.__dict__.setdefault("_one_cache", {})

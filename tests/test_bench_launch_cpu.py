@@ -115,11 +115,11 @@ def test_stdout_line_of_an_eight_rank_run_fits_too():
     assert len(line["ranks"]["ms_per_step"]) == 8 and line["ranks"]["comm_create_s"] == 3.21
 
 
-def test_warmup_settles_on_two_agreeing_steps():
+def test_warmup_settles_on_two_agreeing_rounds():
     import bench
-    assert not bench._settled([40.0, 29.0])
-    assert not bench._settled([40.0, 35.0, 56.0, 50.0])            # round 5's driver run: still moving
-    assert not bench._settled([29.0, 27.0, 33.0, 33.2])            # agreeing, but well above the fastest step seen
-    assert bench._settled([40.0, 27.3, 27.1, 27.2])
+    assert not bench._settled([[448.0, 31.5, 27.2, 26.9, 25.2]])                               # one round says nothing
+    assert not bench._settled([[448.0, 40.0, 35.0, 56.0, 50.0], [41.3, 35.5, 27.0, 25.3]])     # round 5's driver run: still moving
+    assert not bench._settled([[448.0, 31.5, 29.2, 28.9, 25.2], [31.1, 26.9, 27.0, 25.3]])     # agreeing inside, but 7 % below the round before
+    assert bench._settled([[448.0, 31.5, 27.2, 26.9, 25.2], [31.1, 26.9, 27.0, 25.3]])         # this round's measured warm-up
     s = bench.step_stats([27.0, 27.2, 27.1, 56.0])
     assert s["median"] == pytest.approx(27.15) and s["max"] == 56.0 and s["min"] == 27.0

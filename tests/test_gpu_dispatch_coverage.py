@@ -50,6 +50,7 @@ def _bench_sites():
 
     c, f, l = (torch.from_numpy(a).to(dev) for a in make_batch(list(range(8)), voxel=0.02, n_target=150000))
     run("ce bf16 (configs[1], headline)", "ce", "Res16UNet34C", torch.bfloat16, c, f, l)
+    run("ce bf16, balanced category sampling (scripts/train_models.sh:37)", "ce_balanced_sampled", "Res16UNet34C", torch.bfloat16, c, f, l)
     run("ce fp32 (parity path)", "ce", "Res16UNet34C", torch.float32, c, f, l)
     run("clip (configs[2])", "clip", "Res16UNet34D", torch.bfloat16, c, f, l)
     run("insseg full (configs[4])", "insseg", "InsSegRes16UNet34C", torch.bfloat16, c, f, l)
