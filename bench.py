@@ -468,19 +468,19 @@ def make_trainer(model_name, dtype, device, world, args, ctx):
     return model, ddp, opt
 
 
-SETTLE_ROUND = 4      # steps per warm-up round between two synchronisations
+SETTLE_ROUND = 5      # steps per warm-up round between two synchronisations
 
 
 def _settled(rounds):
     """warm-up verdict from the per-step compute-stream times of the warm-up ROUNDS (each a run of steps between two
-    synchronisations).  Inside a round the first step is slow (nothing of it was prepared under the previous step) and the last
-    one fast (no next step builds its maps beside it), so a round is judged by its middle steps: they agree within 3 %, and their
-    mean is within 2 % of the previous round's"""
-    mids = [r[1:-1][-2:] for r in rounds if len(r) >= 4]
+    synchronisations).  Inside a round the first two steps are slow (nothing of the first was prepared under a previous step, the
+    second still catches up) and the last one fast (no next step builds its maps beside it), so a round is judged by the two steps
+    before its last: they agree within 3 %, and their mean is within 2 % of the previous round's"""
+    mids = [r[-3:-1] for r in rounds if len(r) >= 5]
     if len(mids) < 2:
         return False
     a, b = mids[-1]
-    m1, m0 = 0.5 * (a + b), sum(mids[-2]) / len(mids[-2])
+    m1, m0 = 0.5 * (a + b), 0.5 * sum(mids[-2])
     return abs(a - b) <= 0.03 * min(a, b) and abs(m1 - m0) <= 0.02 * m0
 
 
@@ -495,8 +495,8 @@ def step_stats(ms):
     return {"median": med, "p90": v[min(n - 1, int(0.9 * n))], "min": v[0], "max": v[-1]}
 
 
-def measure(model, ddp, opt, coords, feats, labels, dtype, steps, warmup, ctx, clog, world, want_roofline, base=0, settle=12):
-    """`warmup` untimed plain steps, then -- still untimed -- up to `settle` more in rounds of four until two consecutive rounds
+def measure(model, ddp, opt, coords, feats, labels, dtype, steps, warmup, ctx, clog, world, want_roofline, base=0, settle=15):
+    """`warmup` untimed plain steps, then -- still untimed -- up to `settle` more in rounds of five until two consecutive rounds
     agree (`_settled`) (a fresh box pays for allocator growth, code-object loading and clock ramps in its first steps: round 5's
     driver run had six 35 - 56 ms steps inside the timed region); then exactly `steps` timed steps bracketed by barrier +
     synchronize on both sides.  The fully instrumented DISCOVERY step and the SAMPLING steps of the roofline run AFTER the timed

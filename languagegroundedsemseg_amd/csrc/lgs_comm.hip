@@ -13,6 +13,7 @@
 #include "lgs_common.h"
 
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 #include <mutex>
 
@@ -98,13 +99,21 @@ struct lgs_comm {
   void *peer[kMbMaxWorld] = {nullptr};    // mapped mailboxes of all ranks (peer[rank] == mine)
   Mailbox *d_boxes = nullptr;             // device array [world]
   unsigned seq = 0;                       // collectives issued so far (identical on every rank: same model, same order)
+  unsigned *h_err = nullptr;              // pinned, device-mapped word: a kernel that gave up waiting stores its seq here
+  unsigned *d_err = nullptr;              // device view of h_err
+  long long timeout_ticks = 0;            // wall_clock64() ticks a kernel waits for its peers before it gives up
 };
 
 namespace {
 inline size_t mb_slot_bytes(int world) { return (size_t)kMbRing * world * kMbRec * sizeof(float); }
 inline size_t mb_bytes(int world) { return mb_slot_bytes(world) + (size_t)kMbRing * world * sizeof(unsigned) + 256; }
 
-__device__ inline void mb_put_and_wait(const Mailbox *boxes, int world, int rank, unsigned seq, const float *rec, int len) {
+// The wait is BOUNDED (advisor, round 5): ranks whose sequence numbers diverge -- one rank in eval mode, a launch that failed after
+// seq was bumped -- would otherwise spin on the compute stream for ever.  A waiter that sees no record for `timeout` wall-clock
+// ticks stores seq into the communicator's host-mapped error word and leaves (its result is garbage); the host side reads that
+// word at the head of every sync call and fails with a message instead of hanging.
+__device__ inline void mb_put_and_wait(const Mailbox *boxes, int world, int rank, unsigned seq, const float *rec, int len,
+                                       unsigned *err, long long timeout) {
   const int ring = (int)(seq % kMbRing);
   // my record into every rank's mailbox (mine included)
   for (int p = 0; p < world; ++p) {
@@ -118,7 +127,15 @@ __device__ inline void mb_put_and_wait(const Mailbox *boxes, int world, int rank
   // everybody's record of THIS seq in my mailbox
   if ((int)threadIdx.x < world) {
     const unsigned *f = boxes[rank].flag + ring * world + threadIdx.x;
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) __builtin_amdgcn_s_sleep(2);
+    const long long t0 = wall_clock64();
+    unsigned spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 1023u) == 0 && timeout > 0 && wall_clock64() - t0 > timeout) {
+        __hip_atomic_store(err, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
   }
   __syncthreads();
   __threadfence_system();
@@ -130,19 +147,32 @@ __device__ inline float mb_get(const Mailbox *boxes, int world, int rank, unsign
 
 // all-gather of the [mean | M2 | count] records: all[r][0 .. 2C] for every rank r, in rank order
 __global__ __launch_bounds__(256) void k_mbox_allgather(const Mailbox *boxes, int world, int rank, unsigned seq, const float *local, int len,
-                                                        float *all) {
-  mb_put_and_wait(boxes, world, rank, seq, local, len);
+                                                        float *all, unsigned *err, long long timeout) {
+  mb_put_and_wait(boxes, world, rank, seq, local, len, err, timeout);
   for (int r = 0; r < world; ++r)
     for (int i = threadIdx.x; i < len; i += blockDim.x) all[(size_t)r * len + i] = mb_get(boxes, world, rank, seq, r, i);
 }
 // all-reduce (sum, fixed rank order: identical bits on every rank) of `len` floats, in place
-__global__ __launch_bounds__(256) void k_mbox_allreduce(const Mailbox *boxes, int world, int rank, unsigned seq, float *sums, int len) {
-  mb_put_and_wait(boxes, world, rank, seq, sums, len);
+__global__ __launch_bounds__(256) void k_mbox_allreduce(const Mailbox *boxes, int world, int rank, unsigned seq, float *sums, int len,
+                                                        unsigned *err, long long timeout) {
+  mb_put_and_wait(boxes, world, rank, seq, sums, len, err, timeout);
   for (int i = threadIdx.x; i < len; i += blockDim.x) {
     float a = 0.f;
     for (int r = 0; r < world; ++r) a += mb_get(boxes, world, rank, seq, r, i);
     sums[i] = a;
   }
+}
+// next sequence number of a mailbox exchange; fails (instead of queueing more kernels that would wait for the same peers) once a
+// kernel has reported a timeout.  0 is never used: the flags are zero-initialised, a wrapped-around seq 0 would be "already there"
+inline int mbox_next(lgs_comm *c) {
+  if (c->h_err && *reinterpret_cast<volatile unsigned *>(c->h_err) != 0u) {
+    lgs::set_error("SyncBN mailbox exchange " + std::to_string(*reinterpret_cast<volatile unsigned *>(c->h_err)) + " timed out waiting for a peer's "
+                   "record: the ranks' collective sequences have diverged (a rank in eval mode, a failed launch) or a peer died");
+    return 3;
+  }
+  c->seq += 1;
+  if (c->seq == 0) c->seq = 1;
+  return 0;
 }
 }  // namespace
 
@@ -189,6 +219,16 @@ int lgs_comm_create_ipc(int world, int rank, int device, lgs_comm **out, void *h
     (void)hipGetLastError();
     if (c->mine) (void)hipFree(c->mine);
     c->mine = nullptr;
+    // an ordinary (coarse-grained) allocation gives no guarantee that a peer DEVICE's stores become visible to a kernel that is
+    // already spinning: that is "mailbox unavailable" (every rank then agrees to keep the collectives, ddp.EngineComm), unless the
+    // caller says all ranks share one device (LGS_MBOX_ALLOW_COARSE=1: the single-GPU logic tests)
+    const char *allow = getenv("LGS_MBOX_ALLOW_COARSE");
+    if (!(allow && atoi(allow) != 0)) {
+      lgs::set_error("lgs_comm_create_ipc: the runtime grants no fine-grained, IPC-exportable allocation for the mailbox; a coarse-grained "
+                     "one is not coherent with a spinning kernel across devices (LGS_MBOX_ALLOW_COARSE=1 accepts it when all ranks share one GPU)");
+      delete c;
+      return 3;
+    }
     if (hipMalloc(&c->mine, bytes) != hipSuccess || hipIpcGetMemHandle(&h, c->mine) != hipSuccess) {
       lgs::set_error("lgs_comm_create_ipc: could not allocate / export the mailbox (hipIpcGetMemHandle; HSA_ENABLE_IPC_MODE_LEGACY=0 set?)");
       if (c->mine) (void)hipFree(c->mine);
@@ -198,6 +238,16 @@ int lgs_comm_create_ipc(int world, int rank, int device, lgs_comm **out, void *h
   }
   LGS_HIP(hipMemset(c->mine, 0, bytes));
   LGS_HIP(hipDeviceSynchronize());
+  LGS_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_err), sizeof(unsigned), hipHostMallocMapped));
+  *c->h_err = 0;
+  LGS_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_err), c->h_err, 0));
+  {
+    int khz = 100000;                                       // wall_clock64() rate; 100 MHz on every CDNA part so far
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device);
+    const char *t = getenv("LGS_MBOX_TIMEOUT_S");
+    const double secs = t ? atof(t) : 30.0;
+    c->timeout_ticks = (long long)(secs * 1000.0 * (double)(khz > 0 ? khz : 100000));
+  }
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C-ABI hands the handle over as 64 bytes");
   ::memcpy(handle64, &h, 64);
   c->peer[rank] = c->mine;
@@ -234,6 +284,7 @@ int lgs_comm_destroy(lgs_comm *c) {
       if (r != c->rank && c->peer[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
     if (c->d_boxes) (void)hipFree(c->d_boxes);
     if (c->mine) (void)hipFree(c->mine);
+    if (c->h_err) (void)hipHostFree(c->h_err);
   }
   delete c;
   return 0;
@@ -260,8 +311,9 @@ int lgs_bn_forward_sync(lgs_comm *comm, const void *x, int64_t n, int c, const f
   if ((rc = lgs_bn_stats(x, n, c, local, dtype, workspace, nullptr, 0, nullptr, stream))) return rc;
   if (comm->ipc) {
     LGS_REQUIRE(2 * c + 1 <= kMbRec, "lgs_bn_forward_sync: record wider than a mailbox slot");
-    comm->seq += 1;
-    LGS_KLAUNCH(k_mbox_allgather, 1, 256, 0, (hipStream_t)stream, comm->d_boxes, comm->world, comm->rank, comm->seq, local, 2 * c + 1, all);
+    if (mbox_next(comm)) return 3;
+    LGS_KLAUNCH(k_mbox_allgather, 1, 256, 0, (hipStream_t)stream, comm->d_boxes, comm->world, comm->rank, comm->seq, local, 2 * c + 1, all,
+                comm->d_err, comm->timeout_ticks);
     LGS_HIP(hipGetLastError());
   } else {
     LGS_NCCL(rccl().AllGather(local, all, (size_t)(2 * c + 1), kNcclFloat32, comm->comm, (hipStream_t)stream));
@@ -284,8 +336,9 @@ int lgs_bn_backward_sync(lgs_comm *comm, const void *x, const void *y, const voi
                                    stream)))
     return rc;
   if (comm->ipc) {
-    comm->seq += 1;
-    LGS_KLAUNCH(k_mbox_allreduce, 1, 256, 0, (hipStream_t)stream, comm->d_boxes, comm->world, comm->rank, comm->seq, sums, 2 * c);
+    if (mbox_next(comm)) return 3;
+    LGS_KLAUNCH(k_mbox_allreduce, 1, 256, 0, (hipStream_t)stream, comm->d_boxes, comm->world, comm->rank, comm->seq, sums, 2 * c,
+                comm->d_err, comm->timeout_ticks);
     LGS_HIP(hipGetLastError());
   } else {
     LGS_NCCL(rccl().AllReduce(sums, sums, (size_t)(2 * c), kNcclFloat32, kNcclSum, comm->comm, (hipStream_t)stream));

@@ -309,6 +309,9 @@ class FlatSGD:
 
     @torch.no_grad()
     def step(self):
+        # a pending ME result held across the update (me/deferred.py) was recorded with the OLD weights: it runs before they move
+        from .me import deferred as _deferred
+        _deferred.flush_all()
         fused = self.state and self.state[0]["p"].is_cuda
         for b, st in zip(self.ddp.buckets, self.state):
             g = b["flat"]

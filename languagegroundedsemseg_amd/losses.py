@@ -404,12 +404,26 @@ class _ClipCE(torch.autograd.Function):
         return gf, ga, None, None
 
 
+def _ce_like_the_engine(scores, labels, ignore_index, reduction):
+    """torch cross-entropy with the conventions of the engine's fused kernel, so that the result does not depend on which path
+    the gate selects (advisor, round 5): a label outside [0, A) is an ignored row (nn.CrossEntropyLoss raises on it), and the mean
+    over a batch with no counted row is 0 (nn.CrossEntropyLoss returns NaN)."""
+    a = scores.shape[1]
+    lab = torch.where((labels >= 0) & (labels < a) & (labels != ignore_index), labels, torch.full_like(labels, -100))
+    if reduction != "mean":
+        return torch.nn.functional.cross_entropy(scores, lab, ignore_index=-100, reduction=reduction)
+    total = torch.nn.functional.cross_entropy(scores, lab, ignore_index=-100, reduction="sum")
+    return total / (lab != -100).sum().clamp_min(1).to(total.dtype)
+
+
 class ReferenceContrastiveLanguageCELoss(ReferenceContrastiveLanguageLoss):
     """Drop-in for /root/reference/lib/losses/ContrastiveLanguageLoss.py:196-237 (`embedding_loss_type=contrast_ce`,
     lib/train_test/pl_RepresentationTrainer.py:42-43): nn.CrossEntropyLoss(ignore_index, reduction) over the per-voxel
     "distances" to ALL num_labels anchors -- for 'cos' literally normalize(F) . normalize(T)^T in [N, num_labels] (no temperature:
     the reference never applies it), the one dense contraction of the hot path; for 'l2' sqrt(|f - t^|^2 + 1e-7) against the
-    NORMALISED anchors (as written, :208-211,:230).  forward(features, labels, anchor_feats, preds=None) -> (loss, zeros(1), loss)."""
+    NORMALISED anchors (as written, :208-211,:230).  forward(features, labels, anchor_feats, preds=None) -> (loss, zeros(1), loss).
+    Two deliberate conventions, the same on every path (fused kernel, dense fallback, l2): a label outside [0, num_labels) is an
+    ignored row (the reference's nn.CrossEntropyLoss raises), and a batch without a counted row gives 0 (the reference: NaN)."""
 
     def __init__(self, config, num_labels, temperature=0.07, base_temperature=0.07, reduction="mean"):
         super().__init__(config, num_labels, temperature, base_temperature, reduction)
@@ -425,12 +439,12 @@ class ReferenceContrastiveLanguageCELoss(ReferenceContrastiveLanguageLoss):
                 loss = _ClipCE.apply(features, anchor_feats, labels, self.ignore_label)
             else:
                 out = clip_similarity(features, anchor_feats)
-                loss = torch.nn.functional.cross_entropy(out, labels, ignore_index=self.ignore_label, reduction=self.reduction)
+                loss = _ce_like_the_engine(out, labels, self.ignore_label, self.reduction)
         elif self.distance_type == "l2":
             f = features.float()
             t = torch.nn.functional.normalize(anchor_feats.float(), p=2, dim=1)
             d2 = ((f * f).sum(1)[:, None] - 2.0 * (f @ t.t()) + (t * t).sum(1)[None, :]).clamp_min(0)
-            loss = torch.nn.functional.cross_entropy(torch.sqrt(d2 + 1e-7), labels, ignore_index=self.ignore_label, reduction=self.reduction)
+            loss = _ce_like_the_engine(torch.sqrt(d2 + 1e-7), labels, self.ignore_label, self.reduction)
         else:
             raise ValueError("ContrastiveLanguageCELoss supports representation_distance_type 'cos' and 'l2' (:206-220)")
         return loss, torch.zeros(1), loss

@@ -242,7 +242,10 @@ class PackedWeights:
 
 
 def invalidate_packed_weights():
-    """call after writing conv weights behind torch's version counters (`.data` writes, raw-pointer updates)"""
+    """call after writing conv weights behind torch's version counters (`.data` writes, raw-pointer updates).  Recorded ME calls
+    that have not run yet (me/deferred.py) read the weights when they execute: they run first, with the weights of their call."""
+    from . import deferred as _deferred
+    _deferred.flush_all()
     if _PACKED is not None:
         _PACKED.invalidate()
 

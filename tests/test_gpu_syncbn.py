@@ -23,6 +23,7 @@ def _job(rank, world, dtype_name, relu, use_res, ipc=False, layers=1):
     import os
     if ipc:
         os.environ["LGS_SYNCBN_IPC"] = "1"                      # (read when languagegroundedsemseg_amd.tuning.host() is asked)
+        os.environ["LGS_MBOX_ALLOW_COARSE"] = "1"               # both ranks share ONE device: a coarse-grained mailbox is coherent here
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import MinkowskiEngine as ME
     from languagegroundedsemseg_amd.ddp import sync_batch_norm
@@ -101,3 +102,45 @@ def test_fused_sync_bn_two_ranks_match_full_batch(dtype_name, tol, relu, use_res
     assert rel(r0[5] + r1[5], bn.weight.grad) < 5 * tol          # parameter grads stay local: their sum is the full one
     assert rel(r0[6] + r1[6], bn.bias.grad) < 5 * tol
     assert r0[7] == 1 and r1[7] == 1
+
+
+def _diverging_job(rank, world):
+    """rank 1 stops taking part after the first exchange; rank 0's next exchange must give up after LGS_MBOX_TIMEOUT_S and the call
+    after that must fail with a message (advisor, round 5: the mailbox kernel used to spin for ever)"""
+    import os
+    import time
+    os.environ.update(LGS_SYNCBN_IPC="1", LGS_MBOX_ALLOW_COARSE="1", LGS_MBOX_TIMEOUT_S="1.5", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import MinkowskiEngine as ME
+    import torch.distributed as dist
+    from languagegroundedsemseg_amd.ddp import EngineComm, sync_batch_norm
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    mod = ME.MinkowskiSyncBatchNorm(32).to(dev)
+    x = torch.randn(500 + 100 * rank, 32, device=dev)
+    with torch.no_grad():
+        sync_batch_norm(x, mod.bn)                     # both ranks: communicator comes up, one exchange
+    torch.cuda.synchronize()
+    out = None
+    if rank == 0:
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            sync_batch_norm(x, mod.bn)                 # nobody answers: the kernel waits 1.5 s, reports, returns
+        torch.cuda.synchronize()
+        waited = time.perf_counter() - t0
+        try:
+            with torch.no_grad():
+                sync_batch_norm(x, mod.bn)
+            out = ("no error", waited)
+        except RuntimeError as e:
+            out = (str(e), waited)
+    dist.barrier()
+    EngineComm.close_all()
+    return out
+
+
+def test_mailbox_exchange_gives_up_when_the_ranks_diverge():
+    r0, r1 = run_distributed(_diverging_job)
+    assert r1 is None
+    msg, waited = r0
+    assert "timed out" in msg and "diverged" in msg, msg
+    assert 1.0 < waited < 20.0, waited
