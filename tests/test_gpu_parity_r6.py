@@ -208,3 +208,30 @@ def test_toggling_fp32_split_on_a_live_kernel_map_repacks_for_the_new_layout():
     assert float((y1.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, scale)
     assert float((y0.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, scale)
     assert torch.equal(y1, y2)
+
+
+@pytest.mark.parity("torch semantics of zero-row tensors")
+def test_an_empty_batch_flows_through_the_operator_surface():
+    """a collate that dropped every scene (lib/transforms.py:402-412 drops whole scenes over the point limit) hands the model a
+    [0, 4] coordinate tensor: insert, strided maps, 3^3 / 2^3 s2 / transposed / 1x1 convolutions, cat and the losses give zero-row
+    results (BatchNorm in eval mode: batch statistics of nothing are undefined in torch as well), backward runs, nothing is launched
+    with an empty grid"""
+    from languagegroundedsemseg_amd.losses import fused_cross_entropy
+    x = ME.SparseTensor(torch.zeros(0, 3, device=DEV), torch.zeros(0, 4, dtype=torch.int32, device=DEV))
+    assert x.F.shape == (0, 3) and x.C.shape == (0, 4)
+    c0 = ME.MinkowskiConvolution(3, 32, kernel_size=3, dimension=3).to(DEV)
+    dn = ME.MinkowskiConvolution(32, 32, kernel_size=2, stride=2, dimension=3).to(DEV)
+    up = ME.MinkowskiConvolutionTranspose(32, 32, kernel_size=2, stride=2, dimension=3).to(DEV)
+    fin = ME.MinkowskiConvolution(64, 20, kernel_size=1, bias=True, dimension=3).to(DEV)
+    bn = ME.MinkowskiBatchNorm(32).to(DEV).eval()
+    a = bn(c0(x))
+    b = up(dn(a))
+    out = fin(ME.cat(b, a))
+    assert out.F.shape == (0, 20) and out.C.shape == (0, 4)
+    rows = fused_cross_entropy(out.F, torch.zeros(0, dtype=torch.int64, device=DEV), -1, reduction="none")
+    assert rows.shape == (0,)
+    loss = fused_cross_entropy(out.F, torch.zeros(0, dtype=torch.int64, device=DEV), -1)
+    assert float(loss) == 0.0
+    (loss + rows.sum()).backward()
+    for m in (c0, dn, up, fin):
+        assert m.kernel.grad is not None and float(m.kernel.grad.abs().sum()) == 0.0

@@ -9,14 +9,15 @@ mkdir -p $O
 cd $R
 export PYTHONPATH=$R
 if [ -z "$2" ]; then
-  timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
+  timeout 2400 python -m pytest tests -m gpu -q --durations=25 > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 fi
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json
-python bench.py --workload clip --steps 6 --warmup 3 --no-secondary > $O/bench_clip.json 2> $O/bench_clip.err; cut -c1-300 $O/bench_clip.json
+LGS_BENCH_DETAILS=$O/bench_full.json python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json; wc -c $O/bench.json
+LGS_BENCH_DETAILS=$O/bench_clip_full.json python bench.py --workload clip --steps 6 --warmup 3 --no-secondary > $O/bench_clip.json 2> $O/bench_clip.err; cut -c1-300 $O/bench_clip.json
 HOSTTIME_SCENES=1 python tools/hosttime.py > $O/hosttime_1scene.txt 2>&1
 HOSTTIME_SCENES=8 python tools/hosttime.py > $O/hosttime_8scenes.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
+export LGS_BENCH_DETAILS=$O/profiled_run_details.json   # (the profiled runs below: their details are not results)
 # queue timeline: plain kernel trace of the default workload
 timeout 600 rocprofv3 --kernel-trace --output-format rocpd -d $O/prof -o x -- python $R/bench.py --no-cpu-baseline --no-roofline --no-single-scene --no-secondary --steps 20 --warmup 6 > $O/prof.log 2>&1
 DB=$(find $O/prof -name "*.db" | head -1)
