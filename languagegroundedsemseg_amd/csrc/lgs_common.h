@@ -36,7 +36,7 @@ void set_error(const std::string &msg);
 enum Tune {
   T_WW_MIN_ROWS, T_WW_RANGE, T_WGRAD_WIDE, T_BN_FUSED, T_BN_FUSED_MAX_MB, T_BN_FUSED_FWD_MAX_MB, T_BN_FUSED_BLOCKS, T_PS_CUS, T_PS_WIDE3, T_WGRAD_PS,
   T_MASK_WINDOW, T_CONV_SPLIT, T_SMALL_CFG, T_WIDE_GC64, T_ARENA_DBG, T_CONV_WIDE, T_MASK_ORDER,
-  T_BN_FOLD, T_BN_FOLD_MAX_MB, T_BN_FOLD_PARTS, T_BN_FOLD_GRID, T_FP32_SPLIT, T_BLOCK_WGRAD_LATE, T_WGRAD_F32_LDS,
+  T_BN_FOLD, T_BN_FOLD_MAX_MB, T_BN_FOLD_PARTS, T_BN_FOLD_GRID, T_FP32_SPLIT, T_BLOCK_WGRAD_LATE, T_WGRAD_F32_LDS, T_WIDE_SCHED,
   T_COUNT
 };
 int64_t tune(Tune t);                                                   // current value (environment LGS_<NAME> at start, lgs_tuning_set later)

@@ -84,7 +84,7 @@ struct WideIter {
 __global__ __launch_bounds__(512, 2) void k_conv_wide(View v, const bf16_t *__restrict__ in, int cin_real, int nc64,
                                                        const u32x4 *__restrict__ wp, int nb_total, int ncp, int nbp,
                                                        bf16_t *__restrict__ out, int cout_real, const float *__restrict__ bias,
-                                                       unsigned in_bytes, unsigned w_bytes, int in_ld, int gc64, int ny) {
+                                                       unsigned in_bytes, unsigned w_bytes, int in_ld, int gc64, int ny, int sched) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -343,16 +343,22 @@ __global__ __launch_bounds__(512, 2) void k_conv_wide(View v, const bf16_t *__re
     LGS_VMCNT(0);                                                  // this wave's pieces of stage s have landed
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // everybody's have; buffer buf ^ 1 is no longer read
     const uint32_t m4 = __builtin_amdgcn_readlane(stab, cur_slot) & 15u;
+    // where the DMA of stage s+1 goes between the four row blocks of stage s: tuning knob WIDE_SCHED (kernel-uniform branches)
     if (wm == 0) {
-      if (more) issue_w(__builtin_amdgcn_readlane(wtab, it.slot), it.c, buf ^ 1);
+      const int at = sched == 0 || sched == 4 ? 0 : sched == 2 ? 1 : sched == 3 ? 3 : 2;     // weights before block `at`
+      if (more && at == 0) issue_w(__builtin_amdgcn_readlane(wtab, it.slot), it.c, buf ^ 1);
       block0(m4, buf);
+      if (more && at == 1) issue_w(__builtin_amdgcn_readlane(wtab, it.slot), it.c, buf ^ 1);
       block1(m4);
+      if (more && at == 2) issue_w(__builtin_amdgcn_readlane(wtab, it.slot), it.c, buf ^ 1);
       block2(m4);
+      if (more && at == 3) issue_w(__builtin_amdgcn_readlane(wtab, it.slot), it.c, buf ^ 1);
       block3(m4);
     } else {
+      if (more && sched != 0) issue_a(it.slot, __builtin_amdgcn_readlane(stab, it.slot), it.c, buf ^ 1);
       block0(m4, buf);
       block1(m4);
-      if (more) issue_a(it.slot, __builtin_amdgcn_readlane(stab, it.slot), it.c, buf ^ 1);
+      if (more && sched == 0) issue_a(it.slot, __builtin_amdgcn_readlane(stab, it.slot), it.c, buf ^ 1);
       block2(m4);
       block3(m4);
     }
@@ -432,7 +438,7 @@ int launch_conv_wide(const View &v, const void *in, int cin_real, int in_ld, con
   }
   LGS_KLAUNCH(k_conv_wide, dim3(nwg), dim3(512), kWideLds, s, v, reinterpret_cast<const bf16_t *>(in), cin_real, nc64,
               reinterpret_cast<const u32x4 *>(wp), nb_total, ncp, nbp, reinterpret_cast<bf16_t *>(out), cout_real, bias,
-              (unsigned)in_bytes64, (unsigned)w_bytes64, ld, gc64 > 0 ? gc64 : nc64, ny);
+              (unsigned)in_bytes64, (unsigned)w_bytes64, ld, gc64 > 0 ? gc64 : nc64, ny, (int)tune(T_WIDE_SCHED));
   LGS_HIP(hipGetLastError());
   return 0;
 }

@@ -57,6 +57,9 @@ const Knob kKnobs[T_COUNT] = {
                             "beside it (the 96->128 dgrad of block8.0 runs 2.1 x its stand-alone time next to k_wgrad_ps 128->96)"},
     {T_WGRAD_F32_LDS, "WGRAD_F32_LDS", 1, "fp32 weight gradients: 1 = rows staged through LDS with 16-byte loads (k_wgrad_f32_lds; bit-identical "
                                           "partial slabs), 0 = k_wgrad_f32 (one 4-byte load per lane and MFMA operand)"},
+    {T_WIDE_SCHED, "WIDE_SCHED", 0, "k_conv_wide: where the two waves of a SIMD issue the next stage's LDS-DMA between their four row blocks.  0 = "
+                                    "weights first / gathers after block 1 (round 3); 1 = gathers first, weights after block 1; 2 = gathers first, "
+                                    "weights after block 0; 3 = gathers first, weights after block 2; 4 = both first (round 2's schedule)"},
 };
 std::atomic<int64_t> g_val[T_COUNT];
 std::once_flag g_once;

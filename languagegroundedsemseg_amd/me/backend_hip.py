@@ -545,6 +545,8 @@ class HipBackend:
         L = engine.lib()
         x = x.contiguous()
         n, c = x.shape
+        if n == 0:      # what nn.BatchNorm1d (= MinkowskiBatchNorm's `.bn`) says about batch statistics of nothing
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (list(x.shape),))
         dt = _dtype_code(x)
         part, piv = conv_stats if conv_stats is not None else (None, None)
         y_ld = 0
@@ -788,6 +790,8 @@ class HipBackend:
         n, c = x.shape
         with _dev(x.device):
             y, y_ld = self._y_out(x, out_into)
+            if n == 0:                     # an empty batch (a zero-row tensor has no storage to point at): nothing to normalise
+                return y
             res = residual.contiguous() if residual is not None else None
             engine.check(L.lgs_bn_apply(_ptr(x), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(res), int(relu), _ptr(y),
                                         _dtype_code(x), int(y_ld), _stream()))
@@ -854,6 +858,11 @@ class HipBackend:
         dy, dy_ld = self._strided_in(dy, c)
         y, y_ld = self._strided_in(y, c)
         with _dev(x.device):
+            if n == 0:                     # empty batch: zero sums (and zero parameter gradients)
+                for t in (dgamma_out, dbeta_out):
+                    if t is not None:
+                        t.zero_()
+                return torch.zeros(2 * c, dtype=torch.float32, device=x.device)
             sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
             ws = _ws(_bn_ws_bytes(L, n, c), x.device)
             engine.check(L.lgs_bn_backward_reduce(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), int(relu), _ptr(sums),
@@ -870,6 +879,8 @@ class HipBackend:
         with _dev(x.device):
             dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
             dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_residual else None
+            if n == 0:
+                return dx, dres
             engine.check(L.lgs_bn_backward_apply(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(sums),
                                                  0.0 if dev_inv is not None else float(inv_n_total), _ptr(dev_inv), int(relu), _ptr(dx),
                                                  _ptr(dres), _dtype_code(x), int(dy_ld), int(y_ld), _stream()))
@@ -963,6 +974,10 @@ class HipBackend:
         labels = labels.contiguous().to(torch.int64)
         n, c = logits.shape
         dt = _dtype_code(logits)
+        if n == 0:      # empty batch: loss 0 (the convention of the all-ignored batch), an empty gradient
+            one = self._one(logits.device)
+            return (one * 0.0 if grad_scale is None else None), (torch.empty_like(logits) if (want_grad or grad_scale is not None) else None), \
+                (inv_valid if inv_valid is not None else one)
         with _dev(logits.device):
             if inv_valid is None:
                 # the same predicate the kernel uses: a label outside [0, C) is an ignored row, not a counted one
@@ -988,6 +1003,8 @@ class HipBackend:
         logits = logits.contiguous()
         labels = labels.contiguous().to(torch.int64)
         n, c = logits.shape
+        if n == 0:
+            return torch.empty(0, dtype=torch.float32, device=logits.device) if row_grad is None else torch.empty_like(logits)
         with _dev(logits.device):
             one = self._one(logits.device)
             if row_grad is None:

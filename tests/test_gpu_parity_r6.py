@@ -224,6 +224,8 @@ def test_an_empty_batch_flows_through_the_operator_surface():
     up = ME.MinkowskiConvolutionTranspose(32, 32, kernel_size=2, stride=2, dimension=3).to(DEV)
     fin = ME.MinkowskiConvolution(64, 20, kernel_size=1, bias=True, dimension=3).to(DEV)
     bn = ME.MinkowskiBatchNorm(32).to(DEV).eval()
+    with pytest.raises(ValueError, match="more than 1 value per channel"):      # nn.BatchNorm1d's own answer in training mode
+        ME.MinkowskiBatchNorm(32).to(DEV).train()(c0(x)).F
     a = bn(c0(x))
     b = up(dn(a))
     out = fin(ME.cat(b, a))
