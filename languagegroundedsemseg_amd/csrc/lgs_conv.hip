@@ -1012,6 +1012,7 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
                    int transposed_w, int o_real, const float *bias, void *out_v, void *workspace, hipStream_t s,
                    int w_o_real = -1, const BnEpi *bn = nullptr, void *packed_ext = nullptr, int pack_mode = 0, int in_ld = 0) {
   if (w_o_real < 0) w_o_real = o_real;
+  if (v.n_pad == 0) return 0;      // the maps of an empty batch: no row to write (and a 256-byte workspace: nothing is packed)
   LGS_REQUIRE(in_ld == 0 || in_ld == g_real || (g_real % Tr<T>::EPL == 0 && o_real % 4 == 0 && in_ld > g_real && (in_ld * (int)sizeof(T)) % 16 == 0),
               "sparse conv: a strided input needs 16-byte aligned rows and channel counts on the 16-byte grid");
   constexpr int EPL = Tr<T>::EPL, LD = Tr<TK>::WLD;
@@ -1205,6 +1206,9 @@ extern "C" {
 int64_t lgs_conv_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype, int op) {
   if (!km) return -1;
   const int e = esize(dtype);
+  // the maps of an empty batch: no launch plan to size (the planners divide by range and lane counts); the entry points return
+  // before they touch the workspace
+  if (km->fwd.n_pad == 0 && km->bwd.n_pad == 0) return 256;
   if (op == 2) return lgs::wgrad_workspace_bytes(km, cin, cout, dtype);
   int g = op == 0 ? cin : cout, o = op == 0 ? cout : cin;
   // packed weights: fp32 images of the split path hold three bf16 pieces per element (6 instead of 4 bytes)
