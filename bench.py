@@ -861,6 +861,8 @@ def main():
     ap.add_argument("--workload", default="ce", choices=["ce", "clip"],
                     help="ce = BASELINE configs[1] (the headline metric); clip = configs[2], CLIP-contrastive pretrain step "
                          "(scripts/text_representation_train.sh: Res16UNet34D, 512-d text anchors)")
+    ap.add_argument("--settle", type=int, default=15, help="at most this many extra untimed warm-up steps (rounds of five) until two "
+                                                            "rounds agree; 0 = exactly --warmup steps (profiling runs that count steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single-scene", action="store_true", help="skip the secondary 1-scene-per-step measurement")
@@ -968,7 +970,8 @@ def main():
         rl.mode = "roctx"
     if world > 1 or args.dp_world1:
         ddp.enable_timing()
-    res = measure(model, ddp, opt, coords, feats, labels, dtype, args.steps, args.warmup, ctx, clog, world, not args.no_roofline)
+    res = measure(model, ddp, opt, coords, feats, labels, dtype, args.steps, args.warmup, ctx, clog, world, not args.no_roofline,
+                  settle=args.settle)
     dt, loss = res["dt"], res["loss"]
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     nv = torch.tensor([float(n_vox)], dtype=torch.float64, device=device)

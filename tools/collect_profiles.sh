@@ -19,19 +19,19 @@ HOSTTIME_SCENES=8 python tools/hosttime.py > $O/hosttime_8scenes.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 export LGS_BENCH_DETAILS=$O/profiled_run_details.json   # (the profiled runs below: their details are not results)
 # queue timeline: plain kernel trace of the default workload
-timeout 600 rocprofv3 --kernel-trace --output-format rocpd -d $O/prof -o x -- python $R/bench.py --no-cpu-baseline --no-roofline --no-single-scene --no-secondary --steps 20 --warmup 6 > $O/prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format rocpd -d $O/prof -o x -- python $R/bench.py --no-cpu-baseline --no-roofline --no-single-scene --no-secondary --settle 0 --steps 20 --warmup 6 > $O/prof.log 2>&1
 DB=$(find $O/prof -name "*.db" | head -1)
 python $R/tools/prof_timeline.py $DB > $O/queue_timeline.txt 2>&1
 rm -rf $O/prof
 # per-(kernel, grid, shape) statistics: kernel trace + ROCTx ranges around every conv / dgrad / wgrad engine call
 for w in ce clip; do
-  timeout 900 rocprofv3 --kernel-trace --marker-trace --hip-runtime-trace --output-format rocpd -d $O/prof_$w -o x -- python $R/bench.py --workload $w --no-cpu-baseline --no-roofline --no-single-scene --no-secondary --roctx --steps 3 --warmup 3 > $O/prof_$w.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --marker-trace --hip-runtime-trace --output-format rocpd -d $O/prof_$w -o x -- python $R/bench.py --workload $w --no-cpu-baseline --no-roofline --no-single-scene --no-secondary --settle 0 --roctx --steps 3 --warmup 3 > $O/prof_$w.log 2>&1
   DB=$(find $O/prof_$w -name "*.db" | head -1)
   python $R/tools/prof_summary.py $DB 6 > $O/kernel_stats_$w.txt 2>&1
   rm -rf $O/prof_$w
 done
 # the same step with every kernel alone on the machine (weight gradients on the compute stream): stand-alone durations per shape
-timeout 900 env LGS_DBG_WGRAD=inline rocprofv3 --kernel-trace --marker-trace --hip-runtime-trace --output-format rocpd -d $O/prof_sa -o x -- python $R/bench.py --workload ce --no-cpu-baseline --no-roofline --no-single-scene --no-secondary --roctx --steps 3 --warmup 3 > $O/prof_sa.log 2>&1
+timeout 900 env LGS_DBG_WGRAD=inline rocprofv3 --kernel-trace --marker-trace --hip-runtime-trace --output-format rocpd -d $O/prof_sa -o x -- python $R/bench.py --workload ce --no-cpu-baseline --no-roofline --no-single-scene --no-secondary --settle 0 --roctx --steps 3 --warmup 3 > $O/prof_sa.log 2>&1
 DB=$(find $O/prof_sa -name "*.db" | head -1)
 python $R/tools/prof_summary.py $DB 6 > $O/kernel_stats_standalone.txt 2>&1
 rm -rf $O/prof_sa
