@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "liblgs_engine.so")
-SOURCES = ["lgs_manager.hip", "lgs_conv.hip", "lgs_conv_wide.hip", "lgs_wgrad.hip", "lgs_wgrad_wide.hip", "lgs_norm.hip", "lgs_loss.hip", "lgs_voxel.hip", "lgs_cluster.hip", "lgs_tuning.hip", "lgs_block.hip", "lgs_comm.hip"]
+SOURCES = ["lgs_manager.hip", "lgs_conv.hip", "lgs_conv_wide.hip", "lgs_pointwise.hip", "lgs_wgrad.hip", "lgs_wgrad_wide.hip", "lgs_norm.hip", "lgs_loss.hip", "lgs_voxel.hip", "lgs_cluster.hip", "lgs_tuning.hip", "lgs_block.hip", "lgs_comm.hip"]
 HEADERS = ["lgs_common.h", os.path.join("..", "..", "include", "lgs_engine.h")]
 
 

@@ -36,7 +36,7 @@ void set_error(const std::string &msg);
 enum Tune {
   T_WW_MIN_ROWS, T_WW_RANGE, T_WGRAD_WIDE, T_BN_FUSED, T_BN_FUSED_MAX_MB, T_BN_FUSED_FWD_MAX_MB, T_BN_FUSED_BLOCKS, T_PS_CUS, T_PS_WIDE3, T_WGRAD_PS,
   T_MASK_WINDOW, T_CONV_SPLIT, T_SMALL_CFG, T_WIDE_GC64, T_ARENA_DBG, T_CONV_WIDE, T_MASK_ORDER,
-  T_BN_FOLD, T_BN_FOLD_MAX_MB, T_BN_FOLD_PARTS, T_BN_FOLD_GRID, T_FP32_SPLIT, T_BLOCK_WGRAD_LATE, T_WGRAD_F32_LDS, T_WIDE_SCHED,
+  T_BN_FOLD, T_BN_FOLD_MAX_MB, T_BN_FOLD_PARTS, T_BN_FOLD_GRID, T_FP32_SPLIT, T_BLOCK_WGRAD_LATE, T_WGRAD_F32_LDS, T_WIDE_SCHED, T_HEAD_TILE, T_POINTWISE,
   T_COUNT
 };
 int64_t tune(Tune t);                                                   // current value (environment LGS_<NAME> at start, lgs_tuning_set later)
@@ -92,6 +92,10 @@ __device__ inline float ld_elem(const bf16_t *p) { return bf16_to_f32(*p); }
 
 int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype);
 // lgs_conv_wide.hip: 2-D blocked forward / dgrad for >= 256 output channels (bf16); same packed weight image as k_conv_gather's wide tile
+// 1x1 stride-1 convolutions of the big maps as a streaming GEMM (lgs_pointwise.hip)
+bool pointwise_supported(const View &v, int K, int g_real, int o_real, int64_t in_ld);
+int launch_pointwise(const View &v, const void *in, int64_t in_ld, int g_real, const float *w, int cin_w, int cout_w, int transposed,
+                     int o_real, const float *bias, void *out, hipStream_t s);
 int launch_conv_wide(const View &v, const void *in, int cin_real, int in_ld, const void *wp, int nb_total, int ncp, int nbp, int K,
                      void *out, int cout_real, const float *bias, int gc64, hipStream_t s);
 // lgs_wgrad_wide.hip: per-offset dense GEMM over compacted pair lists for >= 256 x 256 channel 3^3 weight gradients (bf16)

@@ -20,6 +20,8 @@
 // both operands so every lane's load is 16 contiguous bytes.
 #include "lgs_common.h"
 
+#include <type_traits>
+
 #include <stdlib.h>
 #include <string.h>
 
@@ -852,7 +854,7 @@ GatherCfg gather_cfg(const View &v, int nb_total) {
   if (big) {
     // 5..7 blocks (e.g. the 200 classes / 200 CLIP anchors = 7 blocks): one 128-position tile spans ALL output
     // channels, so the [N, C] feature matrix is streamed exactly once (dense GEMM with a small N)
-    if (nb_total >= 5 && nb_total <= 7 && v.nbr == nullptr) return {6, kF32 ? 1 : 2, 7, 128};
+    if (nb_total >= 5 && nb_total <= 7 && v.nbr == nullptr && tune(T_HEAD_TILE) == 0) return {6, kF32 ? 1 : 2, 7, 128};
     if (nb_total == 1) return {0, kF32 ? 2 : 4, 1, 256};
     if (nb_total == 2) return {1, kF32 ? 2 : 4, 2, 256};
     if (nb_total == 3 || (nb_total % 3 == 0 && nb_total % 4 != 0)) return {2, kF32 ? 2 : 4, 3, 256};
@@ -1013,6 +1015,12 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
                    int w_o_real = -1, const BnEpi *bn = nullptr, void *packed_ext = nullptr, int pack_mode = 0, int in_ld = 0) {
   if (w_o_real < 0) w_o_real = o_real;
   if (v.n_pad == 0) return 0;      // the maps of an empty batch: no row to write (and a 256-byte workspace: nothing is packed)
+  if constexpr (std::is_same<TK, bf16_t>::value) {
+    // 1x1 layers of the big maps: a streaming GEMM with persistent workgroups (lgs_pointwise.hip), no packed image, no workspace
+    const int64_t ld = in_ld > 0 ? in_ld : g_real;
+    if (!bn && w_o_real == o_real && pointwise_supported(v, K, g_real, o_real, ld))
+      return launch_pointwise(v, in_v, ld, g_real, weight, cin_w, cout_w, transposed_w, o_real, bias, out_v, s);
+  }
   LGS_REQUIRE(in_ld == 0 || in_ld == g_real || (g_real % Tr<T>::EPL == 0 && o_real % 4 == 0 && in_ld > g_real && (in_ld * (int)sizeof(T)) % 16 == 0),
               "sparse conv: a strided input needs 16-byte aligned rows and channel counts on the 16-byte grid");
   constexpr int EPL = Tr<T>::EPL, LD = Tr<TK>::WLD;

@@ -60,6 +60,12 @@ const Knob kKnobs[T_COUNT] = {
     {T_WIDE_SCHED, "WIDE_SCHED", 0, "k_conv_wide: where the two waves of a SIMD issue the next stage's LDS-DMA between their four row blocks.  0 = "
                                     "weights first / gathers after block 1 (round 3); 1 = gathers first, weights after block 1; 2 = gathers first, "
                                     "weights after block 0; 3 = gathers first, weights after block 2; 4 = both first (round 2's schedule)"},
+    {T_HEAD_TILE, "HEAD_TILE", 0, "1x1 layers with 5 - 7 output blocks on the big maps (the 200-class head): 0 = one 128-position tile spans all output "
+                                  "channels (the feature matrix is streamed once; 7 x 16 accumulator registers per wave), 1 = the generic 4-block tile "
+                                  "(two column tiles, features read twice, 3 waves per SIMD)"},
+    {T_POINTWISE, "POINTWISE", 1, "bf16 1x1 stride-1 convolutions (and their dgrads) on maps of >= 65536 positions with <= 224 output channels run on "
+                                  "k_pointwise (persistent streaming GEMM, lgs_pointwise.hip) instead of k_conv_gather's identity-map tiles where that wins (5 - 7 output "
+                                  "blocks, or > 128 reduction channels into 3 blocks: the 200-class head and its dgrad); 2 = every shape it serves; 0 = off (A/B)"},
 };
 std::atomic<int64_t> g_val[T_COUNT];
 std::once_flag g_once;

@@ -76,12 +76,16 @@ def test_wide_weight_gradient_reads_a_column_slice_in_place():
 
 
 @pytest.mark.parametrize("cin,cout,bias,dtype,tol", [(96, 200, True, torch.float32, 2e-5), (96, 200, True, torch.bfloat16, 2e-2),
+                                                      (128, 96, False, torch.bfloat16, 2e-2), (96, 160, True, torch.bfloat16, 2e-2),
                                                       (512, 256, False, torch.bfloat16, 2e-2), (256, 512, False, torch.bfloat16, 2e-2)])
 def test_pointwise_conv_tiles_of_the_big_maps(cin, cout, bias, dtype, tol):
     """1x1 convolutions on maps of >= 65536 positions take tile configurations no small-map test reaches (found by
     tests/test_gpu_dispatch_coverage.py): the 7-block classifier tile (`final`, 96 -> 200 + bias, res16unet.py:193) in fp32 and
     bf16, and the 8-wave 256-channel tile of the representation model's 1x1 downsample branches (clip_models.py:205-215) in both
-    directions (forward 512 -> 256 is its dgrad's 256 -> 512 shape and vice versa)"""
+    directions (forward 512 -> 256 is its dgrad's 256 -> 512 shape and vice versa).  Round 6: the bf16 shapes with <= 224 output
+    channels and >= 5 output blocks (or > 128 reduction channels) run on k_pointwise (lgs_pointwise.hip): 96 -> 200 forward =
+    instance <7, 8>, its dgrad 200 -> 96 = <3, 16>; 96 -> 160 = five output blocks on the seven-block instance, dgrad 160 -> 96;
+    the level-0 downsample branch 128 -> 96 stays on k_conv_gather (as fast there: tools/dbg/pointwise_ab.py)"""
     from languagegroundedsemseg_amd.synthetic import make_batch
     coords, _, _ = make_batch([4], voxel=0.02, n_target=80000)
     assert coords.shape[0] >= 66000

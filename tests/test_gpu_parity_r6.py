@@ -237,3 +237,37 @@ def test_an_empty_batch_flows_through_the_operator_surface():
     (loss + rows.sum()).backward()
     for m in (c0, dn, up, fin):
         assert m.kernel.grad is not None and float(m.kernel.grad.abs().sum()) == 0.0
+
+
+@pytest.mark.parity("the oracle's 1x1 convolution")
+def test_streaming_pointwise_conv_equals_the_gather_kernel_and_reads_column_slices():
+    """k_pointwise (1x1 layers of the big maps, lgs_pointwise.hip) against k_conv_gather's identity-map tiles (POINTWISE=0) on the
+    same tensors -- forward with bias and dgrad, a row count that is not a multiple of 32, an input that is a column slice of a
+    wider buffer (the zero-copy cat hands such slices to the downsample branch) -- and both against the oracle"""
+    from languagegroundedsemseg_amd import engine
+    coords, _, _ = make_batch([4], voxel=0.02, n_target=80000)
+    n = coords.shape[0]
+    assert n >= 66000 and n % 32 != 0
+    torch.manual_seed(1)
+    x = ME.SparseTensor(torch.zeros(n, 3, device=DEV), torch.from_numpy(coords).to(DEV))
+    km = x.coordinate_manager.kernel_map_handle(x.coordinate_map_key, x.coordinate_map_key, 1)
+    wide = torch.randn(n, 160, device=DEV).bfloat16()
+    for cin, cout, sl in ((96, 200, None), (128, 96, slice(32, 160)), (96, 128, slice(0, 96))):
+        f = wide[:, :cin].contiguous() if sl is None else wide[:, sl]
+        w = torch.randn(1, cin, cout, device=DEV) * 0.1
+        b = torch.randn(1, cout, device=DEV)
+        g = torch.randn(n, cout, device=DEV).bfloat16()
+        engine.dispatch_counts(reset=True)
+        with engine.tuning(POINTWISE=2):         # every shape the kernel serves (production keeps the narrow ones on k_conv_gather)
+            y1, d1 = km.conv_forward(f, w, b, False), km.conv_dgrad(g, w, False)
+        sites = engine.dispatch_counts(reset=True)
+        assert sum(v for k, v in sites.items() if k.startswith("k_pointwise")) == 2, sites
+        with engine.tuning(POINTWISE=0):
+            y0, d0 = km.conv_forward(f.contiguous(), w, b, False), km.conv_dgrad(g, w, False)
+            assert not any(k.startswith("k_pointwise") for k in engine.dispatch_counts(reset=True))
+        ref = f.float().cpu() @ w[0].cpu() + b.cpu()
+        dref = g.float().cpu() @ w[0].cpu().t()
+        for got, old, want in ((y1, y0, ref), (d1, d0, dref)):
+            scale = float(want.abs().max())
+            assert float((got.float().cpu() - want).abs().max()) <= 1e-2 * scale          # one bf16 rounding of the result
+            assert float((got.float() - old.float()).abs().max()) <= 1e-2 * scale           # (the two kernels round the same sums)
