@@ -36,77 +36,102 @@ constexpr int kMaxChunks = 4;  // 16-byte chunks per lane per row: C <= 32 * 4 *
 __device__ inline void st_elem(float *p, float v) { *p = v; }
 __device__ inline void st_elem(bf16_t *p, float v) { *p = f32_to_bf16(v); }
 
-template <typename T>
+// Half a wavefront per row; a half-wave takes R consecutive rows and issues the loads of ALL of them before it touches the first
+// (round 6: with one 400-byte row in flight per half-wave the 1.2 M x 200 launch ran at 2.8 TB/s -- 32 waves per CU x 800 bytes is
+// not enough outstanding traffic; Q = 16-byte chunks per lane and row, Q x R = 4 keeps the register count where it was).
+// The arithmetic per row is unchanged (same reduction tree, same order): results are bit-identical to the one-row kernel.
+template <typename T, int Q, int R>
 __global__ __launch_bounds__(256) void k_ce_fwd_bwd(const T *__restrict__ logits, int64_t n, int c, const int64_t *__restrict__ labels,
                                                     int64_t ignore_index, const float *__restrict__ scale_ptr,
                                                     const float *__restrict__ row_scale, float *__restrict__ loss_rows,
                                                     T *__restrict__ dlogits) {
   constexpr int W = LVec<T>::W;
-  const int lane = threadIdx.x & 31;  // half-wave per row
-  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-  if (row >= n) return;
+  const int lane = threadIdx.x & 31;  // half-wave per row group
+  const int64_t row0 = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5) * R;
+  if (row0 >= n) return;
   // class counts that are not a multiple of the 16-byte width (e.g. the 20 ScanNet classes in bf16) take
   // element-wise loads / stores for their rows: kernel-uniform branch, padding lanes hold -inf -> exp = 0
   const bool vec = (c % W) == 0;
   const int nchunk = (c + W - 1) / W;
-  const int64_t lab = labels[row];
-  const bool ignored = (lab == ignore_index) || lab < 0 || lab >= c;
-  float v[kMaxChunks][W];
-  float mx = -3.0e38f;
+  float v[R][Q][W];
+  int64_t labs[R];
 #pragma unroll
-  for (int q = 0; q < kMaxChunks; ++q) {
-    const int ch = q * 32 + lane;
-    if (ch < nchunk) {
-      if (vec) {
-        LVec<T>::load(logits + row * c + ch * W, v[q]);
-      } else {
+  for (int r = 0; r < R; ++r) {
+    const int64_t row = row0 + r;
+    labs[r] = row < n ? labels[row] : -1;
 #pragma unroll
-        for (int i = 0; i < W; ++i) v[q][i] = ch * W + i < c ? ld_elem(logits + row * c + ch * W + i) : -3.0e38f;
-      }
+    for (int q = 0; q < Q; ++q) {
+      const int ch = q * 32 + lane;
+      if (ch < nchunk && row < n) {
+        if (vec) {
+          LVec<T>::load(logits + row * c + ch * W, v[r][q]);
+        } else {
 #pragma unroll
-      for (int i = 0; i < W; ++i) mx = fmaxf(mx, v[q][i]);
-    }
-  }
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 32));
-  float se = 0.f, xl = 0.f;
-#pragma unroll
-  for (int q = 0; q < kMaxChunks; ++q) {
-    const int ch = q * 32 + lane;
-    if (ch < nchunk) {
-#pragma unroll
-      for (int i = 0; i < W; ++i) {
-        const float e = __expf(v[q][i] - mx);
-        se += e;
-        if ((int64_t)(ch * W + i) == lab) xl = v[q][i];
-        v[q][i] = e;
+          for (int i = 0; i < W; ++i) v[r][q][i] = ch * W + i < c ? ld_elem(logits + row * c + ch * W + i) : -3.0e38f;
+        }
       }
     }
   }
+  const float scale0 = dlogits ? *scale_ptr : 0.f;
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) { se += __shfl_xor(se, o, 32); xl += __shfl_xor(xl, o, 32); }
-  const float lse = mx + __logf(se);
-  if (loss_rows && lane == 0) loss_rows[row] = ignored ? 0.f : (lse - xl);
-  if (!dlogits) return;   // loss only (the gradient is produced by a second call in the backward pass)
-  // row_scale: per-row upstream gradient of a reduction='none' loss (balanced category sampling: mask / N), times *scale_ptr
-  const float scale = ignored ? 0.f : (row_scale ? *scale_ptr * row_scale[row] : *scale_ptr);
-  const float inv = scale / se;
+  for (int r = 0; r < R; ++r) {
+    const int64_t row = row0 + r;
+    if (row >= n) break;              // (uniform per half-wave: the shuffles below stay inside it)
+    const int64_t lab = labs[r];
+    const bool ignored = (lab == ignore_index) || lab < 0 || lab >= c;
+    const int lab32 = ignored ? -1 : (int)lab;          // (32-bit compares against compile-time element offsets below)
+    float mx = -3.0e38f;
 #pragma unroll
-  for (int q = 0; q < kMaxChunks; ++q) {
-    const int ch = q * 32 + lane;
-    if (ch < nchunk) {
+    for (int q = 0; q < Q; ++q) {
+      const int ch = q * 32 + lane;
+      if (ch < nchunk) {
 #pragma unroll
-      for (int i = 0; i < W; ++i) {
-        float g = v[q][i] * inv;
-        if ((int64_t)(ch * W + i) == lab) g -= scale;
-        v[q][i] = g;
+        for (int i = 0; i < W; ++i) mx = fmaxf(mx, v[r][q][i]);
       }
-      if (vec) {
-        LVec<T>::store(dlogits + row * c + ch * W, v[q]);
-      } else {
+    }
 #pragma unroll
-        for (int i = 0; i < W; ++i)
-          if (ch * W + i < c) st_elem(dlogits + row * c + ch * W + i, v[q][i]);
+    for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 32));
+    float se = 0.f, xl = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int ch = q * 32 + lane;
+      if (ch < nchunk) {
+        const int rel = lab32 - ch * W;
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+          const float e = __expf(v[r][q][i] - mx);
+          se += e;
+          if (i == rel) xl = v[r][q][i];
+          v[r][q][i] = e;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { se += __shfl_xor(se, o, 32); xl += __shfl_xor(xl, o, 32); }
+    const float lse = mx + __logf(se);
+    if (loss_rows && lane == 0) loss_rows[row] = ignored ? 0.f : (lse - xl);
+    if (!dlogits) continue;   // loss only (the gradient is produced by a second call in the backward pass)
+    // row_scale: per-row upstream gradient of a reduction='none' loss (balanced category sampling: mask / N), times *scale_ptr
+    const float scale = ignored ? 0.f : (row_scale ? scale0 * row_scale[row] : scale0);
+    const float inv = scale / se;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int ch = q * 32 + lane;
+      if (ch < nchunk) {
+        const int rel = lab32 - ch * W;
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+          float g = v[r][q][i] * inv;
+          if (i == rel) g -= scale;
+          v[r][q][i] = g;
+        }
+        if (vec) {
+          LVec<T>::store(dlogits + row * c + ch * W, v[r][q]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < W; ++i)
+            if (ch * W + i < c) st_elem(dlogits + row * c + ch * W + i, v[r][q][i]);
+        }
       }
     }
   }
@@ -195,15 +220,19 @@ extern "C" int lgs_ce_forward_backward_rows(const void *logits, int64_t n, int c
   LGS_REQUIRE(c >= 1 && (c + W - 1) / W <= 32 * kMaxChunks, "lgs_ce_forward_backward: more classes than one half-wave holds (512 fp32 / 1024 bf16)");
   if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  const unsigned blocks = (unsigned)((n * 32 + 255) / 256);
-  if (dtype == LGS_F32)
-    LGS_KLAUNCH((k_ce_fwd_bwd<float>), blocks, 256, 0, s, (const float *)logits, n, c, labels, ignore_index, scale, row_scale, loss_rows,
-                       (float *)dlogits);
-  else if (dtype == LGS_BF16)
-    LGS_KLAUNCH((k_ce_fwd_bwd<bf16_t>), blocks, 256, 0, s, (const bf16_t *)logits, n, c, labels, ignore_index, scale, row_scale, loss_rows,
-                       (bf16_t *)dlogits);
-  else
+  const int nchunk = (c + W - 1) / W, q = (nchunk + 31) / 32;
+  // 8 half-waves per workgroup, R rows per half-wave (Q x R = 4)
+#define LGS_CE_LAUNCH(T_, Q_, R_)                                                                                              \
+  LGS_KLAUNCH((k_ce_fwd_bwd<T_, Q_, R_>), (unsigned)((n + 8 * (R_) - 1) / (8 * (R_))), 256, 0, s, (const T_ *)logits, n, c, labels, \
+              ignore_index, scale, row_scale, loss_rows, (T_ *)dlogits)
+  if (dtype == LGS_F32) {
+    if (q <= 1) LGS_CE_LAUNCH(float, 1, 4); else if (q == 2) LGS_CE_LAUNCH(float, 2, 2); else LGS_CE_LAUNCH(float, 4, 1);
+  } else if (dtype == LGS_BF16) {
+    if (q <= 1) LGS_CE_LAUNCH(bf16_t, 1, 4); else if (q == 2) LGS_CE_LAUNCH(bf16_t, 2, 2); else LGS_CE_LAUNCH(bf16_t, 4, 1);
+  } else {
     LGS_REQUIRE(false, "lgs_ce_forward_backward: unknown dtype");
+  }
+#undef LGS_CE_LAUNCH
   LGS_HIP(hipGetLastError());
   return 0;
 }
