@@ -518,6 +518,32 @@ class EngineComm:
             if c is not None:
                 c.close()
         cls._by_group.clear()
+        _OWN_GROUP.clear()          # (groups of a world that is about to be destroyed)
+
+
+_OWN_GROUP = {}       # default-group object -> the process group SyncBN's torch.distributed collectives use (knob SYNCBN_OWN_GROUP)
+
+
+def syncbn_collective_group(group):
+    """-> the process group SyncBN's statistics exchanges run on.  For the DEFAULT group (group is None: what
+    convert_sync_batchnorm(model) gives every layer, main.py:123) that is a group of the same ranks created once, collectively, at the
+    first exchange -- every rank reaches it at the same program point, the first SyncBN layer of the first forward -- so that the
+    exchanges get their own communicator and stream and never queue behind a gradient bucket's all-reduce on the default group's
+    stream.  A caller-supplied subgroup is used as it is (dist.new_group would need the ranks outside it to take part)."""
+    if group is not None:
+        return group
+    from . import tuning as _tuning
+    knob = _tuning.host("SYNCBN_OWN_GROUP")
+    if knob == 0:
+        return group
+    world = dist.get_world_size()
+    if knob == 1 and (world < 2 or dist.get_backend() != "nccl"):
+        return group
+    key = dist.group.WORLD
+    g = _OWN_GROUP.get(key)
+    if g is None:
+        g = _OWN_GROUP[key] = dist.new_group(ranks=list(range(world)), backend=dist.get_backend())
+    return g
 
 
 def sync_bn_forward(backend, x, weight, bias, residual, running_mean, running_var, nbt, eps, momentum, relu, group, conv_stats=None,
@@ -534,6 +560,7 @@ def sync_bn_forward(backend, x, weight, bias, residual, running_mean, running_va
     # [mean | M2 | count], 2 kernels; the partial sums come from the producing conv's epilogue when it made them
     local = backend.bn_stats(x, conv_stats) if conv_stats is not None else backend.bn_stats(x)
     allst = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=x.device)
+    group = syncbn_collective_group(group)
     if dist.get_backend(group) == "nccl":
         _timed_collective(lambda: dist.all_gather_into_tensor(allst, local, group=group), x.is_cuda)
     else:  # gloo (single-GPU dry runs / CPU tests) has no flat all-gather
@@ -566,6 +593,7 @@ def sync_bn_backward(backend, x, y, dy, weight, bias, stats, inv_n, relu_mode, w
         dx, dres = backend.bn_backward_sync(comm, x, y, dy, weight, bias, stats, inv_n, relu_mode, want_res, dgamma, dbeta)
         return dx, dres, dgamma, dbeta, gview is not None
     sums = backend.bn_backward_reduce(x, y, dy, weight, bias, stats, relu_mode, dgamma, dbeta)
+    group = syncbn_collective_group(group)
     _timed_collective(lambda: dist.all_reduce(sums, group=group), x.is_cuda)
     dx, dres = backend.bn_backward_apply(x, y, dy, weight, bias, stats, sums, inv_n, relu_mode, want_res)
     return dx, dres, dgamma, dbeta, gview is not None
@@ -613,7 +641,7 @@ def sync_batch_norm(x, bn, group=None, residual=None, relu=False, conv_stats=Non
                                   out_into)
     if nbt is not None:
         nbt += 1
-    y = _SyncBNFunction.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, group)
+    y = _SyncBNFunction.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, syncbn_collective_group(group))
     if residual is not None:
         y = y + residual
     if relu:

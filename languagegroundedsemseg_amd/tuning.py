@@ -39,6 +39,11 @@ HOST_KNOBS = {
                            "hipIpc, ONE kernel per exchange that writes to every rank and spins on arrival flags; csrc/lgs_comm.hip) instead of "
                            "RCCL collectives.  Off: visibility of peer stores to a spinning kernel across xGMI has never been exercised (one GPU "
                            "per box); the logic is tested with two processes on one GPU (tests/test_gpu_syncbn.py)"),
+    "SYNCBN_OWN_GROUP": (1, int, "MinkowskiSyncBatchNorm's torch.distributed collectives (the N > 1 default) run on a process group of their own -- "
+                                 "a second communicator and stream -- instead of the default group, whose one RCCL stream also carries the 32 MB "
+                                 "gradient-bucket all-reduces: behind one of those a 800-byte statistics exchange on the backward pass's critical path "
+                                 "waits ~0.2 - 0.3 ms, up to six times per step.  1 = for the default group of an `nccl` world of >= 2 ranks, "
+                                 "2 = for any backend and world size (tests), 0 = off"),
     "SET_HW_QUEUES": (0, int, "1 = importing the package sets GPU_MAX_HW_QUEUES=8 before the HIP runtime starts (see configure_hw_queues)"),
 }
 

@@ -288,3 +288,25 @@ def test_ranks_with_different_unused_parameters_reduce_in_the_same_bucket_order(
         to.step()
     ref = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     assert torch.allclose(p0, ref, atol=1e-6)
+
+
+def _syncbn_own_group_job(rank, world):
+    """LGS_SYNCBN_OWN_GROUP=2: the statistics exchanges of MinkowskiSyncBatchNorm run on a process group of their own (created
+    collectively at the first exchange), next to all-reduces on the default group"""
+    os.environ["LGS_SYNCBN_OWN_GROUP"] = "2"
+    from languagegroundedsemseg_amd import ddp
+    out = _syncbn_job(rank, world)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)                                   # the default group still works beside it
+    groups = list(ddp._OWN_GROUP.values())
+    return out, float(t), len(groups), groups[0] is not dist.group.WORLD and dist.get_world_size(groups[0]) == world
+
+
+def test_sync_batch_norm_on_its_own_process_group_matches_the_default_group():
+    a = run_distributed(_syncbn_job)
+    b = run_distributed(_syncbn_own_group_job)
+    for r in range(2):
+        out, s, n_groups, ok = b[r]
+        assert s == 3.0 and n_groups == 1 and ok
+        for x, y in zip(a[r], out):
+            assert torch.equal(x, y) if torch.is_tensor(x) else x == y

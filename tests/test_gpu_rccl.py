@@ -143,3 +143,48 @@ def test_rccl_collective_paths_with_one_rank_reproduce_the_local_step():
     assert same_rs, "RCCL in-place reduce_scatter_tensor + all_gather_into_tensor of the buckets (world 1) must leave the step bit-identical"
     print("SyncBN over RCCL (world 1) vs local BatchNorm: worst gradient rel-L2 %.3e, running_mean diff %.3e" % (worst, rm))
     assert worst < 2e-2 and rm < 1e-5 and nbt == 2
+
+
+def _own_group_worker(rank, port, ret):
+    """a SECOND RCCL communicator (the process group SyncBN's exchanges get, knob SYNCBN_OWN_GROUP) next to the default group's
+    bucket all-reduces, with a world of one rank: group creation, collectives on both, the result of the local step"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      LGS_SYNCBN_OWN_GROUP="2", LGS_SYNCBN_ENGINE_COMM="0")
+    import torch.distributed as dist
+    import MinkowskiEngine as ME
+    from helpers import Cfg, deterministic_init
+    from languagegroundedsemseg_amd import ddp as ddp_mod
+    from languagegroundedsemseg_amd.ddp import BucketedDDP, FlatSGD
+    from languagegroundedsemseg_amd.models import load_model
+    from languagegroundedsemseg_amd.synthetic import make_batch
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        coords_np, feats_np, _ = make_batch([0, 1], voxel=0.05, n_target=6000)
+        coords, feats = torch.from_numpy(coords_np).to(dev), torch.from_numpy(feats_np).to(dev)
+
+        def run(sync):
+            ME.MinkowskiSyncBatchNorm.force_sync = sync
+            m = deterministic_init(load_model("Res16UNet14A")(3, 20, Cfg()), 42).to(dev).train()
+            if sync:
+                m = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(m)
+            d = BucketedDDP(m, bucket_mb=1.0, force_collectives=sync)
+            return _step(m, d, FlatSGD(d, lr=1e-3), coords, feats, dev)
+        g1, p1, _ = run(True)
+        groups = list(ddp_mod._OWN_GROUP.values())
+        own = len(groups) == 1 and groups[0] is not dist.group.WORLD and dist.get_backend(groups[0]) == "nccl"
+        g0, p0, _ = run(False)
+        worst = max(float((g1[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-12)) for k in g0)
+        ret["own"], ret["worst"], ret["keys"] = own, worst, set(g1) == set(g0)
+    finally:
+        ME.MinkowskiSyncBatchNorm.force_sync = False
+        dist.destroy_process_group()
+
+
+def test_syncbn_exchanges_on_their_own_rccl_group_reproduce_the_local_step():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_own_group_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    assert ret["own"], "SyncBN did not create / use its own process group"
+    assert ret["keys"] and ret["worst"] < 1e-3, ret["worst"]      # one record combined by Chan's formula == the local statistics
