@@ -96,6 +96,9 @@ int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype);
 bool pointwise_supported(const View &v, int K, int g_real, int o_real, int64_t in_ld);
 int launch_pointwise(const View &v, const void *in, int64_t in_ld, int g_real, const float *w, int cin_w, int cout_w, int transposed,
                      int o_real, const float *bias, void *out, hipStream_t s);
+bool pointwise_f32_supported(const View &v, int K, int g_real, int o_real, int64_t in_ld);
+int launch_pointwise_f32(const View &v, const void *in, int64_t in_ld, int g_real, const float *w, int cin_w, int cout_w, int transposed,
+                         int o_real, const float *bias, void *out, hipStream_t s);
 int launch_conv_wide(const View &v, const void *in, int cin_real, int in_ld, const void *wp, int nb_total, int ncp, int nbp, int K,
                      void *out, int cout_real, const float *bias, int gc64, hipStream_t s);
 // lgs_wgrad_wide.hip: per-offset dense GEMM over compacted pair lists for >= 256 x 256 channel 3^3 weight gradients (bf16)

@@ -1053,6 +1053,12 @@ int conv_gather_op(const View &v, const void *in_v, int g_real, const float *wei
     LGS_HIP(hipGetLastError());
     return 0;
   }
+  if constexpr (std::is_same<T, float>::value) {
+    // fp32 1x1 layers of the big maps: streaming GEMM on the exact-fp32 MFMA (k_pointwise_f32), whichever instance multiplies the 3^3 layers
+    const int64_t ld = in_ld > 0 ? in_ld : g_real;
+    if (!bn && w_o_real == o_real && pointwise_f32_supported(v, K, g_real, o_real, ld))
+      return launch_pointwise_f32(v, in_v, ld, g_real, weight, cin_w, cout_w, transposed_w, o_real, bias, out_v, s);
+  }
   const T *in = reinterpret_cast<const T *>(in_v);
   int g_stride = g_real;
   if (g_real % EPL != 0) {  // e.g. the 3-channel colour input of conv0p1s1

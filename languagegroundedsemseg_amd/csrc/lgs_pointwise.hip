@@ -141,6 +141,165 @@ __global__ __launch_bounds__(256, OCC) void k_pointwise(const bf16_t *__restrict
   }
 }
 
+// ---- fp32 (the parity path).  Same structure on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: every product and every sum in fp32,
+// the arithmetic of FP32_SPLIT=0), which at 64 cycles per instruction stays under the memory time of these layers.  The identity-map
+// tiles of k_conv_gather ran them far off the bytes: 96 -> 200 forward 0.80 ms, 200 -> 96 dgrad 1.06, 96 -> 128 dgrad 2.3 ms
+// (profiles/r05_kernel_stats_fp32.txt) for 1.1 - 1.4 GB each; rocBLAS needs 0.34 - 0.72 ms (tools/dbg/gemm_ref.py).
+// A lane's operand piece is a float4 (channels 8 j + 4 h + e): element e of the lanes h = 0 / 1 is the k-pair of MFMA step (j, e).
+// The reduction runs in chunks of 64 channels (eight float4 per lane, two register sets): the next chunk -- of this row block or
+// the first of the next -- is in flight under the current chunk's 32 NB MFMAs.
+template <int NB, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_pointwise_f32(const float *__restrict__ in, int64_t in_ld, int g_real,
+                                                            const float *__restrict__ w, int cin_w, int cout_w, int transposed,
+                                                            int o_real, const float *__restrict__ bias, float *__restrict__ out,
+                                                            int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *l_w = reinterpret_cast<float4 *>(smem);                      // [nj][NB][64]: W[8 j + 4 h + e][32 nb + o], e = 0..3
+  const int nj = (g_real + 7) / 8, nchunk = (nj + 7) / 8;
+  float *l_bias = reinterpret_cast<float *>(smem + (size_t)nj * NB * 64 * 16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vx = lane & 31, h = lane >> 5;
+  for (int idx = tid; idx < nj * NB * 64; idx += 256) {
+    const int ln = idx & 63, nb = (idx >> 6) % NB, j = (idx >> 6) / NB;
+    const int o = nb * 32 + (ln & 31), g0 = j * 8 + (ln >> 5) * 4;
+    float x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int g = g0 + e;
+      x[e] = (g < g_real && o < o_real) ? (transposed ? w[(int64_t)o * cout_w + g] : w[(int64_t)g * cout_w + o]) : 0.f;
+    }
+    l_w[idx] = make_float4(x[0], x[1], x[2], x[3]);
+  }
+  for (int c = tid; c < NB * 32; c += 256) l_bias[c] = (bias && c < o_real) ? bias[c] : 0.f;
+  __syncthreads();
+
+  const int64_t nrb = (n + 31) / 32;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t rb = (int64_t)blockIdx.x * 4 + wave;
+  if (rb >= nrb) return;
+
+  float4 cur[8], nxt[8];
+  auto fetch = [&](int64_t blk, int chunk, float4 (&f)[8]) __attribute__((always_inline)) {
+    const int64_t row = blk * 32 + vx;
+    const float *p = in + row * in_ld + h * 4;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int j = chunk * 8 + jj;
+      f[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < nj && row < n && j * 8 + h * 4 < g_real) f[jj] = *reinterpret_cast<const float4 *>(p + j * 8);
+    }
+  };
+  fetch(rb, 0, cur);
+  int chunk = 0;
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+  while (true) {
+    // what comes after this chunk: the next chunk of the row block, or the first chunk of this wave's next row block
+    const bool last_chunk = chunk + 1 >= nchunk;
+    const int64_t rb_n = last_chunk ? rb + stride : rb;
+    const int chunk_n = last_chunk ? 0 : chunk + 1;
+    const bool more = rb_n < nrb;
+    if (more) fetch(rb_n, chunk_n, nxt);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int j = chunk * 8 + jj;
+      if (j < nj) {
+        const float c4[4] = {cur[jj].x, cur[jj].y, cur[jj].z, cur[jj].w};
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float4 a = l_w[(j * NB + nb) * 64 + lane];
+          const float a4[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], c4[e], acc[nb], 0, 0, 0);
+        }
+      }
+    }
+    if (last_chunk) {
+      // ---- epilogue: lane (voxel vx, half h) owns channels 32 nb + 8 q + 4 h + {0..3} of its row: one 16-byte store each
+      const int64_t row = rb * 32 + vx;
+      if (row < n) {
+        float *dst = out + row * o_real;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c0 = nb * 32 + 8 * q + 4 * h;
+            if (c0 < o_real) {
+              const float4 b = *reinterpret_cast<const float4 *>(l_bias + c0);
+              *reinterpret_cast<float4 *>(dst + c0) = make_float4(acc[nb][4 * q + 0] + b.x, acc[nb][4 * q + 1] + b.y,
+                                                                  acc[nb][4 * q + 2] + b.z, acc[nb][4 * q + 3] + b.w);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    }
+    if (!more) break;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) cur[jj] = nxt[jj];
+    rb = rb_n;
+    chunk = chunk_n;
+  }
+}
+
+constexpr size_t kPwF32MaxLds = 96 * 1024;
+
+bool pointwise_f32_supported(const View &v, int K, int g_real, int o_real, int64_t in_ld) {
+  if (tune(T_POINTWISE) == 0) return false;
+  if (K != 1 || v.KS != 1 || v.nbr || v.out_row || v.tile_k || v.n_in != v.n_out || v.n_out < 65536) return false;
+  if (g_real % 4 != 0 || o_real % 4 != 0 || (in_ld * 4) % 16 != 0) return false;
+  const int nb = (o_real + 31) / 32, nj = (g_real + 7) / 8;
+  if (nb < 3 || nb > 7) return false;
+  const int nbt = nb >= 5 ? 7 : nb;
+  return (size_t)nj * nbt * 64 * 16 + (size_t)nbt * 32 * 4 <= kPwF32MaxLds;
+}
+
+int launch_pointwise_f32(const View &v, const void *in, int64_t in_ld, int g_real, const float *w, int cin_w, int cout_w, int transposed,
+                         int o_real, const float *bias, void *out, hipStream_t s) {
+  const int64_t n = v.n_out;
+  if (n == 0) return 0;
+  LGS_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0,
+              "pointwise conv: feature rows must start 16-byte aligned");
+  const int nb = (o_real + 31) / 32, nj = (g_real + 7) / 8;
+  const int nbt = nb >= 5 ? 7 : nb;
+  const size_t lds = (size_t)nj * nbt * 64 * 16 + (size_t)nbt * 32 * 4;
+  LGS_REQUIRE(lds <= kPwF32MaxLds, "pointwise conv (fp32): weight fragments exceed the LDS budget (internal error)");
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n_cu = p.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const int64_t nrb = (n + 31) / 32;
+  const int occ = lds * 2 <= 156 * 1024 ? 2 : 1;            // workgroups per CU the LDS holds (the register budget allows two)
+  const float *fi = reinterpret_cast<const float *>(in);
+  float *fo = reinterpret_cast<float *>(out);
+#define LGS_PWF_LAUNCH(NB_)                                                                                                       \
+  do {                                                                                                                            \
+    static bool attr = false;                                                                                                     \
+    if (!attr) {                                                                                                                  \
+      LGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pointwise_f32<NB_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwF32MaxLds)); \
+      attr = true;                                                                                                                \
+    }                                                                                                                             \
+    unsigned grid = (unsigned)(occ * n_cu);                                                                                       \
+    if ((int64_t)grid * 4 > nrb) grid = (unsigned)((nrb + 3) / 4);                                                                \
+    LGS_KLAUNCH((k_pointwise_f32<NB_, 2>), grid, 256, lds, s, fi, in_ld, g_real, w, cin_w, cout_w, transposed, o_real, bias, fo, n); \
+  } while (0)
+  if (nbt == 7) LGS_PWF_LAUNCH(7);
+  else if (nbt == 4) LGS_PWF_LAUNCH(4);
+  else LGS_PWF_LAUNCH(3);
+#undef LGS_PWF_LAUNCH
+  LGS_HIP(hipGetLastError());
+  return 0;
+}
+
 // -> true if this launch shape is served (the caller falls back to k_conv_gather otherwise)
 bool pointwise_supported(const View &v, int K, int g_real, int o_real, int64_t in_ld) {
   if (tune(T_POINTWISE) == 0) return false;

@@ -252,11 +252,29 @@ def test_streaming_pointwise_conv_equals_the_gather_kernel_and_reads_column_slic
     x = ME.SparseTensor(torch.zeros(n, 3, device=DEV), torch.from_numpy(coords).to(DEV))
     km = x.coordinate_manager.kernel_map_handle(x.coordinate_map_key, x.coordinate_map_key, 1)
     wide = torch.randn(n, 160, device=DEV).bfloat16()
+    _pointwise_cases(km, n, wide, torch.bfloat16, 1e-2)
+
+
+@pytest.mark.parity("the oracle's 1x1 convolution")
+def test_streaming_pointwise_conv_fp32_on_the_exact_mfma():
+    """k_pointwise_f32 (v_mfma_f32_32x32x2_f32: every product and sum in fp32) against the identity-map tiles of k_conv_gather and
+    against a float64 product: 2e-5 of the result's scale (the per-op bar of the fp32 parity path); same shapes, ragged rows and
+    column slices as the bf16 test"""
+    coords, _, _ = make_batch([4], voxel=0.02, n_target=80000)
+    n = coords.shape[0]
+    torch.manual_seed(2)
+    x = ME.SparseTensor(torch.zeros(n, 3, device=DEV), torch.from_numpy(coords).to(DEV))
+    km = x.coordinate_manager.kernel_map_handle(x.coordinate_map_key, x.coordinate_map_key, 1)
+    _pointwise_cases(km, n, torch.randn(n, 160, device=DEV), torch.float32, 2e-5)
+
+
+def _pointwise_cases(km, n, wide, dtype, tol):
+    from languagegroundedsemseg_amd import engine
     for cin, cout, sl in ((96, 200, None), (128, 96, slice(32, 160)), (96, 128, slice(0, 96))):
         f = wide[:, :cin].contiguous() if sl is None else wide[:, sl]
         w = torch.randn(1, cin, cout, device=DEV) * 0.1
         b = torch.randn(1, cout, device=DEV)
-        g = torch.randn(n, cout, device=DEV).bfloat16()
+        g = torch.randn(n, cout, device=DEV).to(dtype)
         engine.dispatch_counts(reset=True)
         with engine.tuning(POINTWISE=2):         # every shape the kernel serves (production keeps the narrow ones on k_conv_gather)
             y1, d1 = km.conv_forward(f, w, b, False), km.conv_dgrad(g, w, False)
@@ -265,9 +283,10 @@ def test_streaming_pointwise_conv_equals_the_gather_kernel_and_reads_column_slic
         with engine.tuning(POINTWISE=0):
             y0, d0 = km.conv_forward(f.contiguous(), w, b, False), km.conv_dgrad(g, w, False)
             assert not any(k.startswith("k_pointwise") for k in engine.dispatch_counts(reset=True))
-        ref = f.float().cpu() @ w[0].cpu() + b.cpu()
-        dref = g.float().cpu() @ w[0].cpu().t()
+        wq = w[0].to(dtype).double().cpu() if dtype == torch.bfloat16 else w[0].double().cpu()   # (bf16: the kernels multiply bf16 weights)
+        ref = f.double().cpu() @ wq + b.double().cpu()
+        dref = g.double().cpu() @ wq.t()
         for got, old, want in ((y1, y0, ref), (d1, d0, dref)):
             scale = float(want.abs().max())
-            assert float((got.float().cpu() - want).abs().max()) <= 1e-2 * scale          # one bf16 rounding of the result
-            assert float((got.float() - old.float()).abs().max()) <= 1e-2 * scale           # (the two kernels round the same sums)
+            assert float((got.double().cpu() - want).abs().max()) <= tol * scale            # bf16: one rounding of the result
+            assert float((got.float() - old.float()).abs().max()) <= tol * scale            # (the two kernels round the same sums)

@@ -28,15 +28,16 @@ x = ME.SparseTensor(torch.zeros(coords.shape[0], 3, device=DEV), torch.from_nump
 m = x.coordinate_manager
 km = m.kernel_map_handle(x.coordinate_map_key, x.coordinate_map_key, 1)
 n = m.size(x.coordinate_map_key)
+DT = torch.float32 if len(sys.argv) > 1 and sys.argv[1] == "fp32" else torch.bfloat16
 for cin, cout, bias in ((96, 200, True), (128, 96, False), (96, 96, False)):
     torch.manual_seed(0)
-    f = torch.randn(n, cin, device=DEV).bfloat16()
-    g = torch.randn(n, cout, device=DEV).bfloat16()
+    f = torch.randn(n, cin, device=DEV).to(DT)
+    g = torch.randn(n, cout, device=DEV).to(DT)
     w = torch.randn(1, cin, cout, device=DEV) * 0.05
     b = torch.randn(1, cout, device=DEV) if bias else None
-    byts = n * (cin + cout) * 2
+    byts = n * (cin + cout) * f.element_size()
     for rep in range(2):
-        for on in (0, 1):
+        for on in (0, 2):
             with engine.tuning(POINTWISE=on):
                 tf = timeit(lambda: km.conv_forward(f, w, b, False))
                 td = timeit(lambda: km.conv_dgrad(g, w, False))
