@@ -55,8 +55,12 @@ const Knob kKnobs[T_COUNT] = {
                       "0 = the exact-fp32 MFMA instance"},
     {T_BLOCK_WGRAD_LATE, "BLOCK_WGRAD_LATE", 0, "A/B: 1 = lgs_block_backward forks the FIRST convolution's weight gradient after the block's last dgrad instead of "
                             "beside it (the 96->128 dgrad of block8.0 runs 2.1 x its stand-alone time next to k_wgrad_ps 128->96)"},
-    {T_WGRAD_F32_LDS, "WGRAD_F32_LDS", 1, "fp32 weight gradients: 1 = rows staged through LDS with 16-byte loads (k_wgrad_f32_lds; bit-identical "
-                                          "partial slabs), 0 = k_wgrad_f32 (one 4-byte load per lane and MFMA operand)"},
+    {T_WGRAD_F32_LDS, "WGRAD_F32_LDS", 2, "fp32 weight gradients: 2 = rows staged through LDS as three exactly-split bf16 planes, six bf16 MFMAs per 16 pairs "
+                                          "(k_wgrad_f32s_lds; dropped terms < 2^-24 |x g|, fp32 accumulate).  Stand-alone it wins at >= 96 input channels only "
+                                          "(96 -> 96: 3.06 vs 3.38 ms; 32 -> 32: 1.06 vs 0.84), in the STEP it wins everywhere: 82.4 - 82.9 vs 86.1 - 86.7 ms -- it "
+                                          "holds the matrix pipe 2.7 x shorter than the exact-fp32 MFMA and the convolutions on the other stream get it "
+                                          "(round 6); 3 = split only where it also wins stand-alone (83.5 - 83.7 ms); 1 = exact-fp32 MFMA on staged rows "
+                                          "(k_wgrad_f32_lds; bit-identical to 0); 0 = k_wgrad_f32 (one 4-byte load per lane and MFMA operand)"},
     {T_WIDE_SCHED, "WIDE_SCHED", 0, "k_conv_wide: where the two waves of a SIMD issue the next stage's LDS-DMA between their four row blocks.  0 = "
                                     "weights first / gathers after block 1 (round 3); 1 = gathers first, weights after block 1; 2 = gathers first, "
                                     "weights after block 0; 3 = gathers first, weights after block 2; 4 = both first (round 2's schedule)"},

@@ -291,6 +291,184 @@ __host__ __device__ constexpr int tile_stride(int c) {
 
 typedef short short4v __attribute__((ext_vector_type(4)));
 
+// fp32 rows, bf16 products (round 5, knob WGRAD_F32_LDS = 2): k_wgrad_f32_lds's structure -- compacted pairs, rows staged in LDS
+// by the whole workgroup, the next 16 pairs in flight during the multiply -- with every fp32 element split exactly into three bf16
+// pieces (x = hi + mid + lo by truncation, as in k_conv_gather's Tr<f32s_t>) WHEN IT IS STAGED, once per workgroup: three
+// row-major bf16 planes per operand, read back transposed (ds_read_b64_tr_b16, the idiom of k_wgrad_bf16) as 32x32x16 operands.
+// Per 16 pairs and 32 x 32 tile: six bf16 MFMAs (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; 6 x 32 cycles) instead of eight
+// v_mfma_f32_32x32x2_f32 (8 x 64 cycles); dropped terms < 2^-24 |x g|, fp32 accumulation.
+__device__ inline void split3_bf16(float x, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+  const uint32_t h = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(h);                  // exact
+  const uint32_t m = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(m);                 // exact
+  hi = h >> 16; mid = m >> 16; lo = __float_as_uint(r2) >> 16;
+}
+__device__ inline void split3_store(char *plane0, int plane_bytes, int off, const float4 &v4) {
+  uint32_t h[4], m[4], l[4];
+  split3_bf16(v4.x, h[0], m[0], l[0]); split3_bf16(v4.y, h[1], m[1], l[1]);
+  split3_bf16(v4.z, h[2], m[2], l[2]); split3_bf16(v4.w, h[3], m[3], l[3]);
+  *reinterpret_cast<uint2 *>(plane0 + off) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+  *reinterpret_cast<uint2 *>(plane0 + plane_bytes + off) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+  *reinterpret_cast<uint2 *>(plane0 + 2 * plane_bytes + off) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+__device__ inline bf16x8 tr_operand(const char *p0, int row_stride) {
+  short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(p0));
+  short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(p0 + 4 * row_stride));
+  u32x4 pk;
+  pk.x = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+  pk.y = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+  pk.z = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+  pk.w = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+  return __builtin_bit_cast(bf16x8, pk);
+}
+
+template <int NCB>
+__global__ __launch_bounds__(256) void k_wgrad_f32s_lds(View v, const float *__restrict__ in, int cin_real, const float *__restrict__ gout,
+                                                        int cout_real, int cin_pad, int cout_pad, int64_t span,
+                                                        float *__restrict__ partial) {
+  constexpr int PB = 16;                                   // one 32x32x16 k-group of pairs per staged sub-chunk
+  constexpr int SA = tile_stride(128), SG = tile_stride(NCB * 32);   // row pitch (bytes) of the bf16 planes
+  constexpr int PA = PB * SA, PG = PB * SG;                // bytes per plane
+  constexpr int NB4 = NCB * 8;
+  constexpr int NA = PB * 32 / 256, NBQ = (PB * NB4 + 255) / 256;
+  __shared__ int32_t l_in[kWgChunk], l_out[kWgChunk];
+  __shared__ int32_t l_cnt[4];
+  __shared__ __attribute__((aligned(16))) char sA[3 * PA];
+  __shared__ __attribute__((aligned(16))) char sB[3 * PG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vx = lane & 31, h = lane >> 5;
+  const int y = blockIdx.y;
+  const int k = v.K == 27 ? (y == 0 ? 13 : (y & 1) ? 13 - (y + 1) / 2 : 13 + y / 2) : y;     // heavy offsets first (k_wgrad_f32_lds)
+  const int n_cot = cout_pad / (32 * NCB);
+  const int cot = blockIdx.z % n_cot, cig = blockIdx.z / n_cot;
+  const int cib = cig * 4 + wave;
+  const bool wave_active = cib * 32 < cin_pad;
+  const int slot = v.KS > 1 ? k : 0;
+  const int ca0 = cig * 128, cb0 = cot * NCB * 32;
+  // transposing read: 16-lane group g = lane >> 4: cb = g & 1 (16-channel half), pairs 8 (g >> 1) ..; lane i = lane & 15 supplies
+  // the 8-byte address (row 8 (g >> 1) + i / 4 [+ 4], channel 16 cb + 4 (i % 4)) -- see k_wgrad_bf16
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int tr_row = 8 * (g16 >> 1) + (i16 >> 2), tr_col = 16 * (g16 & 1) + 4 * (i16 & 3);
+  const char *pa = sA + tr_row * SA + (32 * wave + tr_col) * 2;
+  const char *pg = sB + tr_row * SG + tr_col * 2;
+
+  f32x16 acc[NCB];
+#pragma unroll
+  for (int nb = 0; nb < NCB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+  float4 ra[NA], rb[NBQ];
+  auto fetch = [&](int sub, int total) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 5, c4 = idx & 31;
+      const int pr = sub * PB + r, ch = ca0 + 4 * c4;
+      ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pr < total && ch < cin_real) ra[u] = *reinterpret_cast<const float4 *>(in + (int64_t)l_in[pr] * cin_real + ch);
+    }
+#pragma unroll
+    for (int u = 0; u < NBQ; ++u) {
+      const int idx = tid + 256 * u, r = idx / NB4, c4 = idx % NB4;
+      const int pr = sub * PB + r, ch = cb0 + 4 * c4;
+      rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < PB * NB4 && pr < total && ch < cout_real) rb[u] = *reinterpret_cast<const float4 *>(gout + (int64_t)l_out[pr] * cout_real + ch);
+    }
+  };
+  auto stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 5, c4 = idx & 31;
+      split3_store(sA, PA, r * SA + 8 * c4, ra[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < NBQ; ++u) {
+      const int idx = tid + 256 * u, r = idx / NB4, c4 = idx % NB4;
+      if (idx < PB * NB4) split3_store(sB, PG, r * SG + 8 * c4, rb[u]);
+    }
+  };
+
+  const int64_t p_begin = (int64_t)blockIdx.x * span;
+  const int64_t p_end = min(p_begin + span, v.n_pad);
+  for (int64_t base = p_begin; base < p_end; base += kWgChunk) {
+    int32_t my_in[2], my_out[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int64_t p = base + wave * 128 + u * 64 + lane;
+      int32_t i = -1, o = -1;
+      if (p < p_end) {
+        bool grp_ok = true;
+        if (v.KS > 1) grp_ok = (v.mask64[p >> 6] >> slot) & 1u;
+        else if (v.tile_k) grp_ok = v.tile_k[p >> 6] == k;
+        if (grp_ok) {
+          o = v.out_row ? v.out_row[p] : (p < v.n_out ? (int32_t)p : -1);
+          i = v.nbr ? v.nbr[(int64_t)slot * v.n_pad + p] : (p < v.n_in ? (int32_t)p : -1);
+        }
+      }
+      my_in[u] = (i >= 0 && o >= 0) ? i : -1;
+      my_out[u] = o;
+    }
+    unsigned long long bal0 = __ballot(my_in[0] >= 0), bal1 = __ballot(my_in[1] >= 0);
+    int c0 = (int)__builtin_popcountll(bal0), c1 = (int)__builtin_popcountll(bal1);
+    if (lane == 0) l_cnt[wave] = c0 + c1;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      int c = l_cnt[w];
+      if (w < wave) wbase += c;
+      total += c;
+    }
+    if (my_in[0] >= 0) {
+      int at = wbase + (int)__builtin_popcountll(bal0 & ((1ull << lane) - 1ull));
+      l_in[at] = my_in[0]; l_out[at] = my_out[0];
+    }
+    if (my_in[1] >= 0) {
+      int at = wbase + c0 + (int)__builtin_popcountll(bal1 & ((1ull << lane) - 1ull));
+      l_in[at] = my_in[1]; l_out[at] = my_out[1];
+    }
+    __syncthreads();
+    const int nsub = (total + PB - 1) / PB;
+    if (nsub > 0) fetch(0, total);
+    for (int sub = 0; sub < nsub; ++sub) {
+      stage();
+      __syncthreads();
+      if (sub + 1 < nsub) fetch(sub + 1, total);
+      if (wave_active) {
+        bf16x8 fa[3], fg[3][NCB];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          fa[p] = tr_operand(pa + p * PA, SA);
+#pragma unroll
+          for (int nb = 0; nb < NCB; ++nb) fg[p][nb] = tr_operand(pg + p * PG + 64 * nb, SG);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NCB; ++nb) {
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fg[1][nb], acc[nb], 0, 0, 0);   // small terms first
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fg[0][nb], acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fg[2][nb], acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fg[0][nb], acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fg[1][nb], acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fg[0][nb], acc[nb], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (!wave_active) return;
+  float *dst = partial + (((int64_t)blockIdx.x * v.K + k) * cin_pad) * cout_pad;
+#pragma unroll
+  for (int nb = 0; nb < NCB; ++nb) {
+    int co = (cot * NCB + nb) * 32 + vx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int ci = cib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      dst[(int64_t)ci * cout_pad + co] = acc[nb][r];
+    }
+  }
+}
+
 // Grid: 1-D.  Workgroup L runs on XCD L % 8 (dispatcher behaviour, used for speed only).  A workgroup owns ONE
 // position range (a few thousand Morton-consecutive voxels: its rows + halo fit the XCD's L2) and its four waves
 // take four different kernel offsets k of that range (or four sub-ranges when K = 1); the offset groups of a range
@@ -1273,12 +1451,18 @@ int conv_wgrad_f32path(const View &v, const void *in_v, int cin, const void *gou
     if (tune(T_WGRAD_F32_LDS) != 0 && cin % 4 == 0 && cout % 4 == 0 && (reinterpret_cast<uintptr_t>(fi) & 15u) == 0 &&
         (reinterpret_cast<uintptr_t>(fg) & 15u) == 0) {
       staged = true;
-      switch (p.ncb) {
-        case 4: LGS_KLAUNCH((k_wgrad_f32_lds<4>), grid, 256, 0, s, v, fi, cin, fg, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
-        case 3: LGS_KLAUNCH((k_wgrad_f32_lds<3>), grid, 256, 0, s, v, fi, cin, fg, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
-        case 2: LGS_KLAUNCH((k_wgrad_f32_lds<2>), grid, 256, 0, s, v, fi, cin, fg, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
-        default: LGS_KLAUNCH((k_wgrad_f32_lds<1>), grid, 256, 0, s, v, fi, cin, fg, cout, p.cin_pad, p.cout_pad, p.span, partial); break;
+#define LGS_WF(KERNEL)                                                                                                          \
+      switch (p.ncb) {                                                                                                         \
+        case 4: LGS_KLAUNCH((KERNEL<4>), grid, 256, 0, s, v, fi, cin, fg, cout, p.cin_pad, p.cout_pad, p.span, partial); break;  \
+        case 3: LGS_KLAUNCH((KERNEL<3>), grid, 256, 0, s, v, fi, cin, fg, cout, p.cin_pad, p.cout_pad, p.span, partial); break;  \
+        case 2: LGS_KLAUNCH((KERNEL<2>), grid, 256, 0, s, v, fi, cin, fg, cout, p.cin_pad, p.cout_pad, p.span, partial); break;  \
+        default: LGS_KLAUNCH((KERNEL<1>), grid, 256, 0, s, v, fi, cin, fg, cout, p.cin_pad, p.cout_pad, p.span, partial); break; \
       }
+      // 2: bf16-split products everywhere; 3: only where they are also faster stand-alone (>= 96 input channels, <= 128 outputs)
+      const int64_t mode = tune(T_WGRAD_F32_LDS);
+      const bool split = mode == 2 || (mode >= 3 && cin >= 96 && cout <= 128);
+      if (split) { LGS_WF(k_wgrad_f32s_lds) } else { LGS_WF(k_wgrad_f32_lds) }
+#undef LGS_WF
     }
   }
   if (!staged) switch (p.ncb) {
