@@ -654,7 +654,9 @@ def secondary_block(workload, model_name, dtype, coords, feats, labels, device, 
     dname = "bf16" if dtype == torch.bfloat16 else "fp32"
     out = {"workload": workload_text("insseg" if workload == "insseg" else workload, model_name),
            "note": note, "dtype": dname, "steps": steps, "warmup": warmup, "voxels_per_step": n_vox, "ms_per_step": ms,
-           "value": n_vox * steps / res["dt"], "unit": "voxels/s", "final_loss": float(res["loss"].item()), "phases": res["phases"]}
+           "value": n_vox * steps / res["dt"], "unit": "voxels/s", "final_loss": float(res["loss"].item()), "phases": res["phases"],
+           "step_ms": dict(step_stats(res["step_ms"]), all=res["step_ms"]), "warmup_extra": res["warmup_extra"]}
+    log("%s %s: %.2f ms/step; per-step %s" % (workload, dname, ms, " ".join("%.1f" % m for m in res["step_ms"])))
     if clog is not None and res["disc"] is not None:
         tp = pmc_traffic(res["disc"]["top"][0][0], args) if (workload == "clip" and dtype == torch.bfloat16) else (None, None)
         out["roofline"] = roofline_report(clog, res["disc"], dname, "clip" if workload == "clip" else ("ce" if workload == "ce" else "insseg"),

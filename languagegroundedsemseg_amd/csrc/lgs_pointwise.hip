@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, OCC) void k_pointwise_f32(const float *__restr
   }
 }
 
-constexpr size_t kPwF32MaxLds = 96 * 1024;
+constexpr size_t kPwF32MaxLds = 144 * 1024;     // (128 -> 192, the level-2 downsample branch's dgrad: 16 x 7 KB of fragments, one workgroup per CU)
 
 bool pointwise_f32_supported(const View &v, int K, int g_real, int o_real, int64_t in_ld) {
   if (tune(T_POINTWISE) == 0) return false;

@@ -77,6 +77,7 @@ def test_wide_weight_gradient_reads_a_column_slice_in_place():
 
 @pytest.mark.parametrize("cin,cout,bias,dtype,tol", [(96, 200, True, torch.float32, 2e-5), (96, 200, True, torch.bfloat16, 2e-2),
                                                       (128, 96, False, torch.bfloat16, 2e-2), (96, 160, True, torch.bfloat16, 2e-2),
+                                                      (192, 128, False, torch.float32, 2e-5), (192, 128, False, torch.bfloat16, 2e-2),
                                                       (512, 256, False, torch.bfloat16, 2e-2), (256, 512, False, torch.bfloat16, 2e-2)])
 def test_pointwise_conv_tiles_of_the_big_maps(cin, cout, bias, dtype, tol):
     """1x1 convolutions on maps of >= 65536 positions take tile configurations no small-map test reaches (found by
