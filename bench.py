@@ -1068,8 +1068,8 @@ def main():
         torch.cuda.empty_cache()
         out["fp32"] = secondary_block("ce", "Res16UNet34C", torch.float32, coords, feats, labels, device, args, clog, steps=6, warmup=5,
                                       note="the parity path (fp32 storage: logits within 1e-3 of the oracle).  Convolution forward / dgrad "
-                                           "multiply on the bf16 matrix pipe with exactly split operands (x = hi + mid + lo, six products, fp32 "
-                                           "accumulate; knob FP32_SPLIT); weight gradients on the exact-fp32 MFMA")
+                                           "and weight gradients multiply on the bf16 matrix pipe with exactly split operands (x = hi + mid + lo, six "
+                                           "products, fp32 accumulate; knobs FP32_SPLIT, WGRAD_F32_LDS); 1x1 layers on the exact-fp32 MFMA")
         from languagegroundedsemseg_amd import engine as _engine
         with _engine.tuning(FP32_SPLIT=0):
             ex = secondary_block("ce", "Res16UNet34C", torch.float32, coords, feats, labels, device, args, None, steps=4, warmup=2,
