@@ -1205,6 +1205,13 @@ inline WgradPlan wgrad_plan(const View &v, int cin, int cout, int dtype) {
     p.S = (int)(lanes > 0 ? lanes : 1);
   } else {
     p.ncb = (nbo % 4 == 0) ? 4 : (nbo % 3 == 0) ? 3 : (nbo % 2 == 0) ? 2 : 1;
+    if (p.ncb == 1 && nbo >= 5) {
+      // 5 or 7 output blocks (the 200-class head: 7): one block per workgroup would stage the input rows seven times over; two
+      // four-block column tiles over a gradient image padded to 8 blocks stage them twice (the reduction drops the padding)
+      p.ncb = 4;
+      p.cout_pad = (nbo + 3) / 4 * 128;
+      per = (int64_t)v.K * p.cin_pad * p.cout_pad * 4;
+    }
     int64_t chunks = (v.n_pad + kWgChunk - 1) / kWgChunk;
     int64_t S = chunks / 4;
     if (S < 1) S = 1;
@@ -1282,7 +1289,7 @@ inline int64_t f32_pad_bytes(const View &v, int cin, int cout) {
 
 int64_t wgrad_workspace_bytes(const lgs_kmap *km, int cin, int cout, int dtype) {
   WgradPlan a = wgrad_plan(km->fwd, cin, cout, dtype), b = wgrad_plan(km->bwd, cin, cout, dtype);
-  int64_t per = (int64_t)km->K * pad32(cin) * pad32(cout) * 4;
+  int64_t per = (int64_t)km->K * pad32(cin) * (a.cout_pad > b.cout_pad ? a.cout_pad : b.cout_pad) * 4;
   int64_t bytes = align256((int64_t)(a.S > b.S ? a.S : b.S) * per) + 256;
   if (dtype == LGS_BF16) {   // position-stationary kernel: forward direction (gathered = in) and transposed (gathered = gout)
     PsPlan f = ps_plan(km->fwd, cin, cout), t = ps_plan(km->fwd, cout, cin);
