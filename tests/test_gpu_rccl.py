@@ -159,7 +159,9 @@ def _own_group_worker(rank, port, ret):
     from languagegroundedsemseg_amd.synthetic import make_batch
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    # device_id as bench.py passes it: the default group's communicator comes up eagerly and dist.new_group() SPLITS it
+    # (ncclCommSplit) instead of initialising a second one from scratch -- the path the N > 1 bench takes
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         coords_np, feats_np, _ = make_batch([0, 1], voxel=0.05, n_target=6000)
         coords, feats = torch.from_numpy(coords_np).to(dev), torch.from_numpy(feats_np).to(dev)
