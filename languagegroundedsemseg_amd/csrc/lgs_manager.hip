@@ -191,7 +191,11 @@ __global__ __launch_bounds__(256) void k_count_levels(const uint64_t *__restrict
   if (threadIdx.x < kPreLevels && l_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], l_cnt[threadIdx.x]);
 }
 
-// 3x3x3 stride-1 map: one thread per sorted position, 27 probes; nbr is offset-major [27][n_pad]
+// 3x3x3 stride-1 map: one thread per sorted position, 27 probes; nbr is offset-major [27][n_pad].
+// Round 6: the probes of one z-plane (nine offsets) are issued TOGETHER -- nine hash slots computed, nine key loads in flight, then
+// the (rare) continued probes, then nine value loads in flight -- instead of 27 dependent load chains one after the other: the
+// kernel is bound by the latency of its random accesses into the 20 - 30 MB table, not by their number (level 0 of the 8-scene
+// batch: 0.87 -> see profiles/r06_experiments.txt).  Same table, same probe sequence per offset: the map is bit-identical.
 __global__ void k_build_map3(const uint64_t *skeys, int64_t n, int64_t n_pad, int ts, const uint64_t *hkeys,
                              const int32_t *hvals, uint64_t capm1, int32_t *nbr, uint32_t *pmask) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // blockDim multiple of 64; p < n_pad by grid
@@ -199,24 +203,41 @@ __global__ void k_build_map3(const uint64_t *skeys, int64_t n, int64_t n_pad, in
   int b = 0, x = 0, y = 0, z = 0;
   if (live) unpack_key(skeys[p], b, x, y, z);
   uint32_t m = 0;
-  for (int k = 0; k < 27; ++k) {
-    int dx = (k % 3 - 1) * ts, dy = ((k / 3) % 3 - 1) * ts, dz = (k / 9 - 1) * ts;
-    int32_t r = -1;
-    if (live) {
-      int xx = x + dx, yy = y + dy, zz = z + dz;
-      if (((unsigned)xx | (unsigned)yy | (unsigned)zz) < (1u << kCoordBits)) {
-        uint64_t key = pack_key(b, xx, yy, zz);
-        uint64_t s = hash64(key) & capm1;
-        for (;;) {
-          uint64_t hk = hkeys[s];
-          if (hk == key) { r = hvals[s]; break; }
-          if (hk == kEmpty) break;
-          s = (s + 1) & capm1;
+#pragma unroll 1
+  for (int g = 0; g < 3; ++g) {
+    uint64_t key[9], slot[9], hk[9];
+    bool ok[9];
+    const int zz = z + (g - 1) * ts;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int xx = x + (j % 3 - 1) * ts, yy = y + (j / 3 - 1) * ts;
+      ok[j] = live && (((unsigned)xx | (unsigned)yy | (unsigned)zz) < (1u << kCoordBits));
+      key[j] = ok[j] ? pack_key(b, xx, yy, zz) : 0ull;
+      slot[j] = hash64(key[j]) & capm1;
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) hk[j] = ok[j] ? hkeys[slot[j]] : kEmpty;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      if (ok[j]) {
+        uint64_t cur = hk[j], sl = slot[j];
+        while (cur != key[j] && cur != kEmpty) {
+          sl = (sl + 1) & capm1;
+          cur = hkeys[sl];
         }
+        slot[j] = sl;
+        ok[j] = cur == key[j];
       }
     }
-    nbr[(int64_t)k * n_pad + p] = r;
-    if (r >= 0) m |= 1u << k;
+    int32_t r[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) r[j] = ok[j] ? hvals[slot[j]] : -1;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int k = 9 * g + j;
+      nbr[(int64_t)k * n_pad + p] = r[j];
+      if (r[j] >= 0) m |= 1u << k;
+    }
   }
   pmask[p] = m;
 }
