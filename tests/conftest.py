@@ -15,6 +15,14 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    # the CPU oracle's per-offset GEMMs are small: on the GPU boxes' many-core hosts torch's default (one thread per core) makes
+    # them several times SLOWER than 16 threads (round 6: the 70 k-voxel oracle steps took 88 s in the full suite and 8 s after a
+    # test that had called set_num_threads(16)); bench.py's cpu_baseline caps at 16 for the same reason
+    try:
+        import torch
+        torch.set_num_threads(min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    except Exception:
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "parity(against): this test compares the HIP path with an INDEPENDENT reference that the "
                                        "automatic detection below cannot see (a module-level golden fixture, a plain-torch "
