@@ -30,6 +30,11 @@ for w in ce clip; do
   python $R/tools/prof_summary.py $DB 6 > $O/kernel_stats_$w.txt 2>&1
   rm -rf $O/prof_$w
 done
+# the fp32 parity path, per launch shape
+timeout 900 rocprofv3 --kernel-trace --marker-trace --hip-runtime-trace --output-format rocpd -d $O/prof_f32 -o x -- python $R/bench.py --dtype fp32 --no-cpu-baseline --no-roofline --no-single-scene --no-secondary --settle 0 --roctx --steps 3 --warmup 3 > $O/prof_f32.log 2>&1
+DB=$(find $O/prof_f32 -name "*.db" | head -1)
+python $R/tools/prof_summary.py $DB 6 > $O/kernel_stats_fp32.txt 2>&1
+rm -rf $O/prof_f32
 # the same step with every kernel alone on the machine (weight gradients on the compute stream): stand-alone durations per shape
 timeout 900 env LGS_DBG_WGRAD=inline rocprofv3 --kernel-trace --marker-trace --hip-runtime-trace --output-format rocpd -d $O/prof_sa -o x -- python $R/bench.py --workload ce --no-cpu-baseline --no-roofline --no-single-scene --no-secondary --settle 0 --roctx --steps 3 --warmup 3 > $O/prof_sa.log 2>&1
 DB=$(find $O/prof_sa -name "*.db" | head -1)
